@@ -1,0 +1,750 @@
+/*
+ * vg_oracle.c -- CPU ORACLE (test infrastructure, NOT product code).  See vg_oracle.h.
+ *
+ * Plain-C restatement of the reference's arithmetic, expression by expression, in the
+ * reference's evaluation order (C/C++ left-to-right for equal precedence; fixed-size matrix
+ * products summed k = 0,1,2).  Build with -O2 -ffp-contract=off and NO fast-math so that
+ * no expression is re-associated or fused.  All paths below are relative to /root/reference.
+ */
+#include "vg_oracle.h"
+
+#include <math.h>
+#include <stddef.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+int vgo_num_intrinsics(int model)
+{
+    switch (model) {
+    case VGO_MODEL_EUCM: return 6;  /* eucm.h:65  INTRINSIC_COUNT */
+    case VGO_MODEL_UCM: return 5;   /* ucm.h:61 */
+    case VGO_MODEL_MEI: return 10;  /* mei.h:70 */
+    default: return -1;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * geometry
+ * ---------------------------------------------------------------------------------------- */
+
+/* Eigen's v.norm() on a 3-vector: sqrt of the sum of squares */
+static double norm3(const double v[3])
+{
+    return sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+}
+
+/* include/geometry/geometry_core.h:24-30 */
+static double sinc_(double x)
+{
+    if (x == 0.) return 1.;
+    return sin(x) / x;
+}
+
+/* include/geometry/geometry_core.h:32-38 */
+static double normalize_angle(double th)
+{
+    if (th > M_PI) return th - 2 * M_PI;
+    else if (th < -M_PI) return th + 2 * M_PI;
+    else return th;
+}
+
+/* include/geometry/quaternion.h:31-50 ; q = (x, y, z, w) */
+void vgo_quat_from_rotvec(const double rot[3], double q[4])
+{
+    double theta = norm3(rot);
+    if (fabs(theta) < 1e-6) {
+        q[0] = rot[0] / 2.;
+        q[1] = rot[1] / 2.;
+        q[2] = rot[2] / 2.;
+        q[3] = 1.;
+    } else {
+        double u0 = rot[0] / theta, u1 = rot[1] / theta, u2 = rot[2] / theta;
+        double s = sin(theta / 2.);
+        q[0] = u0 * s;
+        q[1] = u1 * s;
+        q[2] = u2 * s;
+        q[3] = cos(theta / 2.);
+    }
+}
+
+/* include/geometry/quaternion.h:84-98 */
+void vgo_quat_to_rotvec(const double q[4], double rot[3])
+{
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    double s = sqrt(x * x + y * y + z * z);
+    if (s < 1e-5) {
+        rot[0] = x * 2.;
+        rot[1] = y * 2.;
+        rot[2] = z * 2.;
+    } else {
+        double th = 2. * atan2(s, w);
+        double thn = normalize_angle(th);
+        rot[0] = x / s * thn;
+        rot[1] = y / s * thn;
+        rot[2] = z / s * thn;
+    }
+}
+
+/* include/geometry/quaternion.h:61-82 */
+static void quat_rotate(const double q[4], const double v[3], double out[3])
+{
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    double t1 = w * x;
+    double t2 = w * y;
+    double t3 = w * z;
+    double t4 = -x * x;
+    double t5 = x * y;
+    double t6 = x * z;
+    double t7 = -y * y;
+    double t8 = y * z;
+    double t9 = -z * z;
+    const double v1 = v[0], v2 = v[1], v3 = v[2];
+    out[0] = 2. * ((t7 + t9) * v1 + (t5 - t3) * v2 + (t2 + t6) * v3) + v1;
+    out[1] = 2. * ((t3 + t5) * v1 + (t4 + t9) * v2 + (t8 - t1) * v3) + v2;
+    out[2] = 2. * ((t6 - t2) * v1 + (t1 + t8) * v2 + (t4 + t7) * v3) + v3;
+}
+
+/* include/geometry/quaternion.h:105-118 */
+static void quat_mul(const double a[4], const double b[4], double out[4])
+{
+    const double x = a[0], y = a[1], z = a[2], w = a[3];
+    const double x2 = b[0], y2 = b[1], z2 = b[2], w2 = b[3];
+    double wn = w * w2 - x * x2 - y * y2 - z * z2;
+    double xn = w * x2 + x * w2 + y * z2 - z * y2;
+    double yn = w * y2 - x * z2 + y * w2 + z * x2;
+    double zn = w * z2 + x * y2 - y * x2 + z * w2;
+    out[0] = xn;
+    out[1] = yn;
+    out[2] = zn;
+    out[3] = wn;
+}
+
+/* include/geometry/transformation.h:80-88 ; a, b, out = [t(3), r(3)] (transformation.h:46) */
+void vgo_compose(const double a[6], const double b[6], double out[6])
+{
+    double q1[4], q2[4], qres[4], rt[3];
+    vgo_quat_from_rotvec(a + 3, q1);
+    vgo_quat_from_rotvec(b + 3, q2);
+    quat_rotate(q1, b, rt);
+    double t0 = rt[0] + a[0], t1 = rt[1] + a[1], t2 = rt[2] + a[2];
+    quat_mul(q1, q2, qres);
+    double r[3];
+    vgo_quat_to_rotvec(qres, r);
+    out[0] = t0; out[1] = t1; out[2] = t2;
+    out[3] = r[0]; out[4] = r[1]; out[5] = r[2];
+}
+
+/* include/geometry/transformation.h:101-110 */
+void vgo_compose_inverse(const double a[6], const double b[6], double out[6])
+{
+    double q1[4], q2[4], q2inv[4], qres[4], rt[3];
+    vgo_quat_from_rotvec(a + 3, q1);
+    vgo_quat_from_rotvec(b + 3, q2);
+    q2inv[0] = -q2[0]; q2inv[1] = -q2[1]; q2inv[2] = -q2[2]; q2inv[3] = q2[3]; /* quaternion.h:100-103 */
+    quat_mul(q1, q2inv, qres);
+    quat_rotate(qres, b, rt);
+    double t0 = a[0] - rt[0], t1 = a[1] - rt[1], t2 = a[2] - rt[2];
+    double r[3];
+    vgo_quat_to_rotvec(qres, r);
+    out[0] = t0; out[1] = t1; out[2] = t2;
+    out[3] = r[0]; out[4] = r[1]; out[5] = r[2];
+}
+
+/* include/geometry/geometry_core.h:40-76 ; R row-major 3x3 */
+void vgo_rotation_matrix(const double v[3], double R[9])
+{
+    double th = norm3(v);
+    if (th < 1e-5) {
+        R[0] = 1.;    R[1] = -v[2]; R[2] = v[1];
+        R[3] = v[2];  R[4] = 1.;    R[5] = -v[0];
+        R[6] = -v[1]; R[7] = v[0];  R[8] = 1.;
+    } else {
+        double thInv = 1. / th;
+        double u1 = v[0] * thInv;
+        double u2 = v[1] * thInv;
+        double u3 = v[2] * thInv;
+        double sinth = sin(th);
+        double costhVar = 1. - cos(th);
+
+        R[0] = 1. + costhVar * (u1 * u1 - 1.);
+        R[4] = 1. + costhVar * (u2 * u2 - 1.);
+        R[8] = 1. + costhVar * (u3 * u3 - 1.);
+
+        R[1] = -sinth * u3 + costhVar * u1 * u2;
+        R[2] = sinth * u2 + costhVar * u1 * u3;
+        R[5] = -sinth * u1 + costhVar * u2 * u3;
+
+        R[3] = sinth * u3 + costhVar * u2 * u1;
+        R[6] = -sinth * u2 + costhVar * u3 * u1;
+        R[7] = sinth * u1 + costhVar * u3 * u2;
+    }
+}
+
+/* include/geometry/geometry_core.h:126-132 */
+static void hat_(const double u[3], double M[9])
+{
+    M[0] = 0;     M[1] = -u[2]; M[2] = u[1];
+    M[3] = u[2];  M[4] = 0;     M[5] = -u[0];
+    M[6] = -u[1]; M[7] = u[0];  M[8] = 0;
+}
+
+/* C = A*B, 3x3 row-major, each coefficient summed k = 0,1,2 */
+static void mat3_mul(const double A[9], const double B[9], double C[9])
+{
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+            C[3 * i + j] = A[3 * i + 0] * B[0 + j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+
+/* include/geometry/geometry_core.h:158-180 */
+void vgo_inter_omega_rot(const double v[3], double B[9])
+{
+    double theta = norm3(v);
+    if (theta < 1e-5) {
+        double h0 = v[0] / 2., h1 = v[1] / 2., h2 = v[2] / 2.;
+        B[0] = 1.;  B[1] = -h2; B[2] = h1;
+        B[3] = h2;  B[4] = 1.;  B[5] = -h0;
+        B[6] = -h1; B[7] = h0;  B[8] = 1.;
+    } else {
+        double u[3] = {v[0] / theta, v[1] / theta, v[2] / theta};
+        double uhat[9];
+        hat_(u, uhat);
+        double thetaHalf = theta / 2.;
+        double K1 = sinc_(thetaHalf);
+        K1 = thetaHalf * K1 * K1;
+        double K2 = (1. - sinc_(theta));
+        /* B = Identity + K1*uhat + K2*uhat*uhat  ==  (I + K1*uhat) + ((K2*uhat)*uhat) */
+        double k2u[9], prod[9];
+        for (int i = 0; i < 9; i++) k2u[i] = K2 * uhat[i];
+        mat3_mul(k2u, uhat, prod);
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) {
+                double id = (i == j) ? 1. : 0.;
+                B[3 * i + j] = (id + K1 * uhat[3 * i + j]) + prod[3 * i + j];
+            }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * cameras
+ * ---------------------------------------------------------------------------------------- */
+
+/* EnhancedProjector  include/projection/eucm.h:29-63 */
+static int eucm_project(const double *p, const double X[3], double uv[2])
+{
+    const double alpha = p[0], beta = p[1], fu = p[2], fv = p[3], u0 = p[4], v0 = p[5];
+    const double x = X[0], y = X[1], z = X[2];
+    double denom = alpha * sqrt(z * z + beta * (x * x + y * y)) + (1. - alpha) * z;
+    if (denom < 1e-3) return 0;
+    if (alpha > 0.5) {
+        const double zn = z / denom;
+        const double C = (alpha - 1.) / (alpha + alpha - 1.);
+        if (zn < C) return 0;
+    }
+    const double xn = x / denom;
+    const double yn = y / denom;
+    uv[0] = fu * xn + u0;
+    uv[1] = fv * yn + v0;
+    return 1;
+}
+
+/* EnhancedCamera::projectionJacobian  include/projection/eucm.h:115-167 */
+static int eucm_projection_jacobian(const double *p, const double X[3], double dudx[3], double dvdx[3])
+{
+    const double alpha = p[0], beta = p[1], fu = p[2], fv = p[3];
+    const double x = X[0], y = X[1], z = X[2];
+    double rho = sqrt(z * z + beta * (x * x + y * y));
+    double gamma = 1. - alpha;
+    double eta = alpha * rho + gamma * z;
+
+    int isProjected = 1;
+    if (eta < 1e-3) isProjected = 0;
+    else if (alpha > 0.5) {
+        const double zn = z / eta;
+        const double C = (alpha - 1.) / (alpha + alpha - 1.);
+        if (zn < C) isProjected = 0;
+    }
+    if (!isProjected) {
+        dudx[0] = 0; dudx[1] = 0; dudx[2] = 0;
+        dvdx[0] = 0; dvdx[1] = 0; dvdx[2] = 0;
+        return 0;
+    }
+    double k = 1. / eta / eta;
+    double abrho = alpha * beta / rho;
+    double Jxy = k * abrho * x * y;
+    double Jz = k * (gamma + alpha * z / rho);
+    double Jx = gamma * z + alpha * rho;
+    dudx[0] = fu * k * (Jx - abrho * x * x);
+    dudx[1] = -fu * Jxy;
+    dudx[2] = -fu * x * Jz;
+    dvdx[0] = -fv * Jxy;
+    dvdx[1] = fv * k * (Jx - abrho * y * y);
+    dvdx[2] = -fv * y * Jz;
+    return 1;
+}
+
+/* EnhancedCamera::intrinsicJacobian  include/projection/eucm.h:169-226 */
+static int eucm_intrinsic_jacobian(const double *p, const double X[3], double *du, double *dv)
+{
+    const double alpha = p[0], beta = p[1], fu = p[2], fv = p[3];
+    const double x = X[0], y = X[1], z = X[2];
+    double x2y2 = x * x + y * y;
+    double rho2 = z * z + beta * (x2y2);
+    double rho = sqrt(rho2);
+    double gamma = 1. - alpha;
+    double eta = alpha * rho + gamma * z;
+
+    int isProjected = 1;
+    if (eta < 1e-3) isProjected = 0;
+    else if (alpha > 0.5) {
+        const double zn = z / eta;
+        const double C = (alpha - 1.) / (alpha + alpha - 1.);
+        if (zn < C) isProjected = 0;
+    }
+    if (!isProjected) {
+        for (int i = 0; i < 6; i++) { du[i] = 0; dv[i] = 0; }
+        return 0;
+    }
+    double eta2 = eta * eta;
+    du[0] = -fu * x * (rho - z) / eta2;
+    du[1] = -fu * x * alpha * x2y2 / (2 * eta2 * rho);
+    du[2] = x / eta;
+    du[3] = 0;
+    du[4] = 1;
+    du[5] = 0;
+
+    dv[0] = -fv * y * (rho - z) / eta2;
+    dv[1] = -fv * y * alpha * x2y2 / (2 * eta2 * rho);
+    dv[2] = 0;
+    dv[3] = y / eta;
+    dv[4] = 0;
+    dv[5] = 1;
+    return 1;
+}
+
+/* UnifiedProjector  include/projection/ucm.h:32-59 (never reports failure) */
+static int ucm_project(const double *p, const double X[3], double uv[2])
+{
+    const double xi = p[0], fu = p[1], fv = p[2], u0 = p[3], v0 = p[4];
+    const double x = X[0], y = X[1], z = X[2];
+    double rho = sqrt(z * z + x * x + y * y);
+    double denominv = 1. / (z + xi * rho);
+    double xn = x * denominv;
+    double yn = y * denominv;
+    uv[0] = fu * xn + u0;
+    uv[1] = fv * yn + v0;
+    return 1;
+}
+
+/* the normalized-point Jacobian dm/dX shared verbatim by ucm.h:120-142 and mei.h:136-156 */
+static void unified_dm(double xi, const double X[3], double dm[6], double *xn_, double *yn_,
+                       double *rho_, double *deninv_)
+{
+    const double x = X[0], y = X[1], z = X[2];
+    double xx = x * x;
+    double yy = y * y;
+    double zz = z * z;
+    double rho = sqrt(xx + yy + zz);
+    double rhoinv = 1. / rho;
+    double deninv = 1. / (xi * rho + z);
+    double deninv2 = deninv * deninv;
+    *xn_ = x * deninv;
+    *yn_ = y * deninv;
+    *rho_ = rho;
+    *deninv_ = deninv;
+    dm[0] = (xi * rho + z - xi * xx * rhoinv) * deninv2;
+    dm[1] = -xi * x * y * rhoinv * deninv2;
+    dm[2] = -x * (1 + xi * z * rhoinv) * deninv2;
+    dm[3] = -xi * x * y * rhoinv * deninv2;
+    dm[4] = (xi * rho + z - xi * yy * rhoinv) * deninv2;
+    dm[5] = -y * (1 + xi * z * rhoinv) * deninv2;
+}
+
+/* UnifiedCamera::projectionJacobian  include/projection/ucm.h:112-151 */
+static int ucm_projection_jacobian(const double *p, const double X[3], double dudx[3], double dvdx[3])
+{
+    const double xi = p[0], fu = p[1], fv = p[2];
+    double dm[6], xn, yn, rho, deninv;
+    unified_dm(xi, X, dm, &xn, &yn, &rho, &deninv);
+    for (int j = 0; j < 3; j++) {
+        dudx[j] = fu * dm[j];
+        dvdx[j] = fv * dm[3 + j];
+    }
+    return 1;
+}
+
+/* UnifiedCamera::intrinsicJacobian  include/projection/ucm.h:153-197 */
+static int ucm_intrinsic_jacobian(const double *p, const double X[3], double *du, double *dv)
+{
+    const double xi = p[0], fu = p[1], fv = p[2];
+    const double x = X[0], y = X[1], z = X[2];
+    double xx = x * x;
+    double yy = y * y;
+    double zz = z * z;
+    double rho = sqrt(xx + yy + zz);
+    double deninv = 1. / (xi * rho + z);
+    double xn = x * deninv;
+    double yn = y * deninv;
+    du[0] = -fu * xn * deninv * rho;
+    du[1] = xn;
+    du[2] = 0;
+    du[3] = 1;
+    du[4] = 0;
+    dv[0] = -fv * yn * deninv * rho;
+    dv[1] = 0;
+    dv[2] = yn;
+    dv[3] = 0;
+    dv[4] = 1;
+    return 1;
+}
+
+/* MeiProjector  include/projection/mei.h:29-68 (never reports failure) */
+static int mei_project(const double *p, const double X[3], double uv[2])
+{
+    const double xi = p[0], k1 = p[1], k2 = p[2], k3 = p[3], k4 = p[4], k5 = p[5];
+    const double fu = p[6], fv = p[7], u0 = p[8], v0 = p[9];
+    const double x = X[0], y = X[1], z = X[2];
+    double rho = sqrt(z * z + x * x + y * y);
+    double denominv = 1. / (z + xi * rho);
+    double xn = x * denominv;
+    double yn = y * denominv;
+    double xx = xn * xn, xy = xn * yn, yy = yn * yn;
+    double r2 = xx + yy;
+    double D = 1. + k1 * r2 + k2 * r2 * r2 + k3 * r2 * r2 * r2;
+    double deltax = 2. * k4 * xy + k5 * (r2 + 2. * xx);
+    double deltay = 2. * k5 * xy + k4 * (r2 + 2. * yy);
+    uv[0] = fu * (xn * D + deltax) + u0;
+    uv[1] = fv * (yn * D + deltay) + v0;
+    return 1;
+}
+
+/* distortion Jacobian rows shared by mei.h:158-184 and mei.h:236-247 ; a = fu*dudmn, b = fv*dvdmn */
+static void mei_distortion_rows(const double *p, double xn, double yn, double a[2], double b[2],
+                                double *r2_, double *D_)
+{
+    const double k1 = p[1], k2 = p[2], k3 = p[3], k4 = p[4], k5 = p[5], fu = p[6], fv = p[7];
+    double xxn = xn * xn;
+    double yyn = yn * yn;
+    double xyn = xn * yn;
+    double r2 = yn * yn + xn * xn;
+    double D = 1. + k1 * r2 + k2 * r2 * r2 + k3 * r2 * r2 * r2;
+    double dDdr2 = k1 + 2 * k2 * r2 + 3 * k3 * r2 * r2;
+    a[0] = D + 2 * xxn * dDdr2 + 2 * k4 * yn + 6 * k5 * xn;
+    a[1] = 2 * xyn * dDdr2 + 2 * k4 * xn + 2 * k5 * yn;
+    b[0] = 2 * xyn * dDdr2 + 2 * k5 * yn + 2 * k4 * xn;
+    b[1] = D + 2 * yyn * dDdr2 + 2 * k5 * xn + 6 * k4 * yn;
+    a[0] *= fu; a[1] *= fu;
+    b[0] *= fv; b[1] *= fv;
+    *r2_ = r2;
+    *D_ = D;
+}
+
+/* MeiCamera::projectionJacobian  include/projection/mei.h:121-191 */
+static int mei_projection_jacobian(const double *p, const double X[3], double dudx[3], double dvdx[3])
+{
+    double dm[6], xn, yn, rho, deninv, a[2], b[2], r2, D;
+    unified_dm(p[0], X, dm, &xn, &yn, &rho, &deninv);
+    mei_distortion_rows(p, xn, yn, a, b, &r2, &D);
+    for (int j = 0; j < 3; j++) {
+        dudx[j] = a[0] * dm[j] + a[1] * dm[3 + j]; /* dudmn * jac_m  (1x2 . 2x3) */
+        dvdx[j] = b[0] * dm[j] + b[1] * dm[3 + j];
+    }
+    return 1;
+}
+
+/* MeiCamera::intrinsicJacobian  include/projection/mei.h:193-285 */
+static int mei_intrinsic_jacobian(const double *p, const double X[3], double *du, double *dv)
+{
+    const double xi = p[0], k4 = p[4], k5 = p[5], fu = p[6], fv = p[7];
+    const double x = X[0], y = X[1], z = X[2];
+    double xx = x * x;
+    double yy = y * y;
+    double zz = z * z;
+    double rho = sqrt(xx + yy + zz);
+    double deninv = 1. / (xi * rho + z);
+    double xn = x * deninv;
+    double yn = y * deninv;
+    double xxn = xn * xn;
+    double yyn = yn * yn;
+    double xyn = xn * yn;
+    double a[2], b[2], r2, D;
+    mei_distortion_rows(p, xn, yn, a, b, &r2, &D);
+    double deltax = 2. * k4 * xyn + k5 * (r2 + 2. * xxn);
+    double deltay = 2. * k5 * xyn + k4 * (r2 + 2. * yyn);
+    double xd = xn * D + deltax;
+    double yd = yn * D + deltay;
+    double dxndxi = -xn * deninv * rho;
+    double dyndxi = -yn * deninv * rho;
+
+    du[0] = a[0] * dxndxi + a[1] * dyndxi;
+    du[1] = fu * xn * r2;
+    du[2] = fu * xn * r2 * r2;
+    du[3] = fu * xn * r2 * r2 * r2;
+    du[4] = 2. * fu * xyn;
+    du[5] = fu * (r2 + 2. * xxn);
+    du[6] = xd;
+    du[7] = 0;
+    du[8] = 1;
+    du[9] = 0;
+
+    dv[0] = b[0] * dxndxi + b[1] * dyndxi;
+    dv[1] = fv * yn * r2;
+    dv[2] = fv * yn * r2 * r2;
+    dv[3] = fv * yn * r2 * r2 * r2;
+    dv[4] = fv * (r2 + 2. * yyn);
+    dv[5] = 2. * fv * xyn;
+    dv[6] = 0;
+    dv[7] = yd;
+    dv[8] = 0;
+    dv[9] = 1;
+    return 1;
+}
+
+/* ICamera virtual dispatch  include/projection/generic_camera.h:39-51 */
+int vgo_project_point(int model, const double *intr, const double X[3], double uv[2])
+{
+    switch (model) {
+    case VGO_MODEL_EUCM: return eucm_project(intr, X, uv);
+    case VGO_MODEL_UCM: return ucm_project(intr, X, uv);
+    case VGO_MODEL_MEI: return mei_project(intr, X, uv);
+    default: return 0;
+    }
+}
+
+int vgo_projection_jacobian(int model, const double *intr, const double X[3], double dudx[3], double dvdx[3])
+{
+    switch (model) {
+    case VGO_MODEL_EUCM: return eucm_projection_jacobian(intr, X, dudx, dvdx);
+    case VGO_MODEL_UCM: return ucm_projection_jacobian(intr, X, dudx, dvdx);
+    case VGO_MODEL_MEI: return mei_projection_jacobian(intr, X, dudx, dvdx);
+    default: return 0;
+    }
+}
+
+int vgo_intrinsic_jacobian(int model, const double *intr, const double X[3], double *du, double *dv)
+{
+    switch (model) {
+    case VGO_MODEL_EUCM: return eucm_intrinsic_jacobian(intr, X, du, dv);
+    case VGO_MODEL_UCM: return ucm_intrinsic_jacobian(intr, X, du, dv);
+    case VGO_MODEL_MEI: return mei_intrinsic_jacobian(intr, X, du, dv);
+    default: return 0;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * InterJacobian  include/projection/jacobian.h:136-171
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    double R12[9], M12[9], t13[3];
+} inter_jacobian;
+
+/* ctor  jacobian.h:139-152 */
+static void inter_jacobian_init(inter_jacobian *ij, const double xi13[6], const double xi23[6], int inverted)
+{
+    double Ra[9], Rb[9], negr[3] = {-xi23[3], -xi23[4], -xi23[5]}, M[9];
+    vgo_rotation_matrix(xi13 + 3, Ra); /* xi13.rotMat()    transformation.h:131 */
+    vgo_rotation_matrix(negr, Rb);     /* xi23.rotMatInv() transformation.h:132 */
+    mat3_mul(Ra, Rb, ij->R12);
+    ij->t13[0] = xi13[0]; ij->t13[1] = xi13[1]; ij->t13[2] = xi13[2];
+    vgo_inter_omega_rot(xi23 + 3, M);
+    mat3_mul(ij->R12, M, ij->M12);
+    if (inverted) {
+        for (int i = 0; i < 9; i++) { ij->R12[i] *= -1; ij->M12[i] *= -1; }
+    }
+}
+
+/* dpdxi  jacobian.h:155-171 ; the camera's return value is ignored (jacobian.h:158) */
+static void inter_jacobian_dpdxi(const inter_jacobian *ij, int model, const double *intr,
+                                 const double X1[3], double *dudxi, double *dvdxi)
+{
+    double P[6];
+    vgo_projection_jacobian(model, intr, X1, P, P + 3);
+    double t3X[3] = {X1[0] - ij->t13[0], X1[1] - ij->t13[1], X1[2] - ij->t13[2]};
+    double H[9];
+    hat_(t3X, H);
+    for (int row = 0; row < 2; row++) {
+        const double *p = P + 3 * row;
+        double *out = row == 0 ? dudxi : dvdxi;
+        /* dudtr = projJac.row * R12 */
+        for (int j = 0; j < 3; j++)
+            out[j] = p[0] * ij->R12[0 + j] + p[1] * ij->R12[3 + j] + p[2] * ij->R12[6 + j];
+        /* dudrot = ((-projJac.row) * hat(t3X)) * M12 */
+        double n[3] = {-p[0], -p[1], -p[2]}, tmp[3];
+        for (int j = 0; j < 3; j++) tmp[j] = n[0] * H[0 + j] + n[1] * H[3 + j] + n[2] * H[6 + j];
+        for (int j = 0; j < 3; j++)
+            out[3 + j] = tmp[0] * ij->M12[0 + j] + tmp[1] * ij->M12[3 + j] + tmp[2] * ij->M12[6 + j];
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * GenericProjectionJac::Evaluate  src/calibration/calib_cost_functions.cpp:28-117
+ * ---------------------------------------------------------------------------------------- */
+#define VGO_STACK_POINTS 256
+
+int vgo_eval_block(int model, int L, const int *status, int N, const double *grid, const double *obs,
+                   const double *const *params, double *residual, double **jac)
+{
+    const int K = vgo_num_intrinsics(model);
+    if (K < 0 || L < 0 || L > VGO_MAX_CHAIN || N < 0 || !params || !residual) return 0;
+
+    /* :32-46  xiAcc = Id; compose / composeInverse each chain member */
+    double xiAcc[6] = {0, 0, 0, 0, 0, 0}; /* Transformation() = zeros  transformation.h:36 */
+    for (int l = 0; l < L; l++) {
+        double nxt[6];
+        if (status[l] == VGO_TRANSFORM_DIRECT) vgo_compose(xiAcc, params[1 + l], nxt);
+        else if (status[l] == VGO_TRANSFORM_INVERSE) vgo_compose_inverse(xiAcc, params[1 + l], nxt);
+        else return 0;
+        memcpy(xiAcc, nxt, sizeof nxt);
+    }
+
+    /* :49-50  pointCam = R(xiAcc.rot) * grid + xiAcc.trans   transformation.h:147-155,180-188 */
+    double R[9];
+    vgo_rotation_matrix(xiAcc + 3, R);
+
+    const double *intr = params[0]; /* :53-54 setParameters */
+
+    /* the reference keeps pointCamVec; recomputing X per use gives bit-identical values */
+#define POINT_CAM(i, X)                                                                            \
+    do {                                                                                           \
+        const double *g_ = grid + 3 * (i);                                                         \
+        (X)[0] = (R[0] * g_[0] + R[1] * g_[1] + R[2] * g_[2]) + xiAcc[0];                          \
+        (X)[1] = (R[3] * g_[0] + R[4] * g_[1] + R[5] * g_[2]) + xiAcc[1];                          \
+        (X)[2] = (R[6] * g_[0] + R[7] * g_[1] + R[8] * g_[2]) + xiAcc[2];                          \
+    } while (0)
+
+    /* :57-71 residuals */
+    for (int i = 0; i < N; i++) {
+        double X[3], uv[2];
+        POINT_CAM(i, X);
+        if (vgo_project_point(model, intr, X, uv)) {
+            residual[2 * i] = uv[0] - obs[2 * i];
+            residual[2 * i + 1] = uv[1] - obs[2 * i + 1];
+        } else {
+            residual[2 * i] = VGO_DOUBLE_BIG;
+            residual[2 * i + 1] = VGO_DOUBLE_BIG;
+        }
+    }
+
+    if (jac != NULL) {
+        /* :76-103 second chain walk */
+        double acc[6] = {0, 0, 0, 0, 0, 0};
+        for (int l = 0; l < L; l++) {
+            const double *xi23 = params[1 + l];
+            double xi13[6], nxt[6];
+            int inverted = status[l] == VGO_TRANSFORM_INVERSE;
+            if (!inverted) {
+                vgo_compose(acc, xi23, nxt);
+                memcpy(acc, nxt, sizeof nxt);
+                memcpy(xi13, acc, sizeof acc);
+            } else {
+                memcpy(xi13, acc, sizeof acc);
+                vgo_compose_inverse(acc, xi23, nxt);
+                memcpy(acc, nxt, sizeof nxt);
+            }
+            if (jac[1 + l] != NULL) {
+                inter_jacobian ij;
+                inter_jacobian_init(&ij, xi13, xi23, inverted);
+                for (int i = 0; i < N; i++) {
+                    double X[3];
+                    POINT_CAM(i, X);
+                    inter_jacobian_dpdxi(&ij, model, intr, X, jac[1 + l] + i * 12, jac[1 + l] + i * 12 + 6);
+                }
+            }
+        }
+        /* :105-114 intrinsic Jacobian */
+        if (jac[0] != NULL) {
+            for (int i = 0; i < N; i++) {
+                double X[3];
+                POINT_CAM(i, X);
+                vgo_intrinsic_jacobian(model, intr, X, jac[0] + (size_t)i * 2 * K, jac[0] + ((size_t)i * 2 + 1) * K);
+            }
+        }
+    }
+#undef POINT_CAM
+    return 1; /* :116 */
+}
+
+long vgo_eval_dataset(int model, int L, const int *status, int N, const double *grid, long n_blocks,
+                      const double *obs, const double *param_vec, long intr_offset,
+                      const long *member_base, const long *member_stride, const long *seq_index,
+                      double *residuals, double *jac_intr, double *const *jac_member, int threads)
+{
+    const int K = vgo_num_intrinsics(model);
+    if (K < 0 || L < 0 || L > VGO_MAX_CHAIN) return 0;
+    long done = 0;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) reduction(+ : done) num_threads(threads > 1 ? threads : 1)
+#endif
+    for (long b = 0; b < n_blocks; b++) {
+        const double *params[1 + VGO_MAX_CHAIN];
+        double *jac[1 + VGO_MAX_CHAIN];
+        params[0] = param_vec + intr_offset;
+        jac[0] = jac_intr ? jac_intr + (size_t)b * 2 * N * K : NULL;
+        for (int l = 0; l < L; l++) {
+            params[1 + l] = param_vec + member_base[l] + member_stride[l] * seq_index[b];
+            jac[1 + l] = (jac_member && jac_member[l]) ? jac_member[l] + (size_t)b * 2 * N * 6 : NULL;
+        }
+        int want_jac = jac_intr != NULL || jac_member != NULL;
+        done += vgo_eval_block(model, L, status, N, grid, obs + (size_t)b * 2 * N, params,
+                               residuals + (size_t)b * 2 * N, want_jac ? jac : NULL);
+    }
+    return done;
+}
+
+/* column c of the stacked row block [J_0 | J_1 .. J_L | r], row `row` */
+static double stacked_entry(int K, int L, int row, int c, const double *residual,
+                            const double *jac_intr, const double *const *jac_member)
+{
+    if (c < K) return jac_intr[(size_t)row * K + c];
+    c -= K;
+    if (c < 6 * L) return jac_member[c / 6][(size_t)row * 6 + c % 6];
+    return residual[row];
+}
+
+void vgo_block_gram(int K, int L, int N, const double *residual, const double *jac_intr,
+                    const double *const *jac_member, double *gram)
+{
+    const int W = K + 6 * L + 1;
+    for (int a = 0; a < W; a++)
+        for (int b = a; b < W; b++) {
+            long double s = 0.0L;
+            for (int row = 0; row < 2 * N; row++)
+                s += (long double)stacked_entry(K, L, row, a, residual, jac_intr, jac_member) *
+                     (long double)stacked_entry(K, L, row, b, residual, jac_intr, jac_member);
+            gram[a * W + b] = (double)s;
+            gram[b * W + a] = (double)s;
+        }
+}
+
+void vgo_block_gram_fast(int K, int L, int N, const double *residual, const double *jac_intr,
+                         const double *const *jac_member, double *gram)
+{
+    const int W = K + 6 * L + 1;
+    double row_buf[10 + 6 * VGO_MAX_CHAIN + 1];
+    for (int i = 0; i < W * W; i++) gram[i] = 0.;
+    for (int row = 0; row < 2 * N; row++) {
+        for (int c = 0; c < W; c++) row_buf[c] = stacked_entry(K, L, row, c, residual, jac_intr, jac_member);
+        for (int a = 0; a < W; a++) {
+            const double va = row_buf[a];
+            for (int b = a; b < W; b++) gram[a * W + b] += va * row_buf[b];
+        }
+    }
+    for (int a = 0; a < W; a++)
+        for (int b = a + 1; b < W; b++) gram[b * W + a] = gram[a * W + b];
+}
+
+int vgo_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

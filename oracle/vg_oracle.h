@@ -1,0 +1,99 @@
+/*
+ * vg_oracle.h -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * A plain-C restatement of visgeom's calibration hot path
+ *   GenericProjectionJac::Evaluate   src/calibration/calib_cost_functions.cpp:28-117
+ * and of the headers it calls (geometry, quaternion, EUCM/UCM/Mei, InterJacobian).
+ * Every function in vg_oracle.c cites the reference file:line it follows.
+ *
+ * Who may use it: tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg -- as the CHECKER / reported CPU baseline only.  The product path
+ * (visgeom_amd/, include/visgeom_amd.h) never links, imports or calls this.
+ *
+ * Pinning status: the reference needs Eigen3 + Ceres (absent in this image, no
+ * network) so it cannot be compiled here without writing stand-in headers, which
+ * this build does not do.  The oracle is pinned against the known answers that
+ * the reference's own code produced at survey time (SURVEY.md Appendix C,
+ * transcribed to tests/golden/survey_appendix_c.json), and cross-checked against
+ * central differences and an independent float64 autograd formulation
+ * (tests/test_oracle_*.py).  Anything Appendix C does not exercise is
+ * "parity unpinned" -- see DESIGN.md section 3.
+ */
+#ifndef VG_ORACLE_H
+#define VG_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VGO_MODEL_EUCM 0 /* [alpha,beta,fu,fv,u0,v0]            include/projection/eucm.h  */
+#define VGO_MODEL_UCM 1  /* [xi,fu,fv,u0,v0]                    include/projection/ucm.h   */
+#define VGO_MODEL_MEI 2  /* [xi,k1,k2,k3,k4,k5,fu,fv,u0,v0]     include/projection/mei.h   */
+
+#define VGO_TRANSFORM_DIRECT 0  /* include/calibration/calib_cost_functions.h:25 */
+#define VGO_TRANSFORM_INVERSE 1
+
+#define VGO_MAX_CHAIN 5    /* src/calibration/unified_calibration.cpp:566-567 */
+#define VGO_DOUBLE_BIG 1e15 /* include/std.h:71 */
+
+/* number of intrinsics of a model (6 / 5 / 10), -1 if unknown */
+int vgo_num_intrinsics(int model);
+
+/* ---- geometry primitives, exported so tests can pin each branch ---- */
+void vgo_quat_from_rotvec(const double rot[3], double q[4]);          /* quaternion.h:31-50  */
+void vgo_quat_to_rotvec(const double q[4], double rot[3]);            /* quaternion.h:84-98  */
+void vgo_compose(const double a[6], const double b[6], double out[6]);        /* transformation.h:80-88   */
+void vgo_compose_inverse(const double a[6], const double b[6], double out[6]); /* transformation.h:101-110 */
+void vgo_rotation_matrix(const double v[3], double R[9]);             /* geometry_core.h:40-76   */
+void vgo_inter_omega_rot(const double v[3], double M[9]);             /* geometry_core.h:158-180 */
+
+/* ---- camera primitives: return 1 when projected, 0 when the reference returns false ---- */
+int vgo_project_point(int model, const double *intr, const double X[3], double uv[2]);
+int vgo_projection_jacobian(int model, const double *intr, const double X[3], double dudx[3], double dvdx[3]);
+int vgo_intrinsic_jacobian(int model, const double *intr, const double X[3], double *du, double *dv);
+
+/*
+ * 1:1 restatement of GenericProjectionJac::Evaluate (calib_cost_functions.cpp:28-117).
+ *   params[0]    -> K intrinsics, params[1+l] -> [tx,ty,tz,rx,ry,rz] of chain member l
+ *   residual     -> 2N doubles, [u0,v0,u1,v1,...]; failed projection -> 1e15 pair
+ *   jac          -> NULL, or L+1 pointers, each NULL or row-major [2N x blocksize]
+ * Returns 1 (the reference always returns true) or 0 on invalid arguments.
+ */
+int vgo_eval_block(int model, int L, const int *status, int N, const double *grid /*3N*/,
+                   const double *obs /*2N*/, const double *const *params, double *residual,
+                   double **jac);
+
+/*
+ * Batched convenience used by the CPU-baseline leg: n_blocks independent blocks that
+ * share one camera and one chain shape.  Parameter pointers are given per block through
+ * an index table:  member l of block b lives at  param_vec + member_base[l] + member_stride[l]*seq_index[b].
+ * Outputs use the Ceres block layout, block after block:
+ *   residuals [n_blocks][2N],  jac_intr [n_blocks][2N][K],  jac_member[l] [n_blocks][2N][6].
+ * threads <= 1 -> serial; otherwise OpenMP over blocks.  Returns number of blocks evaluated.
+ */
+long vgo_eval_dataset(int model, int L, const int *status, int N, const double *grid,
+                      long n_blocks, const double *obs /*[n_blocks][2N]*/,
+                      const double *param_vec, long intr_offset, const long *member_base,
+                      const long *member_stride, const long *seq_index,
+                      double *residuals, double *jac_intr, double *const *jac_member,
+                      int threads);
+
+/*
+ * Per-block Gram of the stacked row block [J_0 | J_1 | ... | J_L | r]  (2N x (P+1), P = K + 6L):
+ *   gram[(P+1)*(P+1)] row-major, full symmetric matrix, accumulated in long double.
+ * This is the mathematical definition the normal-equation kernels are checked against
+ * ("How parity is then defined").
+ */
+void vgo_block_gram(int K, int L, int N, const double *residual, const double *jac_intr,
+                    const double *const *jac_member, double *gram);
+
+/* same, plain double accumulation in row order (the CPU-baseline variant that is timed) */
+void vgo_block_gram_fast(int K, int L, int N, const double *residual, const double *jac_intr,
+                         const double *const *jac_member, double *gram);
+
+int vgo_max_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

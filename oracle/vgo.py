@@ -1,0 +1,199 @@
+"""ctypes binding of the CPU ORACLE (oracle/vg_oracle.c).
+
+TEST INFRASTRUCTURE ONLY.  Importable from tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py -- never from visgeom_amd/ (the product path).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libvg_oracle.so")
+
+MODEL_EUCM, MODEL_UCM, MODEL_MEI = 0, 1, 2
+MODELS = {"eucm": MODEL_EUCM, "ucm": MODEL_UCM, "mei": MODEL_MEI}
+NUM_INTRINSICS = {MODEL_EUCM: 6, MODEL_UCM: 5, MODEL_MEI: 10}
+DIRECT, INVERSE = 0, 1
+DOUBLE_BIG = 1e15
+
+_dp = ctypes.POINTER(ctypes.c_double)
+_dpp = ctypes.POINTER(_dp)
+_ip = ctypes.POINTER(ctypes.c_int)
+_lp = ctypes.POINTER(ctypes.c_long)
+
+
+def build(force=False):
+    """Compile oracle/libvg_oracle.so with the committed Makefile (gcc only)."""
+    src = os.path.join(_HERE, "vg_oracle.c")
+    if (not force and os.path.exists(_LIB_PATH)
+            and os.path.getmtime(_LIB_PATH) >= os.path.getmtime(src)):
+        return _LIB_PATH
+    subprocess.check_call(["make", "-C", _HERE, "-B", "libvg_oracle.so"],
+                          stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(_LIB_PATH)
+        L.vgo_eval_block.restype = ctypes.c_int
+        L.vgo_eval_block.argtypes = [ctypes.c_int, ctypes.c_int, _ip, ctypes.c_int, _dp, _dp,
+                                     _dpp, _dp, _dpp]
+        L.vgo_eval_dataset.restype = ctypes.c_long
+        L.vgo_eval_dataset.argtypes = [ctypes.c_int, ctypes.c_int, _ip, ctypes.c_int, _dp,
+                                       ctypes.c_long, _dp, _dp, ctypes.c_long, _lp, _lp, _lp,
+                                       _dp, _dp, _dpp, ctypes.c_int]
+        L.vgo_block_gram.restype = None
+        L.vgo_block_gram.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp, _dp, _dpp, _dp]
+        L.vgo_block_gram_fast.restype = None
+        L.vgo_block_gram_fast.argtypes = L.vgo_block_gram.argtypes
+        for name in ("vgo_compose", "vgo_compose_inverse"):
+            f = getattr(L, name)
+            f.restype = None
+            f.argtypes = [_dp, _dp, _dp]
+        for name in ("vgo_rotation_matrix", "vgo_inter_omega_rot", "vgo_quat_from_rotvec",
+                     "vgo_quat_to_rotvec"):
+            f = getattr(L, name)
+            f.restype = None
+            f.argtypes = [_dp, _dp]
+        L.vgo_project_point.restype = ctypes.c_int
+        L.vgo_project_point.argtypes = [ctypes.c_int, _dp, _dp, _dp]
+        L.vgo_projection_jacobian.restype = ctypes.c_int
+        L.vgo_projection_jacobian.argtypes = [ctypes.c_int, _dp, _dp, _dp, _dp]
+        L.vgo_intrinsic_jacobian.restype = ctypes.c_int
+        L.vgo_intrinsic_jacobian.argtypes = [ctypes.c_int, _dp, _dp, _dp, _dp]
+        L.vgo_max_threads.restype = ctypes.c_int
+        _lib = L
+    return _lib
+
+
+def _c(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_dp)
+
+
+def eval_block(model, status, grid, obs, params, want_jac=True, jac_mask=None):
+    """GenericProjectionJac::Evaluate for one block.
+
+    params = [intrinsics, xi_0, ..., xi_{L-1}];  returns (residual[2N], [J_0 .. J_L] or None).
+    jac_mask[b] False -> that block's Jacobian pointer is NULL (constant parameter block).
+    """
+    L = len(status)
+    grid = _c(grid).reshape(-1, 3)
+    obs = _c(obs).reshape(-1, 2)
+    N = grid.shape[0]
+    assert obs.shape[0] == N
+    K = NUM_INTRINSICS[model]
+    ps = [_c(p) for p in params]
+    assert len(ps) == L + 1 and ps[0].size == K and all(p.size == 6 for p in ps[1:])
+    pp = (_dp * (L + 1))(*[_ptr(p) for p in ps])
+    st = (ctypes.c_int * max(L, 1))(*status)
+    res = np.empty(2 * N)
+    jacs = None
+    jp = None
+    if want_jac:
+        sizes = [K] + [6] * L
+        jacs = [np.full((2 * N, s), np.nan) for s in sizes]
+        if jac_mask is None:
+            jac_mask = [True] * (L + 1)
+        jp = (_dp * (L + 1))(*[_ptr(j) if m else _dp() for j, m in zip(jacs, jac_mask)])
+        jacs = [j if m else None for j, m in zip(jacs, jac_mask)]
+    ok = lib().vgo_eval_block(model, L, st, N, _ptr(grid), _ptr(obs), pp, _ptr(res), jp)
+    assert ok == 1
+    return res, jacs
+
+
+def eval_dataset(model, status, grid, obs, param_vec, intr_offset, member_base, member_stride,
+                 seq_index, want_jac=True, threads=1, out=None):
+    """Batched blocks sharing camera + chain shape; Ceres block layout outputs."""
+    L = len(status)
+    grid = _c(grid).reshape(-1, 3)
+    N = grid.shape[0]
+    obs = _c(obs).reshape(-1, 2 * N)
+    nb = obs.shape[0]
+    K = NUM_INTRINSICS[model]
+    pv = _c(param_vec)
+    st = (ctypes.c_int * max(L, 1))(*status)
+    mb = np.ascontiguousarray(member_base, dtype=np.int64).reshape(-1)
+    ms = np.ascontiguousarray(member_stride, dtype=np.int64).reshape(-1)
+    si = np.ascontiguousarray(seq_index, dtype=np.int64).reshape(-1)
+    assert si.size == nb
+    if out is None:
+        res = np.empty((nb, 2 * N))
+        ji = np.empty((nb, 2 * N, K)) if want_jac else None
+        jm = [np.empty((nb, 2 * N, 6)) for _ in range(L)] if want_jac else None
+    else:
+        res, ji, jm = out
+    jmp = (_dp * max(L, 1))(*[_ptr(j) for j in jm]) if want_jac and L else None
+    n = lib().vgo_eval_dataset(model, L, st, N, _ptr(grid), nb, _ptr(obs), _ptr(pv), intr_offset,
+                               mb.ctypes.data_as(_lp), ms.ctypes.data_as(_lp),
+                               si.ctypes.data_as(_lp), _ptr(res),
+                               _ptr(ji) if want_jac else None, jmp, threads)
+    assert n == nb
+    return res, ji, jm
+
+
+def block_gram(residual, jac_intr, jac_members, fast=False):
+    """[J|r]^T [J|r] of one block, (P+1)x(P+1), long-double accumulation unless fast."""
+    residual = _c(residual)
+    jac_intr = _c(jac_intr)
+    jm = [_c(j) for j in jac_members]
+    N = residual.size // 2
+    K = jac_intr.shape[-1]
+    L = len(jm)
+    W = K + 6 * L + 1
+    g = np.empty((W, W))
+    jmp = (_dp * max(L, 1))(*[_ptr(j) for j in jm])
+    f = lib().vgo_block_gram_fast if fast else lib().vgo_block_gram
+    f(K, L, N, _ptr(residual), _ptr(jac_intr), jmp, _ptr(g))
+    return g
+
+
+def compose(a, b, inverse=False):
+    a, b, o = _c(a), _c(b), np.empty(6)
+    (lib().vgo_compose_inverse if inverse else lib().vgo_compose)(_ptr(a), _ptr(b), _ptr(o))
+    return o
+
+
+def rotation_matrix(v):
+    v, R = _c(v), np.empty(9)
+    lib().vgo_rotation_matrix(_ptr(v), _ptr(R))
+    return R.reshape(3, 3)
+
+
+def inter_omega_rot(v):
+    v, M = _c(v), np.empty(9)
+    lib().vgo_inter_omega_rot(_ptr(v), _ptr(M))
+    return M.reshape(3, 3)
+
+
+def quat_from_rotvec(v):
+    v, q = _c(v), np.empty(4)
+    lib().vgo_quat_from_rotvec(_ptr(v), _ptr(q))
+    return q
+
+
+def quat_to_rotvec(q):
+    q, v = _c(q), np.empty(3)
+    lib().vgo_quat_to_rotvec(_ptr(q), _ptr(v))
+    return v
+
+
+def project_point(model, intr, X):
+    intr, X, uv = _c(intr), _c(X), np.full(2, np.nan)
+    ok = lib().vgo_project_point(model, _ptr(intr), _ptr(X), _ptr(uv))
+    return bool(ok), uv
+
+
+def max_threads():
+    return lib().vgo_max_threads()
