@@ -1,0 +1,244 @@
+#!/usr/bin/env python3
+"""bench.py -- corner residual + Jacobian evaluations per second on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json metric: "corner residual+Jacobian evals/sec ... (EUCM 10k imgs)"):
+  synthetic EUCM mono, 10 000 images x 96 corners (8 x 12 board) PER GPU, chain [xiCamBoard DIRECT],
+  evaluated at the perturbed point of SURVEY 8(d); all Jacobian blocks requested (6 intrinsics + 6 pose).
+One step = one full evaluation of the hot path at the current parameters:
+  kernel 1 (transform-chain prep, one lane per image) + kernel 2 (residual pair + 2 x 12 Jacobian
+  entries per (image, corner), written to HBM in the Ceres block layout).
+Inputs are resident in HBM before the timed region.  Multi-GPU: images are sharded over ranks
+(weak scaling, no data-path collective in this pass; the normal-equation build that needs the
+all-reduce is reported separately under "jtj").
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--images", type=int, default=10000, help="images per GPU")
+    ap.add_argument("--model", default="eucm", choices=["eucm", "ucm", "mei"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU-baseline budget per leg")
+    return ap.parse_args()
+
+
+def cpu_baseline(d, model, budget_s):
+    """The oracle (a C port of the reference's arithmetic, oracle/vg_oracle.c) timed on this box's host
+    cores over the SAME workload: whole passes over the 10 k-image set, residual + all Jacobian blocks,
+    repeated for ~budget_s seconds per leg.  This is the only place bench.py touches oracle/."""
+    import numpy as np
+
+    from oracle import vgo
+
+    n, N = d["corners"].shape[0], d["board"].shape[0]
+    K = d["init_intrinsics"].size
+    pv = np.concatenate([d["init_intrinsics"], d["init_poses"].ravel()])
+    m = vgo.MODELS[model]
+    out = (np.empty((n, 2 * N)), np.empty((n, 2 * N, K)), [np.empty((n, 2 * N, 6))])
+    seq = np.arange(n)
+
+    def leg(threads):
+        vgo.eval_dataset(m, [0], d["board"], d["corners"], pv, 0, [K], [6], seq, threads=threads, out=out)  # warm
+        passes, t0 = 0, time.perf_counter()
+        while True:
+            vgo.eval_dataset(m, [0], d["board"], d["corners"], pv, 0, [K], [6], seq, threads=threads, out=out)
+            passes += 1
+            el = time.perf_counter() - t0
+            if el >= budget_s:
+                return passes, el, passes * n * N / el
+
+    cores = vgo.max_threads()
+    p1, t1, v1 = leg(1)
+    pc, tc, vc = leg(cores)
+    cpu_model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": vc, "unit": "evals/s", "cores": cores, "kind": "port",
+            "sample": "%d passes (%.1f s) over the same %d-image x %d-corner set with %d OpenMP threads; "
+                      "single thread: %d passes (%.1f s)" % (pc, tc, n, N, cores, p1, t1),
+            "single_thread_value": v1, "cpu_model": cpu_model}
+
+
+def main():
+    a = parse()
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (a.gpus, a.gpus))
+        a.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+
+        dist = dist_
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from visgeom_amd import CalibrationProblem, synthetic
+
+    cfg_index = 1  # the metric's configuration: EUCM mono, 10 k images x 96 corners
+    d = synthetic.make_mono(a.model, a.images, cfg_index, first_image=rank * a.images)
+    n_img, N = d["corners"].shape[0], d["board"].shape[0]
+    K = d["init_intrinsics"].size
+    n_obs = n_img * N
+
+    p = CalibrationProblem(local_rank)
+    cam = p.add_camera(a.model, d["init_intrinsics"])
+    seq = p.add_transform(False, d["init_poses"])
+    ds = p.add_dataset(cam, [(seq, 0)], d["board"], d["corners"])
+    p.finalize()
+    res, ji, jm = p.alloc_outputs(ds)
+
+    def step():
+        p.prepare()
+        p.evaluate_dataset(ds, res, ji, jm)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert p.failed_count(ds) == 0
+    value = world * n_obs * a.steps / elapsed
+
+    # ---- roofline of the dominant kernel (emit): HIP events on the launch stream, K launches ----
+    bytes_per_obs = 16 + 16 + 16 * (K + 6)  # obs read + residual write + Jacobian rows  
+    stream = torch.cuda.current_stream()
+    p.prepare()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    for e0, e1 in ev:
+        e0.record(stream)
+        p.evaluate_dataset(ds, res, ji, jm)
+        e1.record(stream)
+    torch.cuda.synchronize()
+    per_launch_ms = np.array([e0.elapsed_time(e1) for e0, e1 in ev])
+    # back-to-back launches bracketed once (includes the ~1.5 us inter-kernel gap)
+    b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    b0.record(stream)
+    for _ in range(a.steps):
+        p.evaluate_dataset(ds, res, ji, jm)
+    b1.record(stream)
+    torch.cuda.synchronize()
+    b2b_ms = b0.elapsed_time(b1) / a.steps
+    emit_ms = float(np.mean(per_launch_ms))
+    achieved = bytes_per_obs * n_obs / (emit_ms * 1e-3) / 1e9
+    traffic = None
+    prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(prof):
+        try:
+            traffic = json.load(open(prof)).get("%s_%d" % (a.model, a.images), {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "kernel": "vg_emit_kernel<%s,jac,frames-in-LDS>" % a.model,
+                "algorithmic_bytes_per_launch": bytes_per_obs * n_obs, "bytes_per_obs": bytes_per_obs,
+                "avg_launch_ms": emit_ms, "median_launch_ms": float(np.median(per_launch_ms)),
+                "back_to_back_ms": b2b_ms}
+
+    # ---- measured streaming rates on this box, same 16 B/lane pattern (context for the fraction) ----
+    from visgeom_amd import capi
+    import ctypes
+
+    L = capi.load()
+    nd = 64 * 1024 * 1024  # 512 MiB of doubles: past the 256 MiB Infinity Cache
+    buf = torch.empty(nd, dtype=torch.float64, device="cuda")
+    buf2 = torch.empty(nd, dtype=torch.float64, device="cuda")
+    sp = ctypes.c_void_p(stream.cuda_stream)
+
+    def rate(fn, nbytes, reps=10):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(reps):
+            fn()
+        e1.record(stream)
+        torch.cuda.synchronize()
+        return nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+    write_gbs = rate(lambda: capi.check(L.vg_calib_stream_write(sp, ctypes.c_void_p(buf.data_ptr()), nd, 1.0)), nd * 8)
+    copy_gbs = rate(lambda: capi.check(L.vg_calib_stream_copy(sp, ctypes.c_void_p(buf2.data_ptr()),
+                                                              ctypes.c_void_p(buf.data_ptr()), nd)), nd * 16)
+    del buf, buf2
+    roofline["measured_stream_write_GBps"] = write_gbs
+    roofline["measured_stream_copy_GBps"] = copy_gbs
+
+    out = {
+        "metric": "corner residual+Jacobian evals/sec",
+        "value": value,
+        "unit": "evals/s",
+        "n_gpus": world,
+        "steps": a.steps,
+        "warmup": a.warmup,
+        "ms_per_step": elapsed / a.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "%s mono, %d images x %d corners (8x12 board) per GPU, chain [xiCamBoard DIRECT], "
+                               "residual + all Jacobian blocks (K=%d intrinsics + 6 pose) emitted to HBM in Ceres "
+                               "block layout; step = chain-prep kernel + emit kernel" % (a.model.upper(), n_img, N, K),
+                   "images_per_gpu": n_img, "corners_per_image": N, "model": a.model, "chain": ["DIRECT"],
+                   "seed": int(d["seed"]), "sharding": "images sharded over ranks, no data-path collective"},
+        "roofline": roofline,
+    }
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(d, a.model, a.cpu_seconds)
+        out["gpu_over_cpu_allcores"] = value / out["cpu_baseline"]["value"]
+    p.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

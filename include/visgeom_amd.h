@@ -1,0 +1,166 @@
+/*
+ * visgeom_amd.h -- C ABI of the MI355X-native reprojection residual / Jacobian engine.
+ *
+ * Drop-in boundary for ONE hot path of BKhomutenko/visgeom: the calibration cost function
+ *     GenericProjectionJac::Evaluate        src/calibration/calib_cost_functions.cpp:28-117
+ * and the normal-equation build (J^T J, J^T r) that Ceres performs on its output
+ * (not in the reference tree; call sites src/calibration/unified_calibration.cpp:53,426,1152).
+ *
+ * Conventions
+ *   - plain C, no torch / Eigen / Ceres types; every function returns a vg_status
+ *     (VG_OK == 0) unless documented otherwise; vg_last_error() gives the text.
+ *   - all arithmetic is IEEE double (the reference computes in double throughout).
+ *   - "device pointer" = memory of the problem's HIP device (hipMalloc'ed or a torch tensor's
+ *     data_ptr()); "host pointer" = ordinary memory.  Output buffers are caller-owned.
+ *   - a 6-vector transform is [tx,ty,tz, rx,ry,rz] (translation, rotation vector),
+ *     include/geometry/transformation.h:46.
+ *   - there is NO CPU fallback: without a usable HIP device every compute entry fails with
+ *     VG_ERR_NO_DEVICE / VG_ERR_HIP.
+ *
+ * All file:line citations are relative to the reference tree (/root/reference).
+ */
+#ifndef VISGEOM_AMD_H
+#define VISGEOM_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VG_ABI_VERSION 1
+
+/* camera models: parseCameras, src/calibration/unified_calibration.cpp:134-180 */
+enum vg_model {
+    VG_MODEL_EUCM = 0, /* [alpha,beta,fu,fv,u0,v0]          include/projection/eucm.h:29-226 */
+    VG_MODEL_UCM = 1,  /* [xi,fu,fv,u0,v0]                  include/projection/ucm.h:32-197  */
+    VG_MODEL_MEI = 2   /* [xi,k1,k2,k3,k4,k5,fu,fv,u0,v0]   include/projection/mei.h:29-285  */
+};
+
+/* enum TransformationStatus, include/calibration/calib_cost_functions.h:25 */
+enum vg_transform_status { VG_TRANSFORM_DIRECT = 0, VG_TRANSFORM_INVERSE = 1 };
+
+enum vg_status {
+    VG_OK = 0,
+    VG_ERR_INVALID_ARGUMENT = 1,
+    VG_ERR_HIP = 2,       /* a HIP runtime call failed (text in vg_last_error) */
+    VG_ERR_NO_DEVICE = 3, /* no HIP device: the product path has no CPU fallback */
+    VG_ERR_STATE = 4,     /* call order violated (e.g. evaluate before finalize) */
+    VG_ERR_ALLOC = 5,
+    VG_ERR_NUMERIC = 6    /* solver: a factorisation failed */
+};
+
+#define VG_MAX_CHAIN 5       /* src/calibration/unified_calibration.cpp:566-567 (> 5 throws) */
+#define VG_MAX_INTRINSICS 10 /* Mei */
+#define VG_DOUBLE_BIG 1e15   /* include/std.h:71, in-band failed-projection residual */
+
+int vg_abi_version(void);
+const char *vg_last_error(void);       /* thread-local, never NULL */
+int vg_device_count(void);             /* number of HIP devices, 0 when none / no driver */
+int vg_num_intrinsics(int model);      /* 6 / 5 / 10, -1 for an unknown model */
+/* box bounds of intrinsic idx: eucm.h:228-246, ucm.h:199-215, mei.h:287-313 */
+int vg_intrinsic_bounds(int model, int idx, double *lower, double *upper);
+
+/* =====================================================================================
+ * 1. Per-block entry -- 1:1 with struct GenericProjectionJac
+ *    (include/calibration/calib_cost_functions.h:27-62).  A 30-line adapter deriving from
+ *    ceres::CostFunction forwards ctor / Evaluate / dtor to these three calls
+ *    (INTEGRATION.md section 1).  One block = one image of one camera.
+ * ===================================================================================== */
+typedef struct vg_block vg_block;
+
+/* ctor (calib_cost_functions.h:29-46): copies obs ("proj", 2N) and grid (3N), records the chain
+ * statuses; parameter blocks are [K, 6 x chain_len], residual count 2N.  chain_len in [0,5]. */
+int vg_block_create(vg_block **out, int device, int model, int chain_len, const int *status,
+                    int n_points, const double *grid /*3N host*/, const double *obs /*2N host*/);
+int vg_block_num_residuals(const vg_block *b);                  /* 2N        (:45) */
+int vg_block_num_parameter_blocks(const vg_block *b);           /* 1 + L           */
+int vg_block_parameter_block_size(const vg_block *b, int idx);  /* K or 6    (:38-42) */
+
+/* Evaluate (calib_cost_functions.cpp:28-117).  Host pointers, exactly Ceres' contract:
+ *   parameters[0] -> K intrinsics, parameters[1+l] -> 6-vector of chain member l;
+ *   residuals[2N] = [u0,v0,u1,v1,...]; failed projection -> (1e15,1e15) and zero Jacobian rows;
+ *   jacobians NULL, or 1+L pointers each NULL or row-major [2N x blocksize].
+ * Returns VG_OK where the reference returns true (it always does, :116). */
+int vg_block_evaluate(vg_block *b, double const *const *parameters, double *residuals,
+                      double **jacobians);
+void vg_block_destroy(vg_block *b);
+
+/* =====================================================================================
+ * 2. Batched problem -- what GenericCameraCalibration assembles
+ *    (src/calibration/unified_calibration.cpp:91-180, 514-630), evaluated in ONE pass over
+ *    all (image x corner) observations per dataset instead of one Evaluate per image.
+ * ===================================================================================== */
+typedef struct vg_problem vg_problem;
+
+/* hip_stream: a hipStream_t to launch on (e.g. torch.cuda.current_stream().cuda_stream), or NULL
+ * for the device's default stream.  All launches of this problem go to that stream, in order. */
+int vg_problem_create(vg_problem **out, int device, void *hip_stream);
+void vg_problem_destroy(vg_problem *p);
+
+/* parseCameras (:134-180).  intrinsics: K host doubles.  constant: SetParameterBlockConstant (:614-617). */
+int vg_problem_add_camera(vg_problem *p, int model, const double *intrinsics, int constant,
+                          int *camera_id);
+/* parseTransforms (:91-132).  is_global: one shared 6-vector; otherwise a sequence of `count`
+ * 6-vectors indexed by image index (include/calibration/unified_calibration.h:161-165).
+ * values: count*6 host doubles or NULL (zeros). */
+int vg_problem_add_transform(vg_problem *p, int is_global, int constant, int count,
+                             const double *values, int *transform_id);
+/* addGridResidualBlocks (:514-630): one residual block per listed image.
+ *   transform_ids/status: the chain, camera-side first (initTransformChainInfo :182-231);
+ *     at most one member may be a sequence transform... the reference requires exactly one (:223-228),
+ *     this ABI also accepts none (all-global chains) and chain_len 0.
+ *   board: 3*n_points host doubles (initGrid :279-309 / initGridIR :234-250);
+ *   image_index[n_images]: index into the sequence transform(s) for each block; images whose
+ *     corner list was empty are simply not listed (:520);
+ *   corners: [n_images][2*n_points] host doubles, [u0,v0,u1,v1,...] per image. */
+int vg_problem_add_dataset(vg_problem *p, int camera_id, int chain_len, const int *transform_ids,
+                           const int *status, int n_points, const double *board, int64_t n_images,
+                           const int32_t *image_index, const double *corners, int *dataset_id);
+/* freezes the layout, uploads everything, allocates per-block frames. */
+int vg_problem_finalize(vg_problem *p);
+
+/* ---- parameter vector: [camera 0 | camera 1 | ... | transform 0 (count x 6) | transform 1 ...] ---- */
+int64_t vg_problem_num_parameters(const vg_problem *p);
+int64_t vg_problem_camera_offset(const vg_problem *p, int camera_id);
+int64_t vg_problem_transform_offset(const vg_problem *p, int transform_id, int64_t index);
+int vg_problem_set_parameters(vg_problem *p, const double *host_params);  /* H2D, stream-ordered + sync */
+int vg_problem_get_parameters(vg_problem *p, double *host_params);        /* D2H + sync */
+double *vg_problem_parameters_device(vg_problem *p); /* device pointer, valid until destroy */
+
+/* ---- shape queries ---- */
+int vg_problem_num_datasets(const vg_problem *p);
+int64_t vg_dataset_num_blocks(const vg_problem *p, int dataset_id);
+int vg_dataset_num_points(const vg_problem *p, int dataset_id);
+int vg_dataset_chain_len(const vg_problem *p, int dataset_id);
+int vg_dataset_num_intrinsics(const vg_problem *p, int dataset_id);
+
+/* ---- evaluation (asynchronous on the problem's stream; sync with vg_problem_synchronize) ----
+ * vg_problem_prepare: kernel 1 -- composes every block's transform chain at the CURRENT device
+ *   parameters (the two chain walks of calib_cost_functions.cpp:32-46 and :76-92, the InterJacobian
+ *   ctor jacobian.h:139-152) into a per-block frame.  Call after every parameter change.
+ * vg_dataset_evaluate: kernel 2 -- one thread per (image, corner): residuals + Jacobian rows in the
+ *   Ceres block layout, block after block:
+ *     residuals  [n_blocks][2N]            jac_intr [n_blocks][2N][K]   (row-major)
+ *     jac_member[l] [n_blocks][2N][6]      any of jac_intr / jac_member / jac_member[l] may be NULL
+ *   (device pointers; jac_member itself is a HOST array of chain_len device pointers). */
+int vg_problem_prepare(vg_problem *p);
+int vg_dataset_evaluate(vg_problem *p, int dataset_id, double *residuals, double *jac_intr,
+                        double *const *jac_member);
+int vg_problem_synchronize(vg_problem *p);
+
+/* number of failed projections (1e15 residual pairs) seen by the last vg_dataset_evaluate of that
+ * dataset; synchronises the stream.  Not in the reference. */
+int vg_dataset_failed_count(vg_problem *p, int dataset_id, int64_t *count);
+
+/* ---- measurement helpers (bench / profiling only): a pure streaming write / copy with the same
+ * 16 B-per-lane access pattern as the emit kernel, to calibrate rocprofv3's WRITE_SIZE / FETCH_SIZE
+ * and to measure the achievable HBM rate on the box. */
+int vg_calib_stream_write(void *hip_stream, double *dst, int64_t n_doubles, double value);
+int vg_calib_stream_copy(void *hip_stream, double *dst, const double *src, int64_t n_doubles);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VISGEOM_AMD_H */

@@ -1,0 +1,107 @@
+"""CPU-side checks of the product boundary: the C-ABI library builds, loads, exports every symbol the
+header declares, and refuses to compute without a GPU (no CPU fallback, no route through the oracle)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "visgeom_amd.h")
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vg_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from visgeom_amd import _build, capi
+
+    _build.build()
+    return capi.load()
+
+
+def test_header_symbols_are_exported_and_bound(lib):
+    from visgeom_amd import _build, capi
+
+    syms = declared_symbols()
+    assert len(syms) >= 30
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _build.LIB], text=True)
+    exported = set(re.findall(r" T (vg_[a-z0-9_]+)", out))
+    missing = [s for s in syms if s not in exported]
+    assert not missing, "declared in the header but not exported: %s" % missing
+    unbound = [s for s in syms if s not in capi.SIGNATURES]
+    assert not unbound, "declared in the header but not bound in capi.py: %s" % unbound
+    extra = [s for s in capi.SIGNATURES if s not in syms]
+    assert not extra, "bound but not declared: %s" % extra
+
+
+def test_library_is_hip_code_for_gfx950():
+    from visgeom_amd import _build
+
+    _build.build()
+    blob = open(_build.LIB, "rb").read()
+    assert b"gfx950" in blob, "no gfx950 code object inside the shared library"
+    assert b"vg_emit_kernel" in blob and b"vg_chain_prep_kernel" in blob
+
+
+def test_static_facts(lib):
+    assert lib.vg_abi_version() == 1
+    assert [lib.vg_num_intrinsics(m) for m in (0, 1, 2, 3)] == [6, 5, 10, -1]
+    lo, hi = ctypes.c_double(), ctypes.c_double()
+    # eucm.h:228-246, ucm.h:199-215, mei.h:287-313
+    expect = {(0, 0): (0, 1), (0, 1): (0.1, 10), (0, 2): (1, 1e5), (1, 0): (0, 3), (1, 4): (1, 1e5),
+              (2, 0): (0, 3), (2, 3): (-10, 10), (2, 5): (-10, 10), (2, 6): (1, 1e5)}
+    for (m, i), (l, h) in expect.items():
+        assert lib.vg_intrinsic_bounds(m, i, ctypes.byref(lo), ctypes.byref(hi)) == 0
+        assert (lo.value, hi.value) == (l, h)
+    assert lib.vg_intrinsic_bounds(1, 5, ctypes.byref(lo), ctypes.byref(hi)) != 0
+
+
+def test_no_cpu_fallback(lib):
+    """Without a GPU every compute entry must fail loudly (VG_ERR_NO_DEVICE), never compute on the host."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present; the no-device path cannot be exercised")
+    from visgeom_amd import capi
+
+    assert lib.vg_device_count() == 0
+    h = ctypes.c_void_p()
+    rc = lib.vg_problem_create(ctypes.byref(h), 0, None)
+    assert rc == capi.ERR_NO_DEVICE and not h.value
+    assert b"no CPU fallback" in lib.vg_last_error()
+    import numpy as np
+
+    import visgeom_amd
+
+    with pytest.raises(capi.VisgeomError) as ei:
+        visgeom_amd.GenericProjectionJac(np.zeros((4, 2)), np.ones((4, 3)), "eucm", [0])
+    assert ei.value.code == capi.ERR_NO_DEVICE
+
+
+def test_product_path_never_touches_the_oracle():
+    """only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use oracle/."""
+    pat = re.compile(r"\boracle\b|vg_oracle|vgo\b")
+    for base in ("visgeom_amd", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                    src = open(os.path.join(dirpath, f)).read()
+                    hits = [ln for ln in src.splitlines() if pat.search(ln)
+                            and "not the oracle" not in ln and "and not the oracle" not in ln
+                            and "GPU and oracle differ" not in ln]
+                    assert not hits, "%s mentions the oracle: %s" % (os.path.join(dirpath, f), hits[:3])
+    out = subprocess.run(["ldd", os.path.join(ROOT, "visgeom_amd", "lib", "libvisgeom_amd.so")],
+                         capture_output=True, text=True).stdout
+    assert "vg_oracle" not in out
+
+
+def test_oracle_header_declares_itself_test_infrastructure():
+    for f in ("vg_oracle.h", "vg_oracle.c", "vgo.py"):
+        head = open(os.path.join(ROOT, "oracle", f)).read()[:1500].upper()
+        assert "TEST INFRASTRUCTURE" in head

@@ -1,0 +1,357 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI, against the CPU oracle and the
+committed golden vectors.  Bar: <= 1e-10 with the SURVEY 8(c) metric (tests/parity.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import vgo
+from tests.parity import BIG, assert_block_parity
+
+pytestmark = pytest.mark.gpu
+
+RNG = np.random.default_rng(20260928)
+MODELS = ["eucm", "ucm", "mei"]
+CHAINS = [[0], [1, 0], [0, 1, 0], [1, 0, 0, 1, 0]]
+
+
+@pytest.fixture(scope="module")
+def vg():
+    import torch
+
+    assert torch.cuda.is_available(), "these tests need a GPU (run with -m gpu on the MI355X box)"
+    import visgeom_amd
+
+    return visgeom_amd
+
+
+@pytest.fixture(scope="module")
+def S():
+    from visgeom_amd import synthetic
+
+    return synthetic
+
+
+def random_chain(L, base_pose):
+    xis = [np.concatenate([RNG.uniform(-0.15, 0.15, 3), RNG.uniform(-0.25, 0.25, 3)]) for _ in range(L - 1)]
+    xis.append(base_pose + np.concatenate([RNG.uniform(-0.05, 0.05, 3), RNG.uniform(-0.05, 0.05, 3)]))
+    return xis
+
+
+# ------------------------------------------------------------------ golden vectors through the C ABI
+def test_appendix_c_golden_vectors_per_block_entry(vg, golden_dir):
+    g = json.load(open(os.path.join(golden_dir, "survey_appendix_c.json")))
+    c1 = g["c1"]
+    for case in c1["cases"]:
+        blk = vg.GenericProjectionJac(c1["obs"], c1["grid"], case["model"], c1["status"])
+        assert blk.num_residuals() == 2
+        assert blk.parameter_block_sizes() == [len(case["intrinsics"]), 6, 6]
+        res, J = blk.Evaluate([case["intrinsics"], c1["xi12"], c1["xiB"]])
+        proj = np.array(case["residual"]) + np.array(c1["obs"][0])
+        assert np.linalg.norm(res - case["residual"]) <= 1e-10 * np.linalg.norm(proj)
+        assert np.max(np.abs(J[0][0] - case["du_dintr"])) <= 1e-10 * np.max(np.abs(case["du_dintr"]))
+        assert np.linalg.norm(J[1][0] - case["du_dxi12"]) <= 1e-10 * np.linalg.norm(case["du_dxi12"])
+        assert np.linalg.norm(J[2][1] - case["dv_dxiB"]) <= 1e-10 * np.linalg.norm(case["dv_dxiB"])
+        blk.close()
+    c2 = g["c2"]
+    b = c2["board"]
+    grid = np.array([[b["size"] * j, b["size"] * i, 0.0] for i in range(b["rows"]) for j in range(b["cols"])])
+    blk = vg.GenericProjectionJac(np.zeros((96, 2)), grid, "eucm", [0])
+    assert blk.num_residuals() == c2["num_residuals"] and blk.parameter_block_sizes() == c2["block_sizes"]
+    res, J = blk.Evaluate([c2["intrinsics"], c2["xi"]])
+    assert np.max(np.abs(J[0][0] - c2["intr_jac_row0"])) <= 1e-10 * 30
+    assert np.linalg.norm(J[1][191] - c2["pose_jac_row191"]) <= 1e-10 * np.linalg.norm(c2["pose_jac_row191"])
+    # C.3 zero rotation (small-angle branches)
+    z = g["c3"]["zero_rotation"]
+    res0, _ = blk.Evaluate([c2["intrinsics"], z["obs_from_xi"]], want_jacobians=False)
+    blk2 = vg.GenericProjectionJac(res0.reshape(-1, 2), grid, "eucm", [0])
+    res, J = blk2.Evaluate([c2["intrinsics"], z["xi"]])
+    assert np.max(np.abs(res[2:4] - z["residual_2_3"])) <= 1e-10 * 5
+    assert np.max(np.abs(J[1][2] - z["pose_jac_row2"])) <= 1e-10 * 300
+    # C.3 board behind the camera: in-band failure
+    res, J = blk.Evaluate([c2["intrinsics"], g["c3"]["behind_camera"]["xi"]])
+    failed = (res.reshape(-1, 2) == BIG).all(axis=1)
+    assert failed.sum() == 94
+    assert np.all(J[0][np.repeat(failed, 2)] == 0) and np.all(J[1][np.repeat(failed, 2)] == 0)
+    blk.close()
+    blk2.close()
+
+
+# ------------------------------------------------------------------ per-block entry vs oracle
+@pytest.mark.parametrize("model", MODELS)
+@pytest.mark.parametrize("status", CHAINS, ids=lambda s: "L%d" % len(s))
+def test_per_block_entry_matches_oracle(vg, S, model, status):
+    d = S.make_mono(model, 3, 2)
+    m = vgo.MODELS[model]
+    for img in range(3):
+        # the last DIRECT member carries the board pose; earlier members are small rig offsets, so the
+        # composed pose is perturbed by a few cm / degrees -> residuals of O(10-100 px)
+        xis = random_chain(len(status), d["gt_poses"][img])
+        params = [d["init_intrinsics"]] + xis
+        blk = vg.GenericProjectionJac(d["corners"][img], d["board"], model, status)
+        res, J = blk.Evaluate(params)
+        rr, JJ = vgo.eval_block(m, status, d["board"], d["corners"][img], params)
+        assert_block_parity(res, J, rr, JJ, d["corners"][img], "%s %s img %d" % (model, status, img))
+        # NULL Jacobian combinations (constant blocks) and cost-only
+        mask = [bool((img + k) % 2) for k in range(len(status) + 1)]
+        res2, J2 = blk.Evaluate(params, jac_mask=mask)
+        assert np.array_equal(res2, res)
+        for k, mk in enumerate(mask):
+            assert (J2[k] is None) == (not mk)
+            if mk:
+                assert np.array_equal(J2[k], J[k])
+        res3, J3 = blk.Evaluate(params, want_jacobians=False)
+        assert J3 is None and np.array_equal(res3, res)
+        blk.close()
+
+
+def test_chain_length_zero_and_argument_errors(vg):
+    from visgeom_amd import capi
+
+    grid = np.array([[0.1 * j - 0.5, 0.1 * i - 0.3, 1.0] for i in range(4) for j in range(5)])
+    obs = RNG.uniform(100, 900, (20, 2))
+    intr = [1.2, 700.0, 700.0, 640.0, 400.0]
+    blk = vg.GenericProjectionJac(obs, grid, "ucm", [])
+    assert blk.parameter_block_sizes() == [5]
+    res, J = blk.Evaluate([intr])
+    rr, JJ = vgo.eval_block(vgo.MODEL_UCM, [], grid, obs, [intr])
+    assert_block_parity(res, J, rr, JJ, obs)
+    blk.close()
+    with pytest.raises(capi.VisgeomError):
+        vg.GenericProjectionJac(obs, grid, "ucm", [0] * 6)  # > 5 transforms throws (unified_calibration.cpp:566-567)
+    with pytest.raises(ValueError):
+        vg.GenericProjectionJac(obs[:5], grid, "ucm", [0])  # corner list must match the board
+
+
+# ------------------------------------------------------------------ geometry branches
+EDGE_ROTS = {
+    "zero": [0.0, 0.0, 0.0],
+    "below_1e-6": [5e-7, -3e-7, 2e-7],
+    "between_1e-6_1e-5": [4e-6, -3e-6, 2e-6],
+    "just_below_1e-5": [9.99e-6 / np.sqrt(3)] * 3,
+    "just_above_1e-5": [1.001e-5 / np.sqrt(3)] * 3,
+    "above_pi": [0.4, 3.3, -0.5],
+    "near_pi": [0.0, 3.1, 0.0],
+    "large": [2.0, -5.0, 1.0],
+}
+
+
+@pytest.mark.parametrize("name", sorted(EDGE_ROTS))
+@pytest.mark.parametrize("status", [[0], [1, 0], [0, 1]], ids=["D", "ID", "DI"])
+def test_small_angle_and_wraparound_branches(vg, name, status):
+    """first-order branches of rotationMatrix / interOmegaRot / Quaternion (geometry_core.h:45-52,163-169,
+    quaternion.h:34-40,88-91) and the |rot| > pi renormalisation of compose (transformation.h:80-88)."""
+    from visgeom_amd import synthetic
+
+    board = synthetic.board_points()
+    rot = np.array(EDGE_ROTS[name])
+    pose = np.array([-0.55, -0.35, 0.9, 0.3, -0.4, 0.1])
+    edge = np.concatenate([[0.02, -0.01, 0.03], rot])
+    params = [synthetic.GT_EUCM_CAM1]
+    if len(status) == 1:
+        params.append(np.concatenate([pose[:3], rot]))
+    elif status == [1, 0]:
+        params += [edge, pose]
+    else:
+        params += [pose, edge]
+    obs = np.full((96, 2), 600.0)
+    blk = vg.GenericProjectionJac(obs, board, "eucm", status)
+    res, J = blk.Evaluate(params)
+    rr, JJ = vgo.eval_block(vgo.MODEL_EUCM, status, board, obs, params)
+    assert_block_parity(res, J, rr, JJ, obs, name)
+    blk.close()
+
+
+@pytest.mark.parametrize("model", MODELS)
+def test_failed_and_behind_camera_points(vg, S, model):
+    """EUCM reports failure in-band (1e15 / zero rows); UCM and Mei never do and return
+    whatever the formulas give -- finite garbage must still match the oracle."""
+    board = S.board_points()
+    pose = np.array([-0.3, -0.2, -0.25, 0.5, 0.9, 0.1])  # board straddles the z = 0 plane of the camera
+    obs = np.zeros((96, 2))
+    params = [S.GT[model], pose]
+    blk = vg.GenericProjectionJac(obs, board, model, [0])
+    res, J = blk.Evaluate(params)
+    rr, JJ = vgo.eval_block(vgo.MODELS[model], [0], board, obs, params)
+    if model == "eucm":
+        nfail = int((rr == BIG).sum() // 2)
+        assert 0 < nfail < 96
+        assert_block_parity(res, J, rr, JJ, obs)
+    else:
+        assert not (rr == BIG).any()
+        fin = np.isfinite(rr)
+        assert np.array_equal(np.isfinite(res), fin)
+        assert np.allclose(res[fin], rr[fin], rtol=1e-9, atol=1e-6)
+    blk.close()
+
+
+# ------------------------------------------------------------------ batched problem vs oracle
+def _check_dataset(p, ds, model, status, board, corners, pv, intr_off, bases, strides, seq, jac_mask=None):
+    res_t, ji_t, jm_t = p.alloc_outputs(ds, jac_mask=jac_mask)
+    p.prepare()
+    p.evaluate_dataset(ds, res_t, ji_t, jm_t)
+    p.synchronize()
+    r_ref, ji_ref, jm_ref = vgo.eval_dataset(vgo.MODELS[model], status, board, corners, pv, intr_off, bases,
+                                             strides, seq, threads=4)
+    res = res_t.cpu().numpy()
+    ji = ji_t.cpu().numpy() if ji_t is not None else None
+    jm = [t.cpu().numpy() if t is not None else None for t in jm_t]
+    worst = {}
+    for b in range(res.shape[0]):
+        J = [ji[b] if ji is not None else None] + [m[b] if m is not None else None for m in jm]
+        Jr = [ji_ref[b] if ji is not None else None] + [jm_ref[l][b] if jm[l] is not None else None
+                                                         for l in range(len(jm))]
+        e = assert_block_parity(res[b], J, r_ref[b], Jr, corners[b], "block %d" % b)
+        for k, v in e.items():
+            worst[k] = max(worst.get(k, 0), v)
+    return worst
+
+
+@pytest.mark.parametrize("model,n_images,cfg", [("eucm", 1000, 2), ("ucm", 257, 2), ("mei", 300, 4)])
+def test_batched_mono_matches_oracle(vg, S, model, n_images, cfg):
+    """config 2 (EUCM mono, 1k images x 96 corners) and the UCM / Mei variants, at the perturbed
+    evaluation point of SURVEY 8(d)."""
+    d = S.make_mono(model, n_images, cfg)
+    p = vg.CalibrationProblem(0)
+    cam = p.add_camera(model, d["init_intrinsics"])
+    seq = p.add_transform(False, d["init_poses"])
+    ds = p.add_dataset(cam, [(seq, 0)], d["board"], d["corners"])
+    p.finalize()
+    K = len(d["init_intrinsics"])
+    assert p.num_parameters == K + 6 * n_images
+    assert p.camera_offset(cam) == 0 and p.transform_offset(seq, 3) == K + 18
+    pv = p.get_parameters()
+    worst = _check_dataset(p, ds, model, [0], d["board"], d["corners"], pv, 0, [K], [6], np.arange(n_images))
+    assert p.failed_count(ds) == 0
+    # and at the generating point (residuals = noise, ~0.1 px)
+    pv2 = np.concatenate([d["gt_intrinsics"], d["gt_poses"].ravel()])
+    p.set_parameters(pv2)
+    _check_dataset(p, ds, model, [0], d["board"], d["corners"], pv2, 0, [K], [6], np.arange(n_images))
+    p.close()
+    print(model, "worst normalised errors (x1e-10):", {k: float("%.3g" % v) for k, v in worst.items()})
+
+
+def test_batched_stereo_shared_sequence_and_global_transform(vg, S):
+    """config 3 shape: cam-1 chain [xiCamBoard D], cam-2 chain [xiCam12 I, xiCamBoard D]; the pose sequence
+    is shared by both datasets and aligned by image index; cam-2 misses some frames (empty corner lists
+    are simply not listed, unified_calibration.cpp:520)."""
+    n = 200
+    s = S.make_stereo(n)
+    keep2 = np.array([i for i in range(n) if i % 7 != 3], dtype=np.int32)
+    p = vg.CalibrationProblem(0)
+    c1 = p.add_camera("eucm", s["init_intrinsics1"])
+    c2 = p.add_camera("eucm", s["init_intrinsics2"])
+    x12 = p.add_transform(True, s["init_xi12"])
+    seq = p.add_transform(False, s["init_poses"])
+    d1 = p.add_dataset(c1, [(seq, 0)], s["board"], s["corners1"])
+    d2 = p.add_dataset(c2, [(x12, 1), (seq, 0)], s["board"], s["corners2"][keep2], image_index=keep2)
+    p.finalize()
+    pv = p.get_parameters()
+    assert p.num_parameters == 12 + 6 + 6 * n
+    o12, oseq = p.transform_offset(x12), p.transform_offset(seq, 0)
+    assert (o12, oseq) == (12, 18)
+    _check_dataset(p, d1, "eucm", [0], s["board"], s["corners1"], pv, 0, [oseq], [6], np.arange(n))
+    _check_dataset(p, d2, "eucm", [1, 0], s["board"], s["corners2"][keep2], pv, 6, [o12, oseq], [0, 6], keep2)
+    # constant blocks: NULL Jacobians for intrinsics and the global transform
+    _check_dataset(p, d2, "eucm", [1, 0], s["board"], s["corners2"][keep2], pv, 6, [o12, oseq], [0, 6], keep2,
+                   jac_mask=[False, False, True])
+    p.close()
+
+
+@pytest.mark.parametrize("n_points,n_images", [(1, 700), (40, 33), (63, 9), (64, 8), (65, 7), (300, 5), (1000, 2)])
+def test_ragged_board_sizes(vg, S, n_points, n_images):
+    """N not a multiple of the wave / workgroup size, N > workgroup, N = 1 (frames-in-LDS and
+    frames-in-global variants of the emit kernel)."""
+    board = np.concatenate([RNG.uniform(0, 1.1, (n_points, 1)), RNG.uniform(0, 0.7, (n_points, 1)),
+                            RNG.uniform(-0.05, 0.05, (n_points, 1))], axis=1)  # explicit 3-D points (ir_data)
+    d = S.make_mono("eucm", n_images, 2)
+    corners = RNG.uniform(50, 1200, (n_images, n_points, 2))
+    for model in MODELS:
+        p = vg.CalibrationProblem(0)
+        cam = p.add_camera(model, S.GT[model])
+        glob = p.add_transform(True, [0.01, -0.02, 0.03, 0.02, 0.01, -0.03])
+        seq = p.add_transform(False, d["init_poses"])
+        ds = p.add_dataset(cam, [(glob, 0), (seq, 0)], board, corners)
+        p.finalize()
+        K = len(S.GT[model])
+        _check_dataset(p, ds, model, [0, 0], board, corners, p.get_parameters(), 0, [K, K + 6], [0, 6],
+                       np.arange(n_images))
+        p.close()
+
+
+def test_empty_dataset_and_failure_counter(vg, S):
+    d = S.make_mono("eucm", 4, 2)
+    p = vg.CalibrationProblem(0)
+    cam = p.add_camera("eucm", d["gt_intrinsics"])
+    poses = d["gt_poses"].copy()
+    poses[2] = [0, 0, -1, 0, 0, 0]  # board behind the camera: 94 of 96 corners fail (see test_oracle_golden)
+    seq = p.add_transform(False, poses)
+    empty = p.add_dataset(cam, [(seq, 0)], d["board"], np.zeros((0, 96, 2)))
+    ds = p.add_dataset(cam, [(seq, 0)], d["board"], d["corners"])
+    p.finalize()
+    res_t, ji_t, jm_t = p.alloc_outputs(empty)
+    p.prepare()
+    p.evaluate_dataset(empty, res_t, ji_t, jm_t)
+    p.synchronize()
+    assert res_t.numel() == 0 and p.failed_count(empty) == 0
+    _check_dataset(p, ds, "eucm", [0], d["board"], d["corners"], p.get_parameters(), 0, [6], [6], np.arange(4))
+    assert p.failed_count(ds) == 94
+    p.close()
+
+
+# ------------------------------------------------------------------ full size: BASELINE configs
+def test_full_size_10k_images_properties_and_oracle(vg, S):
+    """10 k images x 96 corners (the size the metric is quoted on).  The oracle finishes this size in
+    about a second, so it is compared directly; size-independent properties are checked on top:
+    (1) residual + obs is independent of obs (r = proj - obs exactly), (2) permuting the images permutes
+    the output blocks bit for bit, (3) J . dp matches a central difference of GPU cost-only evaluations."""
+    import torch
+
+    n = 10000
+    d = S.make_mono("eucm", n, 1)
+    p = vg.CalibrationProblem(0)
+    cam = p.add_camera("eucm", d["init_intrinsics"])
+    seq = p.add_transform(False, d["init_poses"])
+    ds = p.add_dataset(cam, [(seq, 0)], d["board"], d["corners"])
+    perm = RNG.permutation(n).astype(np.int32)
+    ds_perm = p.add_dataset(cam, [(seq, 0)], d["board"], d["corners"][perm], image_index=perm)
+    ds_zero = p.add_dataset(cam, [(seq, 0)], d["board"], np.zeros_like(d["corners"]))
+    p.finalize()
+    pv = p.get_parameters()
+    worst = _check_dataset(p, ds, "eucm", [0], d["board"], d["corners"], pv, 0, [6], [6], np.arange(n))
+    print("10k worst normalised errors (x1e-10):", {k: float("%.3g" % v) for k, v in worst.items()})
+
+    out = p.alloc_outputs(ds)
+    out_p = p.alloc_outputs(ds_perm)
+    out_z = p.alloc_outputs(ds_zero)
+    p.prepare()
+    p.evaluate_dataset(ds, *out)
+    p.evaluate_dataset(ds_perm, *out_p)
+    p.evaluate_dataset(ds_zero, *out_z)
+    p.synchronize()
+    tperm = torch.as_tensor(perm.astype(np.int64), device=out[0].device)
+    assert torch.equal(out_p[0], out[0][tperm]) and torch.equal(out_p[1], out[1][tperm])
+    assert torch.equal(out_p[2][0], out[2][0][tperm])
+    corners_t = torch.as_tensor(d["corners"].reshape(n, -1), device=out[0].device)
+    assert torch.equal(out_z[0] - corners_t, out[0])          # one subtraction, bit exact
+    assert torch.equal(out_z[1], out[1]) and torch.equal(out_z[2][0], out[2][0])
+
+    # directional derivative vs central difference of GPU residuals
+    dp = np.concatenate([np.array([1e-3, 1e-3, 1.0, 1.0, 1.0, 1.0]) * RNG.normal(0, 1, 6),
+                         1e-3 * RNG.normal(0, 1, pv.size - 6)])
+    h = 1e-4
+    rp = p.alloc_outputs(ds, want_jac=False)[0]
+    rm = torch.empty_like(rp)
+    p.set_parameters(pv + h * dp)
+    p.prepare()
+    p.evaluate_dataset(ds, rp)
+    p.set_parameters(pv - h * dp)
+    p.prepare()
+    p.evaluate_dataset(ds, rm)
+    p.synchronize()
+    fd = ((rp - rm) / (2 * h)).cpu().numpy()
+    Ji, Jp = out[1].cpu().numpy(), out[2][0].cpu().numpy()
+    jd = Ji @ dp[:6] + np.einsum("brc,bc->br", Jp, dp[6:].reshape(n, 6))
+    assert np.max(np.abs(fd - jd)) <= 1e-5 * np.max(np.abs(jd))
+    p.close()

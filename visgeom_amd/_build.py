@@ -1,0 +1,56 @@
+"""In-tree build of the HIP library (gfx950 only).  `python -m visgeom_amd._build` or
+`__graft_entry__.build()`.  hipcc cross-compiles without a GPU."""
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+LIB_DIR = os.path.join(PKG, "lib")
+LIB = os.path.join(LIB_DIR, "libvisgeom_amd.so")
+
+# -ffp-contract=off: keep the per-corner arithmetic in the reference's evaluation order (no FMA
+# fusion), so that GPU and oracle differ only through libm-vs-ocml trig in the chain prep.  The emit
+# kernel is HBM bound, the extra VALU instructions are not on the critical path.
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+               "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+
+
+def sources():
+    return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
+
+
+def _deps():
+    out = []
+    for d in (CSRC, os.path.join(ROOT, "include")):
+        for f in os.listdir(d):
+            if f.endswith((".hip", ".hpp", ".h")):
+                out.append(os.path.join(d, f))
+    return out
+
+
+def up_to_date():
+    if not os.path.exists(LIB):
+        return False
+    t = os.path.getmtime(LIB)
+    return all(os.path.getmtime(f) <= t for f in _deps())
+
+
+def build(force=False, verbose=False):
+    if not force and up_to_date():
+        return LIB
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found: the HIP library cannot be built (there is no CPU fallback)")
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [hipcc] + HIPCC_FLAGS + ["-I", os.path.join(ROOT, "include"), "-o", LIB] + sources()
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

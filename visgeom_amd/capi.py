@@ -1,0 +1,104 @@
+"""ctypes binding of include/visgeom_amd.h (the C ABI is the product boundary; this file is plumbing).
+
+The library is HIP-only.  If it has not been built this module raises -- it never falls back to
+a CPU implementation."""
+import ctypes
+import os
+
+from . import _build
+
+_dp = ctypes.POINTER(ctypes.c_double)
+_dpp = ctypes.POINTER(_dp)
+_ip = ctypes.POINTER(ctypes.c_int)
+_i32p = ctypes.POINTER(ctypes.c_int32)
+_i64p = ctypes.POINTER(ctypes.c_int64)
+_vp = ctypes.c_void_p
+_vpp = ctypes.POINTER(ctypes.c_void_p)
+
+MODEL_EUCM, MODEL_UCM, MODEL_MEI = 0, 1, 2
+MODELS = {"eucm": MODEL_EUCM, "ucm": MODEL_UCM, "mei": MODEL_MEI}
+NUM_INTRINSICS = {MODEL_EUCM: 6, MODEL_UCM: 5, MODEL_MEI: 10}
+TRANSFORM_DIRECT, TRANSFORM_INVERSE = 0, 1
+MAX_CHAIN = 5
+DOUBLE_BIG = 1e15
+OK = 0
+ERR_INVALID_ARGUMENT, ERR_HIP, ERR_NO_DEVICE, ERR_STATE, ERR_ALLOC, ERR_NUMERIC = 1, 2, 3, 4, 5, 6
+
+# every symbol include/visgeom_amd.h declares: (restype, argtypes)
+SIGNATURES = {
+    "vg_abi_version": (ctypes.c_int, []),
+    "vg_last_error": (ctypes.c_char_p, []),
+    "vg_device_count": (ctypes.c_int, []),
+    "vg_num_intrinsics": (ctypes.c_int, [ctypes.c_int]),
+    "vg_intrinsic_bounds": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _dp, _dp]),
+    "vg_block_create": (ctypes.c_int, [_vpp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _ip, ctypes.c_int, _dp, _dp]),
+    "vg_block_num_residuals": (ctypes.c_int, [_vp]),
+    "vg_block_num_parameter_blocks": (ctypes.c_int, [_vp]),
+    "vg_block_parameter_block_size": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "vg_block_evaluate": (ctypes.c_int, [_vp, _dpp, _dp, _dpp]),
+    "vg_block_destroy": (None, [_vp]),
+    "vg_problem_create": (ctypes.c_int, [_vpp, ctypes.c_int, _vp]),
+    "vg_problem_destroy": (None, [_vp]),
+    "vg_problem_add_camera": (ctypes.c_int, [_vp, ctypes.c_int, _dp, ctypes.c_int, _ip]),
+    "vg_problem_add_transform": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp, _ip]),
+    "vg_problem_add_dataset": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _ip, _ip, ctypes.c_int, _dp,
+                                              ctypes.c_int64, _i32p, _dp, _ip]),
+    "vg_problem_finalize": (ctypes.c_int, [_vp]),
+    "vg_problem_num_parameters": (ctypes.c_int64, [_vp]),
+    "vg_problem_camera_offset": (ctypes.c_int64, [_vp, ctypes.c_int]),
+    "vg_problem_transform_offset": (ctypes.c_int64, [_vp, ctypes.c_int, ctypes.c_int64]),
+    "vg_problem_set_parameters": (ctypes.c_int, [_vp, _dp]),
+    "vg_problem_get_parameters": (ctypes.c_int, [_vp, _dp]),
+    "vg_problem_parameters_device": (_vp, [_vp]),
+    "vg_problem_num_datasets": (ctypes.c_int, [_vp]),
+    "vg_dataset_num_blocks": (ctypes.c_int64, [_vp, ctypes.c_int]),
+    "vg_dataset_num_points": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "vg_dataset_chain_len": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "vg_dataset_num_intrinsics": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "vg_problem_prepare": (ctypes.c_int, [_vp]),
+    "vg_dataset_evaluate": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vpp]),
+    "vg_problem_synchronize": (ctypes.c_int, [_vp]),
+    "vg_dataset_failed_count": (ctypes.c_int, [_vp, ctypes.c_int, _i64p]),
+    "vg_calib_stream_write": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_double]),
+    "vg_calib_stream_copy": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64]),
+}
+
+
+class VisgeomError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("visgeom_amd error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def lib_path():
+    return _build.LIB
+
+
+def load():
+    """Load libvisgeom_amd.so.  Raises if it is missing -- build it with
+    `python -c "import __graft_entry__ as g; g.build()"`; there is no CPU fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_build.LIB):
+        raise ImportError("%s is missing: run `python -m visgeom_amd._build` (needs hipcc). "
+                          "visgeom_amd is HIP-only and has no CPU fallback." % _build.LIB)
+    try:  # make torch's bundled HIP runtime the one this process uses (same SONAME, libamdhip64.so.7)
+        import torch  # noqa: F401
+    except Exception:  # the library also works stand-alone against /opt/rocm
+        pass
+    L = ctypes.CDLL(_build.LIB)
+    for name, (res, args) in SIGNATURES.items():
+        f = getattr(L, name)  # AttributeError here = header / library mismatch
+        f.restype = res
+        f.argtypes = args
+    _lib = L
+    return L
+
+
+def check(code):
+    if code != OK:
+        raise VisgeomError(code, load().vg_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,574 @@
+// vg_capi.hip -- implementation of include/visgeom_amd.h (host side + kernel launches).
+// Built with hipcc for gfx950 only.  No CPU fallback: every compute entry needs a HIP device.
+#include "../../include/visgeom_amd.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "vg_kernels.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define VG_HIP(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            return fail(e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice ? VG_ERR_NO_DEVICE  \
+                                                                              : VG_ERR_HIP,       \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                       \
+        }                                                                                         \
+    } while (0)
+
+struct Camera {
+    int model = 0, K = 0;
+    bool constant = false;
+    int64_t offset = -1;
+    std::vector<double> init;
+};
+
+struct Transform {
+    bool global = true, constant = false;
+    int64_t count = 1;
+    int64_t offset = -1;
+    std::vector<double> init;
+};
+
+struct Dataset {
+    int camera = -1, L = 0, N = 0;
+    int tids[vg::kMaxChain] = {0};
+    int status[vg::kMaxChain] = {0};
+    int64_t n_blocks = 0;
+    std::vector<double> h_board, h_obs;
+    std::vector<int32_t> h_seq;
+    double *d_board = nullptr, *d_obs = nullptr, *d_frames = nullptr;
+    int32_t *d_seq = nullptr;
+    unsigned long long *d_failed = nullptr;
+    int frame_stride = 0;
+    vg::ChainDesc chain;
+};
+
+}  // namespace
+
+struct vg_problem {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool finalized = false;
+    std::vector<Camera> cams;
+    std::vector<Transform> tfs;
+    std::vector<Dataset> dss;
+    int64_t n_params = 0;
+    double *d_params = nullptr;
+};
+
+struct vg_block {
+    vg_problem *p = nullptr;
+    int model = 0, K = 0, L = 0, N = 0;
+    double *d_res = nullptr, *d_jintr = nullptr;
+    double *d_jm[vg::kMaxChain] = {nullptr};
+    std::vector<double> h_params;
+};
+
+namespace {
+
+int check_device(int device)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(VG_ERR_NO_DEVICE, std::string("no HIP device available (") +
+                                          (e == hipSuccess ? "device count 0" : hipGetErrorString(e)) +
+                                          "); visgeom_amd has no CPU fallback");
+    if (device < 0 || device >= n) return fail(VG_ERR_INVALID_ARGUMENT, "device index out of range");
+    return VG_OK;
+}
+
+void free_dataset(Dataset &d)
+{
+    if (d.d_board) (void)hipFree(d.d_board);
+    if (d.d_obs) (void)hipFree(d.d_obs);
+    if (d.d_frames) (void)hipFree(d.d_frames);
+    if (d.d_seq) (void)hipFree(d.d_seq);
+    if (d.d_failed) (void)hipFree(d.d_failed);
+    d.d_board = d.d_obs = d.d_frames = nullptr;
+    d.d_seq = nullptr;
+    d.d_failed = nullptr;
+}
+
+template <int MODEL>
+size_t emit_lds_bytes(bool want_jac, bool frames_lds, int N, int frame_stride)
+{
+    size_t bytes = 0;
+    // the tile region is always reserved so the frame region's offset does not depend on WANT_JAC
+    bytes += (size_t)(vg::kEmitThreads / vg::kWave) * vg::emit_stage_doubles_per_wave<MODEL>() * sizeof(double);
+    (void)want_jac;
+    if (frames_lds) bytes += (size_t)(vg::kEmitThreads / N + 2) * frame_stride * sizeof(double);
+    return bytes;
+}
+
+template <int MODEL>
+int launch_emit(hipStream_t stream, const vg::EmitArgs &a, bool want_jac)
+{
+    const int max_frames = vg::kEmitThreads / (int)a.N + 2;
+    const bool frames_lds = (size_t)max_frames * a.frame_stride_d * sizeof(double) <= 32 * 1024;
+    const size_t lds = emit_lds_bytes<MODEL>(want_jac, frames_lds, (int)a.N, a.frame_stride_d);
+    const unsigned int grid = (a.n_obs + vg::kEmitThreads - 1) / vg::kEmitThreads;
+    if (want_jac) {
+        if (frames_lds)
+            hipLaunchKernelGGL((vg::vg_emit_kernel<MODEL, true, true>), dim3(grid), dim3(vg::kEmitThreads), lds, stream, a);
+        else
+            hipLaunchKernelGGL((vg::vg_emit_kernel<MODEL, true, false>), dim3(grid), dim3(vg::kEmitThreads), lds, stream, a);
+    } else {
+        if (frames_lds)
+            hipLaunchKernelGGL((vg::vg_emit_kernel<MODEL, false, true>), dim3(grid), dim3(vg::kEmitThreads), lds, stream, a);
+        else
+            hipLaunchKernelGGL((vg::vg_emit_kernel<MODEL, false, false>), dim3(grid), dim3(vg::kEmitThreads), lds, stream, a);
+    }
+    VG_HIP(hipGetLastError());
+    return VG_OK;
+}
+
+int valid_dataset(const vg_problem *p, int d)
+{
+    if (!p) return fail(VG_ERR_INVALID_ARGUMENT, "problem is NULL");
+    if (d < 0 || d >= (int)p->dss.size()) return fail(VG_ERR_INVALID_ARGUMENT, "dataset id out of range");
+    return VG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vg_abi_version(void) { return VG_ABI_VERSION; }
+
+const char *vg_last_error(void) { return g_err.c_str(); }
+
+int vg_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int vg_num_intrinsics(int model) { return vg::num_intrinsics(model); }
+
+int vg_intrinsic_bounds(int model, int idx, double *lower, double *upper)
+{
+    const int K = vg::num_intrinsics(model);
+    if (K < 0 || idx < 0 || idx >= K || !lower || !upper) return fail(VG_ERR_INVALID_ARGUMENT, "bad model / index");
+    double lo = 1., hi = 1e5;  // "the rest": focal lengths and centre
+    if (model == VG_MODEL_EUCM) {          // eucm.h:228-246
+        if (idx == 0) { lo = 0.; hi = 1.; }
+        else if (idx == 1) { lo = 0.1; hi = 10.; }
+    } else if (model == VG_MODEL_UCM) {    // ucm.h:199-215
+        if (idx == 0) { lo = 0.; hi = 3.; }
+    } else {                               // mei.h:287-313
+        if (idx == 0) { lo = 0.; hi = 3.; }
+        else if (idx <= 5) { lo = -10.; hi = 10.; }
+    }
+    *lower = lo;
+    *upper = hi;
+    return VG_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ problem */
+
+int vg_problem_create(vg_problem **out, int device, void *hip_stream)
+{
+    if (!out) return fail(VG_ERR_INVALID_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    int rc = check_device(device);
+    if (rc != VG_OK) return rc;
+    VG_HIP(hipSetDevice(device));
+    vg_problem *p = new (std::nothrow) vg_problem();
+    if (!p) return fail(VG_ERR_ALLOC, "out of host memory");
+    p->device = device;
+    p->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    *out = p;
+    return VG_OK;
+}
+
+void vg_problem_destroy(vg_problem *p)
+{
+    if (!p) return;
+    (void)hipSetDevice(p->device);
+    for (auto &d : p->dss) free_dataset(d);
+    if (p->d_params) (void)hipFree(p->d_params);
+    delete p;
+}
+
+int vg_problem_add_camera(vg_problem *p, int model, const double *intrinsics, int constant, int *camera_id)
+{
+    if (!p || !intrinsics) return fail(VG_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (p->finalized) return fail(VG_ERR_STATE, "problem already finalized");
+    const int K = vg::num_intrinsics(model);
+    if (K < 0) return fail(VG_ERR_INVALID_ARGUMENT, "unknown camera model");  // :177 throws
+    Camera c;
+    c.model = model;
+    c.K = K;
+    c.constant = constant != 0;
+    c.init.assign(intrinsics, intrinsics + K);
+    p->cams.push_back(c);
+    if (camera_id) *camera_id = (int)p->cams.size() - 1;
+    return VG_OK;
+}
+
+int vg_problem_add_transform(vg_problem *p, int is_global, int constant, int count, const double *values,
+                             int *transform_id)
+{
+    if (!p) return fail(VG_ERR_INVALID_ARGUMENT, "problem is NULL");
+    if (p->finalized) return fail(VG_ERR_STATE, "problem already finalized");
+    if (is_global) count = 1;
+    if (count < 0) return fail(VG_ERR_INVALID_ARGUMENT, "negative transform count");
+    Transform t;
+    t.global = is_global != 0;
+    t.constant = constant != 0;
+    t.count = count;
+    t.init.assign((size_t)count * 6, 0.);
+    if (values) std::memcpy(t.init.data(), values, sizeof(double) * 6 * (size_t)count);
+    p->tfs.push_back(t);
+    if (transform_id) *transform_id = (int)p->tfs.size() - 1;
+    return VG_OK;
+}
+
+int vg_problem_add_dataset(vg_problem *p, int camera_id, int chain_len, const int *transform_ids, const int *status,
+                           int n_points, const double *board, int64_t n_images, const int32_t *image_index,
+                           const double *corners, int *dataset_id)
+{
+    if (!p) return fail(VG_ERR_INVALID_ARGUMENT, "problem is NULL");
+    if (p->finalized) return fail(VG_ERR_STATE, "problem already finalized");
+    if (camera_id < 0 || camera_id >= (int)p->cams.size()) return fail(VG_ERR_INVALID_ARGUMENT, "camera id out of range");
+    if (chain_len < 0 || chain_len > VG_MAX_CHAIN)
+        return fail(VG_ERR_INVALID_ARGUMENT, "chain length must be in [0, 5]");  // :566-567 throws above 5
+    if (chain_len > 0 && (!transform_ids || !status)) return fail(VG_ERR_INVALID_ARGUMENT, "chain arrays are NULL");
+    if (n_points <= 0 || !board) return fail(VG_ERR_INVALID_ARGUMENT, "empty board");
+    if (n_images < 0 || (n_images > 0 && !corners)) return fail(VG_ERR_INVALID_ARGUMENT, "corners are NULL");
+    Dataset d;
+    d.camera = camera_id;
+    d.L = chain_len;
+    d.N = n_points;
+    d.n_blocks = n_images;
+    int64_t min_seq = -1;
+    for (int l = 0; l < chain_len; l++) {
+        const int t = transform_ids[l];
+        if (t < 0 || t >= (int)p->tfs.size()) return fail(VG_ERR_INVALID_ARGUMENT, "transform id out of range");
+        if (status[l] != VG_TRANSFORM_DIRECT && status[l] != VG_TRANSFORM_INVERSE)
+            return fail(VG_ERR_INVALID_ARGUMENT, "status must be DIRECT or INVERSE");
+        d.tids[l] = t;
+        d.status[l] = status[l];
+        if (!p->tfs[t].global && (min_seq < 0 || p->tfs[t].count < min_seq)) min_seq = p->tfs[t].count;
+    }
+    d.h_seq.resize((size_t)n_images);
+    for (int64_t i = 0; i < n_images; i++) {
+        const int64_t idx = image_index ? image_index[i] : i;
+        if (idx < 0 || (min_seq >= 0 && idx >= min_seq))
+            return fail(VG_ERR_INVALID_ARGUMENT, "image index outside the sequence transform");
+        d.h_seq[(size_t)i] = (int32_t)idx;
+    }
+    d.h_board.assign(board, board + 3 * (size_t)n_points);
+    d.h_obs.assign(corners, corners + (size_t)n_images * 2 * n_points);
+    p->dss.push_back(std::move(d));
+    if (dataset_id) *dataset_id = (int)p->dss.size() - 1;
+    return VG_OK;
+}
+
+int vg_problem_finalize(vg_problem *p)
+{
+    if (!p) return fail(VG_ERR_INVALID_ARGUMENT, "problem is NULL");
+    if (p->finalized) return fail(VG_ERR_STATE, "problem already finalized");
+    VG_HIP(hipSetDevice(p->device));
+    int64_t off = 0;
+    for (auto &c : p->cams) { c.offset = off; off += c.K; }
+    for (auto &t : p->tfs) { t.offset = off; off += 6 * t.count; }
+    p->n_params = off;
+    std::vector<double> h((size_t)off, 0.);
+    for (auto &c : p->cams) std::memcpy(h.data() + c.offset, c.init.data(), sizeof(double) * c.K);
+    for (auto &t : p->tfs)
+        if (t.count) std::memcpy(h.data() + t.offset, t.init.data(), sizeof(double) * 6 * (size_t)t.count);
+    VG_HIP(hipMalloc(&p->d_params, sizeof(double) * (size_t)(off > 0 ? off : 1)));
+    if (off) VG_HIP(hipMemcpy(p->d_params, h.data(), sizeof(double) * (size_t)off, hipMemcpyHostToDevice));
+
+    for (auto &d : p->dss) {
+        d.frame_stride = vg::frame_stride(d.L);
+        d.chain.L = d.L;
+        for (int l = 0; l < vg::kMaxChain; l++) {
+            d.chain.status[l] = 0;
+            d.chain.base[l] = 0;
+            d.chain.stride[l] = 0;
+        }
+        for (int l = 0; l < d.L; l++) {
+            const Transform &t = p->tfs[d.tids[l]];
+            d.chain.status[l] = d.status[l];
+            d.chain.base[l] = t.offset;
+            d.chain.stride[l] = t.global ? 0 : 6;
+        }
+        const size_t nb = (size_t)d.n_blocks;
+        VG_HIP(hipMalloc(&d.d_board, sizeof(double) * 3 * (size_t)d.N));
+        VG_HIP(hipMemcpy(d.d_board, d.h_board.data(), sizeof(double) * 3 * (size_t)d.N, hipMemcpyHostToDevice));
+        VG_HIP(hipMalloc(&d.d_obs, sizeof(double) * (nb ? nb : 1) * 2 * d.N));
+        VG_HIP(hipMalloc(&d.d_seq, sizeof(int32_t) * (nb ? nb : 1)));
+        VG_HIP(hipMalloc(&d.d_frames, sizeof(double) * (nb ? nb : 1) * d.frame_stride));
+        VG_HIP(hipMalloc(&d.d_failed, sizeof(unsigned long long)));
+        VG_HIP(hipMemset(d.d_failed, 0, sizeof(unsigned long long)));
+        if (nb) {
+            VG_HIP(hipMemcpy(d.d_obs, d.h_obs.data(), sizeof(double) * nb * 2 * d.N, hipMemcpyHostToDevice));
+            VG_HIP(hipMemcpy(d.d_seq, d.h_seq.data(), sizeof(int32_t) * nb, hipMemcpyHostToDevice));
+        }
+        // host copies are no longer needed; everything stays resident in HBM
+        std::vector<double>().swap(d.h_obs);
+    }
+    p->finalized = true;
+    return VG_OK;
+}
+
+int64_t vg_problem_num_parameters(const vg_problem *p) { return p && p->finalized ? p->n_params : -1; }
+
+int64_t vg_problem_camera_offset(const vg_problem *p, int camera_id)
+{
+    if (!p || !p->finalized || camera_id < 0 || camera_id >= (int)p->cams.size()) return -1;
+    return p->cams[camera_id].offset;
+}
+
+int64_t vg_problem_transform_offset(const vg_problem *p, int transform_id, int64_t index)
+{
+    if (!p || !p->finalized || transform_id < 0 || transform_id >= (int)p->tfs.size()) return -1;
+    const Transform &t = p->tfs[transform_id];
+    if (index < 0 || index >= t.count) return -1;
+    return t.offset + 6 * index;
+}
+
+int vg_problem_set_parameters(vg_problem *p, const double *host_params)
+{
+    if (!p || !host_params) return fail(VG_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!p->finalized) return fail(VG_ERR_STATE, "problem not finalized");
+    VG_HIP(hipSetDevice(p->device));
+    VG_HIP(hipMemcpyAsync(p->d_params, host_params, sizeof(double) * (size_t)p->n_params, hipMemcpyHostToDevice, p->stream));
+    VG_HIP(hipStreamSynchronize(p->stream));
+    return VG_OK;
+}
+
+int vg_problem_get_parameters(vg_problem *p, double *host_params)
+{
+    if (!p || !host_params) return fail(VG_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!p->finalized) return fail(VG_ERR_STATE, "problem not finalized");
+    VG_HIP(hipSetDevice(p->device));
+    VG_HIP(hipMemcpyAsync(host_params, p->d_params, sizeof(double) * (size_t)p->n_params, hipMemcpyDeviceToHost, p->stream));
+    VG_HIP(hipStreamSynchronize(p->stream));
+    return VG_OK;
+}
+
+double *vg_problem_parameters_device(vg_problem *p) { return p && p->finalized ? p->d_params : nullptr; }
+
+int vg_problem_num_datasets(const vg_problem *p) { return p ? (int)p->dss.size() : -1; }
+int64_t vg_dataset_num_blocks(const vg_problem *p, int d) { return valid_dataset(p, d) == VG_OK ? p->dss[d].n_blocks : -1; }
+int vg_dataset_num_points(const vg_problem *p, int d) { return valid_dataset(p, d) == VG_OK ? p->dss[d].N : -1; }
+int vg_dataset_chain_len(const vg_problem *p, int d) { return valid_dataset(p, d) == VG_OK ? p->dss[d].L : -1; }
+int vg_dataset_num_intrinsics(const vg_problem *p, int d)
+{
+    return valid_dataset(p, d) == VG_OK ? p->cams[p->dss[d].camera].K : -1;
+}
+
+int vg_problem_prepare(vg_problem *p)
+{
+    if (!p) return fail(VG_ERR_INVALID_ARGUMENT, "problem is NULL");
+    if (!p->finalized) return fail(VG_ERR_STATE, "problem not finalized");
+    VG_HIP(hipSetDevice(p->device));
+    for (auto &d : p->dss) {
+        if (!d.n_blocks) continue;
+        const unsigned int grid = (unsigned int)((d.n_blocks + 63) / 64);
+        hipLaunchKernelGGL(vg::vg_chain_prep_kernel, dim3(grid), dim3(64), 0, p->stream, p->d_params, d.chain,
+                           d.d_seq, (long long)d.n_blocks, d.d_frames, d.frame_stride);
+        VG_HIP(hipGetLastError());
+    }
+    return VG_OK;
+}
+
+int vg_dataset_evaluate(vg_problem *p, int dataset_id, double *residuals, double *jac_intr, double *const *jac_member)
+{
+    int rc = valid_dataset(p, dataset_id);
+    if (rc != VG_OK) return rc;
+    if (!p->finalized) return fail(VG_ERR_STATE, "problem not finalized");
+    if (!residuals) return fail(VG_ERR_INVALID_ARGUMENT, "residuals is NULL");
+    VG_HIP(hipSetDevice(p->device));
+    Dataset &d = p->dss[dataset_id];
+    const Camera &cam = p->cams[d.camera];
+    bool want_jac = jac_intr != nullptr;
+    for (int l = 0; l < d.L; l++)
+        if (jac_member && jac_member[l]) want_jac = true;
+    VG_HIP(hipMemsetAsync(d.d_failed, 0, sizeof(unsigned long long), p->stream));
+    if (!d.n_blocks) return VG_OK;
+
+    // 32-bit observation indices inside a launch: chunk very large datasets by whole images
+    const int64_t max_blocks_per_launch = ((int64_t)1 << 30) / d.N > 0 ? ((int64_t)1 << 30) / d.N : 1;
+    for (int64_t b0 = 0; b0 < d.n_blocks; b0 += max_blocks_per_launch) {
+        const int64_t nb = d.n_blocks - b0 < max_blocks_per_launch ? d.n_blocks - b0 : max_blocks_per_launch;
+        vg::EmitArgs a;
+        a.frames = d.d_frames + (size_t)b0 * d.frame_stride;
+        a.board = d.d_board;
+        a.obs = d.d_obs + (size_t)b0 * 2 * d.N;
+        a.intr = p->d_params + cam.offset;
+        a.res = residuals + (size_t)b0 * 2 * d.N;
+        a.jac_intr = jac_intr ? jac_intr + (size_t)b0 * 2 * d.N * cam.K : nullptr;
+        for (int l = 0; l < vg::kMaxChain; l++)
+            a.jac_member[l] = (l < d.L && jac_member && jac_member[l]) ? jac_member[l] + (size_t)b0 * 2 * d.N * 6 : nullptr;
+        a.failed = d.d_failed;
+        a.n_obs = (unsigned int)(nb * d.N);
+        a.N = (unsigned int)d.N;
+        a.L = d.L;
+        a.frame_stride_d = d.frame_stride;
+        switch (cam.model) {
+        case VG_MODEL_EUCM: rc = launch_emit<vg::kEUCM>(p->stream, a, want_jac); break;
+        case VG_MODEL_UCM: rc = launch_emit<vg::kUCM>(p->stream, a, want_jac); break;
+        default: rc = launch_emit<vg::kMEI>(p->stream, a, want_jac); break;
+        }
+        if (rc != VG_OK) return rc;
+    }
+    return VG_OK;
+}
+
+int vg_problem_synchronize(vg_problem *p)
+{
+    if (!p) return fail(VG_ERR_INVALID_ARGUMENT, "problem is NULL");
+    VG_HIP(hipSetDevice(p->device));
+    VG_HIP(hipStreamSynchronize(p->stream));
+    return VG_OK;
+}
+
+int vg_dataset_failed_count(vg_problem *p, int dataset_id, int64_t *count)
+{
+    int rc = valid_dataset(p, dataset_id);
+    if (rc != VG_OK) return rc;
+    if (!count) return fail(VG_ERR_INVALID_ARGUMENT, "count is NULL");
+    if (!p->finalized) return fail(VG_ERR_STATE, "problem not finalized");
+    VG_HIP(hipSetDevice(p->device));
+    unsigned long long v = 0;
+    VG_HIP(hipMemcpyAsync(&v, p->dss[dataset_id].d_failed, sizeof v, hipMemcpyDeviceToHost, p->stream));
+    VG_HIP(hipStreamSynchronize(p->stream));
+    *count = (int64_t)v;
+    return VG_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ per-block */
+
+int vg_block_create(vg_block **out, int device, int model, int chain_len, const int *status, int n_points,
+                    const double *grid, const double *obs)
+{
+    if (!out) return fail(VG_ERR_INVALID_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    const int K = vg::num_intrinsics(model);
+    if (K < 0) return fail(VG_ERR_INVALID_ARGUMENT, "unknown camera model");
+    if (chain_len < 0 || chain_len > VG_MAX_CHAIN) return fail(VG_ERR_INVALID_ARGUMENT, "chain length must be in [0, 5]");
+    if (n_points <= 0 || !grid || !obs) return fail(VG_ERR_INVALID_ARGUMENT, "empty block");
+    vg_block *b = new (std::nothrow) vg_block();
+    if (!b) return fail(VG_ERR_ALLOC, "out of host memory");
+    b->model = model;
+    b->K = K;
+    b->L = chain_len;
+    b->N = n_points;
+    int rc = vg_problem_create(&b->p, device, nullptr);
+    std::vector<double> zeros(VG_MAX_INTRINSICS, 0.);
+    int cam = -1, ds = -1, tids[vg::kMaxChain] = {0};
+    if (rc == VG_OK) rc = vg_problem_add_camera(b->p, model, zeros.data(), 0, &cam);
+    for (int l = 0; l < chain_len && rc == VG_OK; l++) rc = vg_problem_add_transform(b->p, 1, 0, 1, nullptr, &tids[l]);
+    if (rc == VG_OK) rc = vg_problem_add_dataset(b->p, cam, chain_len, tids, status, n_points, grid, 1, nullptr, obs, &ds);
+    if (rc == VG_OK) rc = vg_problem_finalize(b->p);
+    if (rc == VG_OK) {
+        const size_t rows = 2 * (size_t)n_points;
+        hipError_t e = hipMalloc(&b->d_res, sizeof(double) * rows);
+        if (e == hipSuccess) e = hipMalloc(&b->d_jintr, sizeof(double) * rows * K);
+        for (int l = 0; l < chain_len && e == hipSuccess; l++) e = hipMalloc(&b->d_jm[l], sizeof(double) * rows * 6);
+        if (e != hipSuccess) rc = fail(VG_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+    }
+    if (rc != VG_OK) {
+        vg_block_destroy(b);
+        return rc;
+    }
+    b->h_params.assign((size_t)K + 6 * (size_t)chain_len, 0.);
+    *out = b;
+    return VG_OK;
+}
+
+int vg_block_num_residuals(const vg_block *b) { return b ? 2 * b->N : -1; }
+int vg_block_num_parameter_blocks(const vg_block *b) { return b ? 1 + b->L : -1; }
+int vg_block_parameter_block_size(const vg_block *b, int idx)
+{
+    if (!b || idx < 0 || idx > b->L) return -1;
+    return idx == 0 ? b->K : 6;
+}
+
+int vg_block_evaluate(vg_block *b, double const *const *parameters, double *residuals, double **jacobians)
+{
+    if (!b || !parameters || !residuals) return fail(VG_ERR_INVALID_ARGUMENT, "NULL argument");
+    for (int i = 0; i <= b->L; i++)
+        if (!parameters[i]) return fail(VG_ERR_INVALID_ARGUMENT, "NULL parameter block");
+    // parameter vector layout of the one-image problem: [intrinsics | member 0 | member 1 ...]
+    std::memcpy(b->h_params.data(), parameters[0], sizeof(double) * b->K);
+    for (int l = 0; l < b->L; l++) std::memcpy(b->h_params.data() + b->K + 6 * l, parameters[1 + l], sizeof(double) * 6);
+    int rc = vg_problem_set_parameters(b->p, b->h_params.data());
+    if (rc != VG_OK) return rc;
+    rc = vg_problem_prepare(b->p);
+    if (rc != VG_OK) return rc;
+    double *jm[vg::kMaxChain] = {nullptr};
+    double *ji = nullptr;
+    if (jacobians) {
+        if (jacobians[0]) ji = b->d_jintr;
+        for (int l = 0; l < b->L; l++)
+            if (jacobians[1 + l]) jm[l] = b->d_jm[l];
+    }
+    rc = vg_dataset_evaluate(b->p, 0, b->d_res, ji, jm);
+    if (rc != VG_OK) return rc;
+    const size_t rows = 2 * (size_t)b->N;
+    hipStream_t s = b->p->stream;
+    VG_HIP(hipMemcpyAsync(residuals, b->d_res, sizeof(double) * rows, hipMemcpyDeviceToHost, s));
+    if (ji) VG_HIP(hipMemcpyAsync(jacobians[0], ji, sizeof(double) * rows * b->K, hipMemcpyDeviceToHost, s));
+    for (int l = 0; l < b->L; l++)
+        if (jm[l]) VG_HIP(hipMemcpyAsync(jacobians[1 + l], jm[l], sizeof(double) * rows * 6, hipMemcpyDeviceToHost, s));
+    VG_HIP(hipStreamSynchronize(s));
+    return VG_OK;
+}
+
+void vg_block_destroy(vg_block *b)
+{
+    if (!b) return;
+    if (b->p) (void)hipSetDevice(b->p->device);
+    if (b->d_res) (void)hipFree(b->d_res);
+    if (b->d_jintr) (void)hipFree(b->d_jintr);
+    for (int l = 0; l < vg::kMaxChain; l++)
+        if (b->d_jm[l]) (void)hipFree(b->d_jm[l]);
+    vg_problem_destroy(b->p);
+    delete b;
+}
+
+/* ------------------------------------------------------------------------------------------ measurement helpers */
+
+int vg_calib_stream_write(void *hip_stream, double *dst, int64_t n_doubles, double value)
+{
+    if (!dst || n_doubles < 0 || (n_doubles & 1)) return fail(VG_ERR_INVALID_ARGUMENT, "need an even number of doubles");
+    hipLaunchKernelGGL(vg::vg_stream_write_kernel, dim3(2048), dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream),
+                       dst, (long long)(n_doubles / 2), value);
+    VG_HIP(hipGetLastError());
+    return VG_OK;
+}
+
+int vg_calib_stream_copy(void *hip_stream, double *dst, const double *src, int64_t n_doubles)
+{
+    if (!dst || !src || n_doubles < 0 || (n_doubles & 1)) return fail(VG_ERR_INVALID_ARGUMENT, "need an even number of doubles");
+    hipLaunchKernelGGL(vg::vg_stream_copy_kernel, dim3(2048), dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream),
+                       dst, src, (long long)(n_doubles / 2));
+    VG_HIP(hipGetLastError());
+    return VG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,290 @@
+// vg_geometry.hpp -- SE(3) primitives of the calibration hot path, device + host.
+//
+// Semantics (branch thresholds, operation order) follow the reference headers cited on each
+// function (paths relative to /root/reference); the code is written for one GPU lane per
+// transform chain: plain doubles, no matrix class, trig shared between the three places that
+// need the same angle (quaternion, Rodrigues matrix, interaction matrix).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#define VG_HD __host__ __device__ __forceinline__
+
+namespace vg {
+
+struct Quat {
+    double x, y, z, w;
+};
+
+// translation + rotation vector, parameter order [t(3), r(3)]  (geometry/transformation.h:46)
+struct Transf {
+    double t[3];
+    double r[3];
+};
+
+VG_HD double norm3(const double *v) { return sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
+
+VG_HD void sincos_(double x, double *s, double *c)
+{
+    // same reduction for both -> one range reduction per angle instead of two
+    ::sincos(x, s, c);
+}
+
+// geometry/geometry_core.h:24-30
+VG_HD double sinc_from(double x, double sinx) { return x == 0. ? 1. : sinx / x; }
+
+// Trig of one rotation vector, evaluated once and shared (every consumer below needs the same
+// theta = |v|: Quaternion(v) needs sin/cos(theta/2), rotationMatrix(+-v) sin/cos(theta),
+// interOmegaRot(v) sin(theta/2) and sin(theta)).
+struct RotTrig {
+    double th;      // |v|
+    double s, c;    // sin(th), cos(th)
+    double sh, ch;  // sin(th/2.), cos(th/2.)
+};
+
+VG_HD RotTrig rot_trig(const double *v, bool need_full, bool need_half)
+{
+    RotTrig q;
+    q.th = norm3(v);
+    q.s = 0.; q.c = 1.; q.sh = 0.; q.ch = 1.;
+    if (need_full && !(q.th < 1e-5)) sincos_(q.th, &q.s, &q.c);
+    if (need_half && !(fabs(q.th) < 1e-6)) sincos_(q.th / 2., &q.sh, &q.ch);
+    return q;
+}
+
+// Quaternion(rot)  geometry/quaternion.h:31-50 ; |theta| < 1e-6 -> (rot/2, 1), not normalised
+VG_HD Quat quat_from_rotvec(const double *rot, const RotTrig &g)
+{
+    Quat q;
+    if (fabs(g.th) < 1e-6) {
+        q.x = rot[0] / 2.;
+        q.y = rot[1] / 2.;
+        q.z = rot[2] / 2.;
+        q.w = 1.;
+    } else {
+        const double u0 = rot[0] / g.th, u1 = rot[1] / g.th, u2 = rot[2] / g.th;
+        q.x = u0 * g.sh;
+        q.y = u1 * g.sh;
+        q.z = u2 * g.sh;
+        q.w = g.ch;
+    }
+    return q;
+}
+
+// geometry/geometry_core.h:32-38
+VG_HD double normalize_angle(double th)
+{
+    if (th > M_PI) return th - 2 * M_PI;
+    else if (th < -M_PI) return th + 2 * M_PI;
+    else return th;
+}
+
+// Quaternion::toRotationVector  geometry/quaternion.h:84-98
+VG_HD void quat_to_rotvec(const Quat &q, double *rot)
+{
+    const double s = sqrt(q.x * q.x + q.y * q.y + q.z * q.z);
+    if (s < 1e-5) {
+        rot[0] = q.x * 2.;
+        rot[1] = q.y * 2.;
+        rot[2] = q.z * 2.;
+    } else {
+        const double th = 2. * atan2(s, q.w);
+        const double thn = normalize_angle(th);
+        rot[0] = q.x / s * thn;
+        rot[1] = q.y / s * thn;
+        rot[2] = q.z / s * thn;
+    }
+}
+
+// Quaternion::rotate  geometry/quaternion.h:61-82
+VG_HD void quat_rotate(const Quat &q, const double *v, double *out)
+{
+    const double t1 = q.w * q.x;
+    const double t2 = q.w * q.y;
+    const double t3 = q.w * q.z;
+    const double t4 = -q.x * q.x;
+    const double t5 = q.x * q.y;
+    const double t6 = q.x * q.z;
+    const double t7 = -q.y * q.y;
+    const double t8 = q.y * q.z;
+    const double t9 = -q.z * q.z;
+    const double v1 = v[0], v2 = v[1], v3 = v[2];
+    out[0] = 2. * ((t7 + t9) * v1 + (t5 - t3) * v2 + (t2 + t6) * v3) + v1;
+    out[1] = 2. * ((t3 + t5) * v1 + (t4 + t9) * v2 + (t8 - t1) * v3) + v2;
+    out[2] = 2. * ((t6 - t2) * v1 + (t1 + t8) * v2 + (t4 + t7) * v3) + v3;
+}
+
+// Quaternion::operator*  geometry/quaternion.h:105-118
+VG_HD Quat quat_mul(const Quat &a, const Quat &b)
+{
+    Quat r;
+    r.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
+    r.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
+    r.y = a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x;
+    r.z = a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w;
+    return r;
+}
+
+// rotationMatrix(sign * v)  geometry/geometry_core.h:40-76 ; R row-major.
+// sign = -1 gives Transformation::rotMatInv() (geometry/transformation.h:132): |-v| == |v| bit for bit.
+VG_HD void rotation_matrix(const double *v, double sign, const RotTrig &g, double *R)
+{
+    const double v0 = sign * v[0], v1 = sign * v[1], v2 = sign * v[2];
+    if (g.th < 1e-5) {
+        R[0] = 1.;  R[1] = -v2; R[2] = v1;
+        R[3] = v2;  R[4] = 1.;  R[5] = -v0;
+        R[6] = -v1; R[7] = v0;  R[8] = 1.;
+    } else {
+        const double thInv = 1. / g.th;
+        const double u1 = v0 * thInv;
+        const double u2 = v1 * thInv;
+        const double u3 = v2 * thInv;
+        const double sinth = g.s;
+        const double costhVar = 1. - g.c;
+
+        R[0] = 1. + costhVar * (u1 * u1 - 1.);
+        R[4] = 1. + costhVar * (u2 * u2 - 1.);
+        R[8] = 1. + costhVar * (u3 * u3 - 1.);
+
+        R[1] = -sinth * u3 + costhVar * u1 * u2;
+        R[2] = sinth * u2 + costhVar * u1 * u3;
+        R[5] = -sinth * u1 + costhVar * u2 * u3;
+
+        R[3] = sinth * u3 + costhVar * u2 * u1;
+        R[6] = -sinth * u2 + costhVar * u3 * u1;
+        R[7] = sinth * u1 + costhVar * u3 * u2;
+    }
+}
+
+// C = A * B, 3x3 row-major, each coefficient summed k = 0,1,2
+VG_HD void mat3_mul(const double *A, const double *B, double *C)
+{
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            C[3 * i + j] = A[3 * i + 0] * B[0 + j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+
+// interOmegaRot(v)  geometry/geometry_core.h:158-180  (omega = M(r) * rdot)
+VG_HD void inter_omega_rot(const double *v, const RotTrig &g, double *B)
+{
+    if (g.th < 1e-5) {
+        const double h0 = v[0] / 2., h1 = v[1] / 2., h2 = v[2] / 2.;
+        B[0] = 1.;  B[1] = -h2; B[2] = h1;
+        B[3] = h2;  B[4] = 1.;  B[5] = -h0;
+        B[6] = -h1; B[7] = h0;  B[8] = 1.;
+    } else {
+        const double u0 = v[0] / g.th, u1 = v[1] / g.th, u2 = v[2] / g.th;
+        // uhat = hat(v / theta)   geometry_core.h:126-132
+        const double uhat[9] = {0, -u2, u1, u2, 0, -u0, -u1, u0, 0};
+        const double thetaHalf = g.th / 2.;
+        double K1 = sinc_from(thetaHalf, g.sh);
+        K1 = thetaHalf * K1 * K1;
+        const double K2 = (1. - sinc_from(g.th, g.s));
+        double k2u[9], prod[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++) k2u[i] = K2 * uhat[i];
+        mat3_mul(k2u, uhat, prod);  // (K2*uhat)*uhat
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                const double id = (i == j) ? 1. : 0.;
+                B[3 * i + j] = (id + K1 * uhat[3 * i + j]) + prod[3 * i + j];
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Per-block frame: everything GenericProjectionJac::Evaluate derives from the chain parameters
+// and then re-uses for every corner of the image.
+//   [0..8]  Racc   = R(xiAcc.rot)                     calib_cost_functions.cpp:49-50
+//   [9..11] tacc   = xiAcc.trans
+//   member l at 12 + 21*l:  R12[9], M12[9], t13[3]    InterJacobian ctor, jacobian.h:139-152
+// Frame stride is padded to an even number of doubles so frames stay 16-byte aligned.
+// ------------------------------------------------------------------------------------------
+VG_HD constexpr int frame_doubles(int L) { return 12 + 21 * L; }
+VG_HD constexpr int frame_stride(int L) { return (frame_doubles(L) + 1) & ~1; }
+
+// One chain walk producing the frame.  `member(l)` returns a pointer to the 6-vector of chain
+// member l.  Mirrors calib_cost_functions.cpp:32-46 (accumulation) and :76-92 (xi13 / xi23 pick);
+// the reference walks the chain twice with identical arithmetic, one walk is enough.
+template <typename MemberFn>
+VG_HD void build_frame(int L, const int *status, MemberFn member, double *frame)
+{
+    Transf acc = {{0., 0., 0.}, {0., 0., 0.}};  // Transformation() = zeros  transformation.h:36
+    double Racc[9] = {1., -0., 0., 0., 1., -0., -0., 0., 1.};  // rotationMatrix(0) = I + hat(0)
+    bool racc_valid = true;
+
+    for (int l = 0; l < L; l++) {
+        const double *xi23 = member(l);
+        const double t23[3] = {xi23[0], xi23[1], xi23[2]};
+        const double r23[3] = {xi23[3], xi23[4], xi23[5]};
+        const bool inverted = status[l] != 0;
+
+        const RotTrig g23 = rot_trig(r23, true, true);
+        const RotTrig gacc = rot_trig(acc.r, false, true);
+        const Quat q1 = quat_from_rotvec(acc.r, gacc);
+        const Quat q2 = quat_from_rotvec(r23, g23);
+
+        double R13[9], t13[3];
+        if (!inverted) {
+            // xiAcc = xiAcc.compose(xi23); xi13 = xiAcc      transformation.h:80-88
+            double rt[3];
+            quat_rotate(q1, t23, rt);
+            const Quat qres = quat_mul(q1, q2);
+            acc.t[0] = rt[0] + acc.t[0];
+            acc.t[1] = rt[1] + acc.t[1];
+            acc.t[2] = rt[2] + acc.t[2];
+            quat_to_rotvec(qres, acc.r);
+            const RotTrig gn = rot_trig(acc.r, true, false);
+            rotation_matrix(acc.r, 1., gn, Racc);
+            racc_valid = true;
+#pragma unroll
+            for (int i = 0; i < 9; i++) R13[i] = Racc[i];
+            t13[0] = acc.t[0]; t13[1] = acc.t[1]; t13[2] = acc.t[2];
+        } else {
+            // xi13 = xiAcc; xiAcc = xiAcc.composeInverse(xi23)   transformation.h:101-110
+            if (!racc_valid) {
+                const RotTrig go = rot_trig(acc.r, true, false);
+                rotation_matrix(acc.r, 1., go, Racc);
+            }
+#pragma unroll
+            for (int i = 0; i < 9; i++) R13[i] = Racc[i];
+            t13[0] = acc.t[0]; t13[1] = acc.t[1]; t13[2] = acc.t[2];
+            const Quat q2inv = {-q2.x, -q2.y, -q2.z, q2.w};  // quaternion.h:100-103
+            const Quat qres = quat_mul(q1, q2inv);
+            double rt[3];
+            quat_rotate(qres, t23, rt);
+            acc.t[0] = acc.t[0] - rt[0];
+            acc.t[1] = acc.t[1] - rt[1];
+            acc.t[2] = acc.t[2] - rt[2];
+            quat_to_rotvec(qres, acc.r);
+            racc_valid = false;
+        }
+
+        // InterJacobian(camera, xi13, xi23, inverted)   jacobian.h:139-152
+        double Rb[9], M[9], R12[9], M12[9];
+        rotation_matrix(r23, -1., g23, Rb);  // xi23.rotMatInv()
+        mat3_mul(R13, Rb, R12);
+        inter_omega_rot(r23, g23, M);
+        mat3_mul(R12, M, M12);
+        double *out = frame + 12 + 21 * l;
+#pragma unroll
+        for (int i = 0; i < 9; i++) out[i] = inverted ? R12[i] * -1 : R12[i];
+#pragma unroll
+        for (int i = 0; i < 9; i++) out[9 + i] = inverted ? M12[i] * -1 : M12[i];
+        out[18] = t13[0]; out[19] = t13[1]; out[20] = t13[2];
+    }
+    if (!racc_valid) {
+        const RotTrig go = rot_trig(acc.r, true, false);
+        rotation_matrix(acc.r, 1., go, Racc);
+    }
+#pragma unroll
+    for (int i = 0; i < 9; i++) frame[i] = Racc[i];
+    frame[9] = acc.t[0]; frame[10] = acc.t[1]; frame[11] = acc.t[2];
+}
+
+}  // namespace vg

@@ -1,0 +1,211 @@
+// vg_kernels.hpp -- HIP kernels of the residual / Jacobian hot path (gfx950, wave64).
+//
+//   kernel 1  vg_chain_prep_kernel   one lane per residual block (image): transform chain -> frame
+//   kernel 2  vg_emit_kernel         one lane per (image, corner) observation: residual pair +
+//                                    the 2 x (K + 6L) Jacobian rows, written in the Ceres block layout
+//
+// Both are HBM-streaming kernels (about 1 flop per byte); nothing here is GEMM shaped.  Design notes
+// and the roofline arithmetic are in DESIGN.md sections 4-5.
+#pragma once
+
+#include "vg_camera.hpp"
+
+namespace vg {
+
+constexpr int kMaxChain = 5;
+constexpr int kEmitThreads = 256;  // 4 waves
+constexpr int kWave = 64;
+constexpr double kDoubleBig = 1e15;  // include/std.h:71
+
+// where chain member l of block b lives:  params + base[l] + stride[l] * seq_index[b]
+// (stride 0 = global transform, 6 = sequence transform; unified_calibration.h:161-165)
+struct ChainDesc {
+    int L;
+    int status[kMaxChain];
+    long long base[kMaxChain];
+    long long stride[kMaxChain];
+};
+
+// ------------------------------------------------------------------------------------------
+// kernel 1: chain prep.  64-thread workgroups so that 10 k images spread over ~157 CUs with one
+// wave each: the kernel is latency bound (a dependent chain of sqrt / sincos / atan2 / divisions),
+// not throughput bound.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void vg_chain_prep_kernel(const double *__restrict__ params, ChainDesc cd,
+                                                            const int *__restrict__ seq_index, long long n_blocks,
+                                                            double *__restrict__ frames, int frame_stride_d)
+{
+    const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_blocks) return;
+    const long long si = seq_index ? (long long)seq_index[b] : b;
+    // the frame is written straight to global memory (fire-and-forget stores, no scratch array)
+    build_frame(cd.L, cd.status, [&](int l) { return params + cd.base[l] + cd.stride[l] * si; },
+                frames + b * frame_stride_d);
+}
+
+// ------------------------------------------------------------------------------------------
+// kernel 2: emit.
+// ------------------------------------------------------------------------------------------
+struct EmitArgs {
+    const double *frames;  // [n_blocks][frame_stride]
+    const double *board;   // [N][3]
+    const double *obs;     // [n_blocks][N][2]
+    const double *intr;    // [K]
+    double *res;           // [n_blocks][2N]
+    double *jac_intr;      // [n_blocks][2N][K] or NULL
+    double *jac_member[kMaxChain];  // [n_blocks][2N][6] or NULL
+    unsigned long long *failed;     // device counter of failed projections (may be NULL)
+    unsigned int n_obs;    // n_blocks * N  (< 2^31 per launch; the host chunks larger problems)
+    unsigned int N;
+    int L;
+    int frame_stride_d;
+};
+
+// Each lane holds the 2S doubles of its observation's two rows; the wave's 64 observations are one
+// contiguous 1024*S-byte run of the output.  Lanes write their rows to the wave's private LDS tile
+// (16 B stores at a 16*S-byte lane stride) and the tile is then streamed out linearly, 16 B per lane
+// per store -> every global store instruction writes 1 KiB of consecutive bytes.
+template <int S>
+__device__ __forceinline__ void wave_store_rows(double *__restrict__ stage, const double *vals,
+                                                double *__restrict__ out_tile, int n_valid_obs, int lane)
+{
+    using d2 = HIP_vector_type<double, 2>;
+    d2 *st = reinterpret_cast<d2 *>(stage);
+#pragma unroll
+    for (int i = 0; i < S; i++) {
+        d2 v;
+        v.x = vals[2 * i];
+        v.y = vals[2 * i + 1];
+        st[lane * S + i] = v;
+    }
+    // wave-private tile: LDS executes one wave's DS ops in order, only the compiler needs fencing
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int n16 = n_valid_obs * S;
+    d2 *dst = reinterpret_cast<d2 *>(out_tile);
+#pragma unroll
+    for (int k = 0; k < S; k++) {
+        const int idx = k * kWave + lane;
+        if (idx < n16) dst[idx] = st[idx];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int MODEL>
+constexpr int emit_stage_doubles_per_wave()
+{
+    constexpr int K = CameraTraits<MODEL>::K;
+    return 2 * kWave * (K > 6 ? K : 6);
+}
+
+// dynamic LDS: 4 wave tiles, then (FRAMES_LDS) the frames of the images this workgroup touches
+template <int MODEL, bool WANT_JAC, bool FRAMES_LDS>
+__global__ __launch_bounds__(kEmitThreads) void vg_emit_kernel(EmitArgs a)
+{
+    constexpr int K = CameraTraits<MODEL>::K;
+    using d2 = HIP_vector_type<double, 2>;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wave = tid >> 6;
+    const unsigned int o0 = blockIdx.x * (unsigned)kEmitThreads;
+    const unsigned int o = o0 + tid;
+    const bool active = o < a.n_obs;
+    const unsigned int oc = active ? o : a.n_obs - 1;
+    const unsigned int b = oc / a.N;
+    const unsigned int c = oc - b * a.N;
+
+    const double *fr;
+    if (FRAMES_LDS) {
+        double *fr_lds = smem + (kEmitThreads / kWave) * emit_stage_doubles_per_wave<MODEL>();
+        const unsigned int b_first = o0 / a.N;
+        const unsigned int o_last = (o0 + kEmitThreads - 1 < a.n_obs) ? o0 + kEmitThreads - 1 : a.n_obs - 1;
+        const unsigned int nf = o_last / a.N - b_first + 1;
+        const int n16 = (int)(nf * (unsigned)a.frame_stride_d) >> 1;
+        const d2 *src = reinterpret_cast<const d2 *>(a.frames + (size_t)b_first * a.frame_stride_d);
+        d2 *dst = reinterpret_cast<d2 *>(fr_lds);
+        for (int i = tid; i < n16; i += kEmitThreads) dst[i] = src[i];
+        __syncthreads();
+        fr = fr_lds + (b - b_first) * a.frame_stride_d;
+    } else {
+        fr = a.frames + (size_t)b * a.frame_stride_d;
+    }
+
+    // pointCam = R(xiAcc.rot) * grid + xiAcc.trans     calib_cost_functions.cpp:49-50
+    const double g0 = a.board[3 * c], g1 = a.board[3 * c + 1], g2 = a.board[3 * c + 2];
+    const double X0 = (fr[0] * g0 + fr[1] * g1 + fr[2] * g2) + fr[9];
+    const double X1 = (fr[3] * g0 + fr[4] * g1 + fr[5] * g2) + fr[10];
+    const double X2 = (fr[6] * g0 + fr[7] * g1 + fr[8] * g2) + fr[11];
+
+    const d2 ob = reinterpret_cast<const d2 *>(a.obs)[oc];
+
+    CornerEval<K> e;
+    eval_corner<MODEL, WANT_JAC, WANT_JAC>(a.intr, X0, X1, X2, e);
+
+    // residual pair, or the in-band failure value       calib_cost_functions.cpp:57-71
+    d2 r;
+    r.x = e.ok ? e.u - ob.x : kDoubleBig;
+    r.y = e.ok ? e.v - ob.y : kDoubleBig;
+    if (active) reinterpret_cast<d2 *>(a.res)[o] = r;
+
+    if (a.failed) {
+        const unsigned long long m = __ballot(active && !e.ok);
+        if (m && lane == 0) atomicAdd(a.failed, (unsigned long long)__popcll(m));
+    }
+
+    if (WANT_JAC) {
+        double *stage = smem + wave * emit_stage_doubles_per_wave<MODEL>();
+        const unsigned int ow = o0 + wave * kWave;  // first observation of this wave
+        int n_valid = 0;
+        if (ow < a.n_obs) n_valid = (a.n_obs - ow < (unsigned)kWave) ? (int)(a.n_obs - ow) : kWave;
+
+        // intrinsic block, rows 2i / 2i+1 of [2N x K]       calib_cost_functions.cpp:105-114
+        if (a.jac_intr) {
+            double rows[2 * K];
+#pragma unroll
+            for (int i = 0; i < K; i++) {
+                rows[i] = e.Ju[i];
+                rows[K + i] = e.Jv[i];
+            }
+            wave_store_rows<K>(stage, rows, a.jac_intr + (size_t)ow * (2 * K), n_valid, lane);
+        }
+        // pose blocks, u-row at +12i, v-row at +12i+6       calib_cost_functions.cpp:93-101
+        for (int l = 0; l < a.L; l++) {
+            double *Jm = a.jac_member[l];
+            if (!Jm) continue;
+            double rows[12];
+            pose_rows(e.P, X0, X1, X2, fr + 12 + 21 * l, rows);
+            wave_store_rows<6>(stage, rows, Jm + (size_t)ow * 12, n_valid, lane);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// measurement helpers: pure streaming write / copy, 16 B per lane, grid-stride
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vg_stream_write_kernel(double *__restrict__ dst, long long n2, double value)
+{
+    using d2 = HIP_vector_type<double, 2>;
+    d2 v;
+    v.x = value;
+    v.y = value;
+    d2 *d = reinterpret_cast<d2 *>(dst);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long long)gridDim.x * blockDim.x)
+        d[i] = v;
+}
+
+__global__ __launch_bounds__(256) void vg_stream_copy_kernel(double *__restrict__ dst, const double *__restrict__ src,
+                                                              long long n2)
+{
+    using d2 = HIP_vector_type<double, 2>;
+    d2 *d = reinterpret_cast<d2 *>(dst);
+    const d2 *s = reinterpret_cast<const d2 *>(src);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long long)gridDim.x * blockDim.x)
+        d[i] = s[i];
+}
+
+}  // namespace vg

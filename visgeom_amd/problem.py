@@ -1,0 +1,225 @@
+"""Host-side mirrors of the reference interface, on top of the C ABI (include/visgeom_amd.h).
+
+  GenericProjectionJac   <->  struct GenericProjectionJac        include/calibration/calib_cost_functions.h:27-62
+  CalibrationProblem     <->  what GenericCameraCalibration assembles   src/calibration/unified_calibration.cpp:91-180,514-630
+
+torch is used only to own device memory (output tensors) and to name the stream; every number is
+computed by the HIP kernels behind the C ABI.
+"""
+import ctypes
+
+import numpy as np
+
+from . import capi
+
+_dp = ctypes.POINTER(ctypes.c_double)
+
+
+def _c(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a.reshape(shape) if shape is not None else a
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_dp)
+
+
+class GenericProjectionJac:
+    """One residual block = one image of one camera.
+
+    Same constructor arguments, parameter-block sizes and Evaluate contract as the reference's
+    cost function (calib_cost_functions.h:29-46, calib_cost_functions.cpp:28-117); the arithmetic runs
+    on the GPU through vg_block_evaluate.
+    """
+
+    def __init__(self, proj, grid, model, transform_status_vec, device=0):
+        L = capi.load()
+        self._lib = L
+        self.model = capi.MODELS[model] if isinstance(model, str) else int(model)
+        self.status = [int(s) for s in transform_status_vec]
+        grid = _c(grid).reshape(-1, 3)
+        proj = _c(proj).reshape(-1, 2)
+        if proj.shape[0] != grid.shape[0]:
+            # the corner list must have exactly as many entries as the board
+            raise ValueError("proj and grid must have the same number of points")
+        self.N = grid.shape[0]
+        st = (ctypes.c_int * max(len(self.status), 1))(*self.status)
+        h = ctypes.c_void_p()
+        capi.check(L.vg_block_create(ctypes.byref(h), device, self.model, len(self.status), st, self.N,
+                                     _ptr(grid), _ptr(proj)))
+        self._h = h
+
+    def parameter_block_sizes(self):
+        n = self._lib.vg_block_num_parameter_blocks(self._h)
+        return [self._lib.vg_block_parameter_block_size(self._h, i) for i in range(n)]
+
+    def num_residuals(self):
+        return self._lib.vg_block_num_residuals(self._h)
+
+    def Evaluate(self, params, want_jacobians=True, jac_mask=None):
+        """params = [intrinsics, xi_0 .. xi_{L-1}] -> (residual[2N], list of row-major Jacobians or None).
+        jac_mask[b] False passes a NULL pointer for block b (constant parameter block)."""
+        sizes = self.parameter_block_sizes()
+        ps = [_c(p) for p in params]
+        if len(ps) != len(sizes) or any(p.size != s for p, s in zip(ps, sizes)):
+            raise ValueError("parameter blocks must have sizes %s" % sizes)
+        pp = (_dp * len(ps))(*[_ptr(p) for p in ps])
+        res = np.empty(self.num_residuals())
+        jacs, jp = None, None
+        if want_jacobians:
+            if jac_mask is None:
+                jac_mask = [True] * len(sizes)
+            jacs = [np.full((res.size, s), np.nan) if m else None for s, m in zip(sizes, jac_mask)]
+            jp = (_dp * len(sizes))(*[_ptr(j) if j is not None else _dp() for j in jacs])
+        capi.check(self._lib.vg_block_evaluate(self._h, pp, _ptr(res), jp))
+        return res, jacs
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.vg_block_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class CalibrationProblem:
+    """Batched problem resident in HBM: cameras, global / sequence transforms, datasets."""
+
+    def __init__(self, device=0, stream=None):
+        import torch
+
+        self._torch = torch
+        L = capi.load()
+        self._lib = L
+        self.device = device
+        if stream is None and torch.cuda.is_available():
+            stream = torch.cuda.current_stream(device).cuda_stream
+        self.stream = stream or 0
+        h = ctypes.c_void_p()
+        capi.check(L.vg_problem_create(ctypes.byref(h), device, ctypes.c_void_p(self.stream)))
+        self._h = h
+        self.cameras, self.transforms, self.datasets = [], [], []
+
+    # -- assembly ---------------------------------------------------------------------------
+    def add_camera(self, model, intrinsics, constant=False):
+        m = capi.MODELS[model] if isinstance(model, str) else int(model)
+        v = _c(intrinsics)
+        if v.size != capi.NUM_INTRINSICS[m]:
+            raise ValueError("wrong number of intrinsics")  # unified_calibration.cpp:153 throws
+        cid = ctypes.c_int(-1)
+        capi.check(self._lib.vg_problem_add_camera(self._h, m, _ptr(v), int(constant), ctypes.byref(cid)))
+        self.cameras.append({"model": m, "K": v.size, "constant": constant})
+        return cid.value
+
+    def add_transform(self, is_global, values=None, count=1, constant=False):
+        if is_global:
+            count = 1
+        v = None
+        if values is not None:
+            v = _c(values).reshape(-1, 6)
+            count = v.shape[0]
+        tid = ctypes.c_int(-1)
+        capi.check(self._lib.vg_problem_add_transform(self._h, int(is_global), int(constant), int(count),
+                                                      _ptr(v) if v is not None else None, ctypes.byref(tid)))
+        self.transforms.append({"global": bool(is_global), "count": count, "constant": constant})
+        return tid.value
+
+    def add_dataset(self, camera, chain, board, corners, image_index=None):
+        """chain = [(transform_id, status), ...] camera side first; corners [n_images, N, 2]."""
+        board = _c(board).reshape(-1, 3)
+        N = board.shape[0]
+        corners = _c(corners).reshape(-1, 2 * N)
+        n_img = corners.shape[0]
+        tids = (ctypes.c_int * max(len(chain), 1))(*[c[0] for c in chain])
+        st = (ctypes.c_int * max(len(chain), 1))(*[c[1] for c in chain])
+        idx = None
+        if image_index is not None:
+            idx = np.ascontiguousarray(image_index, dtype=np.int32)
+            if idx.size != n_img:
+                raise ValueError("image_index must have one entry per image")
+        did = ctypes.c_int(-1)
+        capi.check(self._lib.vg_problem_add_dataset(
+            self._h, camera, len(chain), tids, st, N, _ptr(board), n_img,
+            idx.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)) if idx is not None else None,
+            _ptr(corners), ctypes.byref(did)))
+        self.datasets.append({"camera": camera, "chain": list(chain), "N": N, "n_blocks": n_img,
+                              "K": self.cameras[camera]["K"], "L": len(chain)})
+        return did.value
+
+    def finalize(self):
+        capi.check(self._lib.vg_problem_finalize(self._h))
+        self.num_parameters = self._lib.vg_problem_num_parameters(self._h)
+        return self
+
+    # -- parameters -------------------------------------------------------------------------
+    def camera_offset(self, cam):
+        return self._lib.vg_problem_camera_offset(self._h, cam)
+
+    def transform_offset(self, tid, index=0):
+        return self._lib.vg_problem_transform_offset(self._h, tid, index)
+
+    def set_parameters(self, params):
+        v = _c(params)
+        if v.size != self.num_parameters:
+            raise ValueError("parameter vector has the wrong length")
+        capi.check(self._lib.vg_problem_set_parameters(self._h, _ptr(v)))
+
+    def get_parameters(self):
+        v = np.empty(self.num_parameters)
+        capi.check(self._lib.vg_problem_get_parameters(self._h, _ptr(v)))
+        return v
+
+    def parameters_device_ptr(self):
+        return self._lib.vg_problem_parameters_device(self._h)
+
+    # -- evaluation -------------------------------------------------------------------------
+    def alloc_outputs(self, d, want_jac=True, jac_mask=None):
+        """torch device tensors in the Ceres block layout for dataset d."""
+        torch = self._torch
+        ds = self.datasets[d]
+        dev = torch.device("cuda", self.device)
+        nb, N, K, L = ds["n_blocks"], ds["N"], ds["K"], ds["L"]
+        if jac_mask is None:
+            jac_mask = [True] * (L + 1)
+        res = torch.empty((nb, 2 * N), dtype=torch.float64, device=dev)
+        ji = torch.empty((nb, 2 * N, K), dtype=torch.float64, device=dev) if want_jac and jac_mask[0] else None
+        jm = [torch.empty((nb, 2 * N, 6), dtype=torch.float64, device=dev) if want_jac and jac_mask[1 + l] else None
+              for l in range(L)]
+        return res, ji, jm
+
+    def prepare(self):
+        capi.check(self._lib.vg_problem_prepare(self._h))
+
+    def evaluate_dataset(self, d, res, jac_intr=None, jac_member=None):
+        """kernel 2 on dataset d; outputs are torch tensors (or None) from alloc_outputs."""
+        L = self.datasets[d]["L"]
+        jm = (ctypes.c_void_p * max(L, 1))()
+        for l in range(L):
+            t = jac_member[l] if jac_member else None
+            jm[l] = t.data_ptr() if t is not None else None
+        capi.check(self._lib.vg_dataset_evaluate(self._h, d, ctypes.c_void_p(res.data_ptr()),
+                                                 ctypes.c_void_p(jac_intr.data_ptr()) if jac_intr is not None else None,
+                                                 jm))
+
+    def synchronize(self):
+        capi.check(self._lib.vg_problem_synchronize(self._h))
+
+    def failed_count(self, d):
+        n = ctypes.c_int64(0)
+        capi.check(self._lib.vg_dataset_failed_count(self._h, d, ctypes.byref(n)))
+        return n.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.vg_problem_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,228 @@
+"""Deterministic synthetic calibration sets.
+
+The reference ships no images and no corner dumps, so every benchmark /
+parity workload is generated: a 12 x 8 board of 0.1 m squares seen by fisheye cameras whose
+ground-truth intrinsics are the real calibrated values in data/ex_epipolar_stereo.json:2,4,6.
+One portable counter-based generator (splitmix64 -> U(0,1), Box-Muller) is shared by the fixture
+generator, the CPU baseline and the GPU bench: seed = 20260928 + config index, stream = image index.
+
+Pure numpy; this module computes ground-truth projections only to place the observations -- it is
+not the evaluation path (that is the HIP library) and not the oracle.
+"""
+import numpy as np
+
+BASE_SEED = 20260928
+IMAGE_W, IMAGE_H = 1280, 800          # data/ex_epipolar_stereo.json:17-18
+BOARD_COLS, BOARD_ROWS, BOARD_SIZE = 12, 8, 0.1
+
+GT_EUCM_CAM1 = np.array([0.595728, 0.768828, 307.318, 289.542, 642.617, 398.42])
+GT_EUCM_CAM2 = np.array([0.593948, 0.774335, 307.356, 289.482, 637.871, 396.818])
+GT_XI_CAM12 = np.array([0.197255, 0.000222456, -0.00421324, -0.00570702, 0.00103386, -0.0140923])
+_alpha = GT_EUCM_CAM1[0]
+GT_UCM = np.array([_alpha / (1 - _alpha), GT_EUCM_CAM1[2] / (1 - _alpha), GT_EUCM_CAM1[3] / (1 - _alpha),
+                   GT_EUCM_CAM1[4], GT_EUCM_CAM1[5]])
+GT_MEI = np.concatenate([GT_UCM[:1], [-0.05, 0.01, -0.002, 0.001, -0.0015], GT_UCM[1:]])
+GT = {"eucm": GT_EUCM_CAM1, "ucm": GT_UCM, "mei": GT_MEI}
+# evaluation / initial point (style of data/calib_example.json:17)
+INIT = {"eucm": np.array([0.5, 1.0, 300.0, 300.0, 640.0, 400.0]),
+        "ucm": np.array([1.2, 700.0, 700.0, 640.0, 400.0]),
+        "mei": np.array([1.2, 0, 0, 0, 0, 0, 700.0, 700.0, 640.0, 400.0])}
+
+_GOLDEN = np.uint64(0x9E3779B97F4A7C15)
+_M1 = np.uint64(0xBF58476D1CE4E5B9)
+_M2 = np.uint64(0x94D049BB133111EB)
+NOISE_OFFSET = 1 << 20   # noise draws live in their own counter range of each stream
+PERTURB_OFFSET = 1 << 21
+
+
+def _mix(z):
+    z = (z ^ (z >> np.uint64(30))) * _M1
+    z = (z ^ (z >> np.uint64(27))) * _M2
+    return z ^ (z >> np.uint64(31))
+
+
+def uniform(seed, stream, counter):
+    """U[0,1) number `counter` of stream `stream`: splitmix64 output k of state mix(seed, stream)."""
+    with np.errstate(over="ignore"):
+        stream = np.asarray(stream, dtype=np.uint64)
+        counter = np.asarray(counter, dtype=np.uint64)
+        s0 = _mix(np.uint64(seed) * _GOLDEN + _mix(stream + np.uint64(1)))
+        z = _mix(s0 + (counter + np.uint64(1)) * _GOLDEN)
+    return (z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def normal_pair(seed, stream, counter):
+    """Box-Muller: two N(0,1) from uniforms 2*counter and 2*counter+1 (offset into the noise range)."""
+    c = np.asarray(counter, dtype=np.uint64) * np.uint64(2) + np.uint64(NOISE_OFFSET)
+    u1 = uniform(seed, stream, c)
+    u2 = uniform(seed, stream, c + np.uint64(1))
+    r = np.sqrt(-2.0 * np.log(1.0 - u1))   # 1-u1 in (0,1]
+    return r * np.cos(2 * np.pi * u2), r * np.sin(2 * np.pi * u2)
+
+
+def board_points(cols=BOARD_COLS, rows=BOARD_ROWS, size=BOARD_SIZE):
+    """k = i*cols + j -> (size*j, size*i, 0)   (ordering of unified_calibration.cpp:286-292)."""
+    j, i = np.meshgrid(np.arange(cols), np.arange(rows))
+    return np.stack([size * j.ravel(), size * i.ravel(), np.zeros(cols * rows)], axis=1).astype(np.float64)
+
+
+# ------------------------------------------------------------------ ground-truth geometry (numpy)
+def rodrigues(r):
+    """rotation vectors [...,3] -> matrices [...,3,3] (exact formula)."""
+    r = np.asarray(r, dtype=np.float64)
+    th = np.linalg.norm(r, axis=-1)[..., None, None]
+    safe = np.where(th > 0, th, 1.0)
+    k = r[..., None, :] / safe  # placeholder to build hat
+    kx, ky, kz = (r[..., 0] / safe[..., 0, 0], r[..., 1] / safe[..., 0, 0], r[..., 2] / safe[..., 0, 0])
+    z = np.zeros_like(kx)
+    Kh = np.stack([np.stack([z, -kz, ky], -1), np.stack([kz, z, -kx], -1), np.stack([-ky, kx, z], -1)], -2)
+    del k
+    return np.eye(3) + np.sin(th) * Kh + (1 - np.cos(th)) * (Kh @ Kh)
+
+
+def rotvec_from_matrix(R):
+    """log map, valid for angles in (0, pi) (the generator only keeps 1e-3 < angle < pi - 0.2)."""
+    tr = np.clip((np.trace(R, axis1=-2, axis2=-1) - 1) / 2, -1, 1)
+    th = np.arccos(tr)
+    v = np.stack([R[..., 2, 1] - R[..., 1, 2], R[..., 0, 2] - R[..., 2, 0], R[..., 1, 0] - R[..., 0, 1]], -1)
+    s = 2 * np.sin(th)
+    s = np.where(np.abs(s) > 1e-300, s, 1.0)
+    return v / s[..., None] * th[..., None]
+
+
+def project(model, p, X):
+    """ground-truth projection of points X[...,3]; returns (uv[...,2], ok[...])."""
+    x, y, z = X[..., 0], X[..., 1], X[..., 2]
+    if model == "eucm":
+        a, b, fu, fv, u0, v0 = p
+        d = a * np.sqrt(z * z + b * (x * x + y * y)) + (1 - a) * z
+        ok = d >= 1e-3
+        ds = np.where(ok, d, 1.0)
+        if a > 0.5:
+            ok &= (z / ds) >= (a - 1) / (2 * a - 1)
+        return np.stack([fu * x / ds + u0, fv * y / ds + v0], -1), ok
+    xi = p[0]
+    rho = np.sqrt(x * x + y * y + z * z)
+    den = z + xi * rho
+    ok = den > 1e-3
+    den = np.where(ok, den, 1.0)
+    xn, yn = x / den, y / den
+    if model == "ucm":
+        return np.stack([p[1] * xn + p[3], p[2] * yn + p[4]], -1), ok
+    k1, k2, k3, k4, k5, fu, fv, u0, v0 = p[1:]
+    r2 = xn * xn + yn * yn
+    D = 1 + k1 * r2 + k2 * r2 ** 2 + k3 * r2 ** 3
+    dx = 2 * k4 * xn * yn + k5 * (r2 + 2 * xn * xn)
+    dy = 2 * k5 * xn * yn + k4 * (r2 + 2 * yn * yn)
+    return np.stack([fu * (xn * D + dx) + u0, fv * (yn * D + dy) + v0], -1), ok
+
+
+def _draw_pose(seed, stream, attempt, board_centre):
+    """board -> camera pose for each stream at attempt index `attempt` (6 uniforms per attempt)."""
+    base = np.asarray(attempt, dtype=np.uint64) * np.uint64(8)
+    u = [uniform(seed, stream, base + np.uint64(k)) for k in range(6)]
+    rng_, off, az = 0.5 + u[0], np.deg2rad(60.0) * u[1], 2 * np.pi * u[2]
+    inplane, mag, axis_az = 2 * np.pi * u[3], np.deg2rad(35.0) * u[4], 2 * np.pi * u[5]
+    c = rng_[:, None] * np.stack([np.sin(off) * np.cos(az), np.sin(off) * np.sin(az), np.cos(off)], -1)
+    d = c / np.linalg.norm(c, axis=-1, keepdims=True)          # board z axis = viewing ray
+    helper = np.where(np.abs(d[:, :1]) < 0.9, np.array([[1.0, 0, 0]]), np.array([[0, 1.0, 0]]))
+    e1 = np.cross(helper, d)
+    e1 /= np.linalg.norm(e1, axis=-1, keepdims=True)
+    e2 = np.cross(d, e1)
+    R0 = np.stack([e1, e2, d], axis=-1)                        # columns
+    Rz = rodrigues(np.stack([np.zeros_like(inplane), np.zeros_like(inplane), inplane], -1))
+    tilt = rodrigues(mag[:, None] * np.stack([np.cos(axis_az), np.sin(axis_az), np.zeros_like(axis_az)], -1))
+    R = R0 @ Rz @ tilt
+    t = c - np.einsum("nij,j->ni", R, board_centre)
+    return R, t
+
+
+def _accept(uv, ok):
+    inside = ((uv[..., 0] >= 20) & (uv[..., 0] <= IMAGE_W - 20) & (uv[..., 1] >= 20) & (uv[..., 1] <= IMAGE_H - 20))
+    return (ok & inside).all(axis=-1)
+
+
+def make_poses(seed, n_images, cameras, board, max_attempts=200, first=0):
+    """Rejection-sample n_images board poses visible (all corners, >= 20 px inside the image) in every
+    camera of `cameras` = [(model, intrinsics, R_cam_from_ref, t_cam_from_ref)], with 1e-3 < |rot| < pi-0.2.
+    Returns xi [n,6] = [t, rotvec] (board -> reference camera)."""
+    stream = np.arange(first, first + n_images, dtype=np.uint64)
+    xi = np.zeros((n_images, 6))
+    todo = np.ones(n_images, dtype=bool)
+    centre = np.array([board[:, 0].max() / 2, board[:, 1].max() / 2, 0.0])
+    for attempt in range(max_attempts):
+        idx = np.nonzero(todo)[0]
+        if idx.size == 0:
+            break
+        R, t = _draw_pose(seed, stream[idx], np.full(idx.size, attempt), centre)
+        X = np.einsum("nij,kj->nki", R, board) + t[:, None, :]
+        good = np.ones(idx.size, dtype=bool)
+        for model, intr, Rc, tc in cameras:
+            Xc = np.einsum("ij,nkj->nki", Rc, X) + tc
+            uv, ok = project(model, intr, Xc)
+            good &= _accept(uv, ok)
+        r = rotvec_from_matrix(R)
+        th = np.linalg.norm(r, axis=-1)
+        good &= (th > 1e-3) & (th < np.pi - 0.2)
+        sel = idx[good]
+        xi[sel, :3] = t[good]
+        xi[sel, 3:] = r[good]
+        todo[sel] = False
+    if todo.any():
+        raise RuntimeError("pose sampling did not converge for %d images" % todo.sum())
+    return xi
+
+
+def _noise(seed, n_images, N, sigma, first=0):
+    stream = np.repeat(np.arange(first, first + n_images, dtype=np.uint64), N)
+    k = np.tile(np.arange(N, dtype=np.uint64), n_images)
+    a, b = normal_pair(seed, stream, k)
+    return sigma * np.stack([a, b], -1).reshape(n_images, N, 2)
+
+
+def _perturb(seed, n_images, cols, lo=-0.01, hi=0.01, salt=0, first=0):
+    stream = np.repeat(np.arange(first, first + n_images, dtype=np.uint64), cols)
+    k = np.tile(np.arange(cols, dtype=np.uint64), n_images) + np.uint64(PERTURB_OFFSET + 64 * salt)
+    return (lo + (hi - lo) * uniform(seed, stream, k)).reshape(n_images, cols)
+
+
+def make_mono(model, n_images, config_index, sigma=0.1, first_image=0):
+    """Configs 2 / 4: one camera, chain [xiCamBoard DIRECT].  first_image offsets the per-image streams, so a
+    rank can generate images [first_image, first_image + n_images) of a larger set (multi-GPU shards)."""
+    seed = BASE_SEED + config_index
+    board = board_points()
+    gt = GT[model]
+    poses = make_poses(seed, n_images, [(model, gt, np.eye(3), np.zeros(3))], board, first=first_image)
+    X = np.einsum("nij,kj->nki", rodrigues(poses[:, 3:]), board) + poses[:, None, :3]
+    uv, ok = project(model, gt, X)
+    assert ok.all()
+    corners = uv + _noise(seed, n_images, board.shape[0], sigma, first=first_image)
+    init_poses = poses + _perturb(seed, n_images, 6, first=first_image)
+    return {"model": model, "board": board, "corners": corners, "gt_intrinsics": gt.copy(), "gt_poses": poses,
+            "init_intrinsics": INIT[model].copy(), "init_poses": init_poses, "seed": seed}
+
+
+def make_stereo(n_pairs, config_index=3, sigma=0.1):
+    """Config 3: cam-1 chain [xiCamBoard D], cam-2 chain [xiCam12 I, xiCamBoard D]
+    (data/calib_stereo_example.json:51-53,88-91)."""
+    seed = BASE_SEED + config_index
+    board = board_points()
+    R12 = rodrigues(GT_XI_CAM12[3:])
+    # X2 = R12^T (X1 - t12)
+    cams = [("eucm", GT_EUCM_CAM1, np.eye(3), np.zeros(3)),
+            ("eucm", GT_EUCM_CAM2, R12.T, -R12.T @ GT_XI_CAM12[:3])]
+    poses = make_poses(seed, n_pairs, cams, board)
+    X1 = np.einsum("nij,kj->nki", rodrigues(poses[:, 3:]), board) + poses[:, None, :3]
+    X2 = np.einsum("ij,nkj->nki", cams[1][2], X1) + cams[1][3]
+    uv1, ok1 = project("eucm", GT_EUCM_CAM1, X1)
+    uv2, ok2 = project("eucm", GT_EUCM_CAM2, X2)
+    assert ok1.all() and ok2.all()
+    N = board.shape[0]
+    n1 = _noise(seed, n_pairs, N, sigma)
+    n2 = _noise(seed + 7919, n_pairs, N, sigma)
+    return {"board": board, "corners1": uv1 + n1, "corners2": uv2 + n2,
+            "gt_intrinsics1": GT_EUCM_CAM1.copy(), "gt_intrinsics2": GT_EUCM_CAM2.copy(),
+            "gt_xi12": GT_XI_CAM12.copy(), "gt_poses": poses,
+            "init_intrinsics1": INIT["eucm"].copy(), "init_intrinsics2": INIT["eucm"].copy(),
+            "init_xi12": GT_XI_CAM12 + _perturb(seed, 1, 6, salt=1)[0],
+            "init_poses": poses + _perturb(seed, n_pairs, 6), "seed": seed}
