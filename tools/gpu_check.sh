@@ -1,23 +1,33 @@
 #!/bin/bash
-# One GPU-box session: smoke, GPU parity tests, bench, rocprofv3 kernel trace.  Outputs -> gpurun_out/.
-# usage: gpurun -- bash tools/gpu_check.sh [tag]
+# One GPU-box session: smoke, GPU parity tests, bench, rocprofv3 kernel trace + PMC passes.
+# Outputs -> gpurun_out/.   usage: gpurun -- bash tools/gpu_check.sh [tag] [skip-tests]
 TAG=${1:-r01}
+SKIP=${2:-}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$R" || exit 1
 mkdir -p gpurun_out
-rocm-smi --showproductname 2>/dev/null | head -8 > gpurun_out/box_$TAG.txt
-nproc >> gpurun_out/box_$TAG.txt; grep -m1 'model name' /proc/cpuinfo >> gpurun_out/box_$TAG.txt
+{ rocm-smi --showproductname 2>/dev/null | grep -E "Card|GPU" | head -4; echo "nproc $(nproc)"; grep -m1 'model name' /proc/cpuinfo; } > gpurun_out/box_$TAG.txt
+if [ -z "$SKIP" ]; then
 timeout 600 python -c "import __graft_entry__ as g; g.build(); g.smoke()" > gpurun_out/smoke_$TAG.log 2>&1
 echo "smoke rc=$?" | tee -a gpurun_out/smoke_$TAG.log
 timeout 1500 python -m pytest tests -m gpu -x -q -s > gpurun_out/pytest_gpu_$TAG.log 2>&1
 echo "pytest rc=$?" | tee -a gpurun_out/pytest_gpu_$TAG.log
-tail -5 gpurun_out/pytest_gpu_$TAG.log
+tail -4 gpurun_out/pytest_gpu_$TAG.log
+fi
 timeout 600 python bench.py > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err
 echo "bench rc=$?"; cat gpurun_out/bench_$TAG.json; tail -3 gpurun_out/bench_$TAG.err
+timeout 600 python bench.py --images 100000 --steps 50 --warmup 5 --no-cpu-baseline > gpurun_out/bench_100k_$TAG.json 2> gpurun_out/bench_100k_$TAG.err
+echo "bench100k rc=$?"; cat gpurun_out/bench_100k_$TAG.json
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/prof_$TAG" -o trace -- python "$R/bench.py" --steps 100 --warmup 10 --no-cpu-baseline > "$R/gpurun_out/prof_$TAG.log" 2>&1
-echo "rocprof rc=$?"
-find "$R/gpurun_out/prof_$TAG" -name '*stats*' | head; 
-f=$(find "$R/gpurun_out/prof_$TAG" -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && head -12 "$f"
-# keep the merged output small: drop the raw per-dispatch trace if it is huge
-find "$R/gpurun_out/prof_$TAG" -name '*kernel_trace.csv' -size +20M -delete
+P="$R/gpurun_out/prof_$TAG"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$P/trace" -o t -- python "$R/bench.py" --steps 100 --warmup 10 --no-cpu-baseline > "$P.trace.log" 2>&1
+echo "rocprof trace rc=$?"
+for C in FETCH_SIZE WRITE_SIZE; do
+  timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$P/pmc_$C" -o t -- python "$R/bench.py" --steps 20 --warmup 2 --no-cpu-baseline > "$P.pmc_$C.log" 2>&1
+  echo "rocprof pmc $C rc=$?"
+done
+timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d "$P/pmc_SQ" -o t -- python "$R/bench.py" --steps 20 --warmup 2 --no-cpu-baseline > "$P.pmc_SQ.log" 2>&1
+echo "rocprof pmc SQ rc=$?"
+find "$P" -type f | head -40
+f=$(find "$P/trace" -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && head -8 "$f"
+find "$P" -name '*.csv' -size +8M -delete

@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Turn the rocprofv3 CSV output of tools/gpu_check.sh (gpurun_out/prof_<tag>/...) into the committed
+evidence under profiles/:  <tag>_kernel_stats.csv (verbatim --stats summary), <tag>_pmc.md (counters per
+kernel, calibration, corrected HBM traffic) and pmc_traffic.json (what bench.py reports as roofline.traffic).
+
+Corrections follow /opt/skills/guides/MI355X_MICROARCH.md section HBM: FETCH_SIZE / WRITE_SIZE are KiB and come
+from separate --pmc passes; on gfx950 FETCH_SIZE counts half of a wide coalesced read, so the factor is
+CALIBRATED here on a kernel with a known byte count and the same 16 B/lane pattern (vg_stream_copy_kernel,
+vg_stream_write_kernel: 512 MiB each way) instead of assumed.
+"""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1]
+workload_key = sys.argv[2] if len(sys.argv) > 2 else "eucm_10000"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+OUT = os.path.join(ROOT, "profiles")
+os.makedirs(OUT, exist_ok=True)
+CAL_BYTES = 64 * 1024 * 1024 * 8  # bench.py streams 2^26 doubles
+
+
+def counters(sub):
+    agg = collections.defaultdict(list)
+    f = os.path.join(P, sub, "t_counter_collection.csv")
+    if not os.path.exists(f):
+        return agg
+    for r in csv.DictReader(open(f)):
+        agg[(r["Kernel_Name"], r["Counter_Name"])].append(float(r["Counter_Value"]))
+    return agg
+
+
+def short(name):
+    return name.split("(")[0].replace("void ", "")
+
+
+shutil.copy(os.path.join(P, "trace", "t_kernel_stats.csv"), os.path.join(OUT, tag + "_kernel_stats.csv"))
+stats = {short(r["Name"]): r for r in csv.DictReader(open(os.path.join(P, "trace", "t_kernel_stats.csv")))}
+fetch, write, sq = counters("pmc_FETCH_SIZE"), counters("pmc_WRITE_SIZE"), counters("pmc_SQ")
+mean = lambda v: sum(v) / len(v)
+fk = {short(k[0]): mean(v) for k, v in fetch.items()}
+wk = {short(k[0]): mean(v) for k, v in write.items()}
+f_cal = CAL_BYTES / (fk["vg::vg_stream_copy_kernel"] * 1024)
+w_cal = CAL_BYTES / (wk["vg::vg_stream_write_kernel"] * 1024)
+lines = ["# rocprofv3 PMC summary, round tag `%s`" % tag, "",
+         "Source: `tools/gpu_check.sh %s` on one MI355X (separate `--pmc` passes, `--kernel-trace` only)." % tag, "",
+         "Calibration on known byte counts (512 MiB each way, 16 B per lane, same pattern as the emit kernel):", "",
+         "| kernel | counter | raw KiB | true bytes / (raw KiB x 1024) |", "|---|---|---|---|",
+         "| vg_stream_copy_kernel | FETCH_SIZE | %.1f | **%.4f** |" % (fk["vg::vg_stream_copy_kernel"], f_cal),
+         "| vg_stream_write_kernel | WRITE_SIZE | %.1f | **%.4f** |" % (wk["vg::vg_stream_write_kernel"], w_cal), "",
+         "| kernel | calls (trace) | avg ns (trace) | FETCH_SIZE KiB raw | WRITE_SIZE KiB raw | corrected HBM bytes / launch |",
+         "|---|---|---|---|---|---|"]
+traffic = {}
+for k in sorted(set(fk) | set(wk)):
+    if not k.startswith("vg::"):
+        continue
+    b = fk.get(k, 0) * 1024 * f_cal + wk.get(k, 0) * 1024 * w_cal
+    s = stats.get(k, {})
+    lines.append("| %s | %s | %s | %.1f | %.1f | %.4g |" % (k, s.get("Calls", "-"), s.get("AverageNs", "-"), fk.get(k, 0),
+                                                        wk.get(k, 0), b))
+    traffic[k] = b
+lines += ["", "SQ counters (means per dispatch):", "", "| kernel | counter | mean |", "|---|---|---|"]
+for (kn, cn), v in sorted(sq.items()):
+    if short(kn).startswith("vg::") and "stream" not in kn:
+        lines.append("| %s | %s | %.4g |" % (short(kn), cn, mean(v)))
+open(os.path.join(OUT, tag + "_pmc.md"), "w").write("\n".join(lines) + "\n")
+emit = [k for k in traffic if "vg_emit_kernel" in k]
+tj = os.path.join(OUT, "pmc_traffic.json")
+cur = json.load(open(tj)) if os.path.exists(tj) else {}
+if emit:
+    cur[workload_key] = {"hbm_bytes_per_launch": traffic[emit[0]], "kernel": emit[0], "tag": tag,
+                         "fetch_factor": f_cal, "write_factor": w_cal,
+                         "trace_avg_ns": float(stats[emit[0]]["AverageNs"]) if emit[0] in stats else None}
+json.dump(cur, open(tj, "w"), indent=1, sort_keys=True)
+print("\n".join(lines))

@@ -56,6 +56,7 @@ struct Dataset {
     double *d_board = nullptr, *d_obs = nullptr, *d_frames = nullptr;
     int32_t *d_seq = nullptr;
     unsigned long long *d_failed = nullptr;
+    unsigned long long epoch = 0;  // evaluation counter, tags d_failed
     int frame_stride = 0;
     vg::ChainDesc chain;
 };
@@ -400,15 +401,16 @@ int vg_dataset_evaluate(vg_problem *p, int dataset_id, double *residuals, double
     int rc = valid_dataset(p, dataset_id);
     if (rc != VG_OK) return rc;
     if (!p->finalized) return fail(VG_ERR_STATE, "problem not finalized");
+    Dataset &d = p->dss[dataset_id];
+    d.epoch = (d.epoch + 1) & 0xFFFFFFull;
+    if (d.epoch == 0) d.epoch = 1;
+    if (!d.n_blocks) return VG_OK;  // nothing to evaluate (outputs may be zero-sized / NULL)
     if (!residuals) return fail(VG_ERR_INVALID_ARGUMENT, "residuals is NULL");
     VG_HIP(hipSetDevice(p->device));
-    Dataset &d = p->dss[dataset_id];
     const Camera &cam = p->cams[d.camera];
     bool want_jac = jac_intr != nullptr;
     for (int l = 0; l < d.L; l++)
         if (jac_member && jac_member[l]) want_jac = true;
-    VG_HIP(hipMemsetAsync(d.d_failed, 0, sizeof(unsigned long long), p->stream));
-    if (!d.n_blocks) return VG_OK;
 
     // 32-bit observation indices inside a launch: chunk very large datasets by whole images
     const int64_t max_blocks_per_launch = ((int64_t)1 << 30) / d.N > 0 ? ((int64_t)1 << 30) / d.N : 1;
@@ -424,6 +426,7 @@ int vg_dataset_evaluate(vg_problem *p, int dataset_id, double *residuals, double
         for (int l = 0; l < vg::kMaxChain; l++)
             a.jac_member[l] = (l < d.L && jac_member && jac_member[l]) ? jac_member[l] + (size_t)b0 * 2 * d.N * 6 : nullptr;
         a.failed = d.d_failed;
+        a.epoch = d.epoch;
         a.n_obs = (unsigned int)(nb * d.N);
         a.N = (unsigned int)d.N;
         a.L = d.L;
@@ -456,7 +459,8 @@ int vg_dataset_failed_count(vg_problem *p, int dataset_id, int64_t *count)
     unsigned long long v = 0;
     VG_HIP(hipMemcpyAsync(&v, p->dss[dataset_id].d_failed, sizeof v, hipMemcpyDeviceToHost, p->stream));
     VG_HIP(hipStreamSynchronize(p->stream));
-    *count = (int64_t)v;
+    const Dataset &d = p->dss[dataset_id];
+    *count = (v >> 40) == d.epoch ? (int64_t)(v & ((1ull << 40) - 1)) : 0;
     return VG_OK;
 }
 
@@ -556,8 +560,11 @@ void vg_block_destroy(vg_block *b)
 int vg_calib_stream_write(void *hip_stream, double *dst, int64_t n_doubles, double value)
 {
     if (!dst || n_doubles < 0 || (n_doubles & 1)) return fail(VG_ERR_INVALID_ARGUMENT, "need an even number of doubles");
-    hipLaunchKernelGGL(vg::vg_stream_write_kernel, dim3(2048), dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream),
-                       dst, (long long)(n_doubles / 2), value);
+    const long long n2 = n_doubles / 2;
+    const unsigned int grid = (unsigned int)((n2 + 256 * vg::kStreamUnroll - 1) / (256 * vg::kStreamUnroll));
+    if (!grid) return VG_OK;
+    hipLaunchKernelGGL(vg::vg_stream_write_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream),
+                       dst, n2, value);
     VG_HIP(hipGetLastError());
     return VG_OK;
 }
@@ -565,8 +572,11 @@ int vg_calib_stream_write(void *hip_stream, double *dst, int64_t n_doubles, doub
 int vg_calib_stream_copy(void *hip_stream, double *dst, const double *src, int64_t n_doubles)
 {
     if (!dst || !src || n_doubles < 0 || (n_doubles & 1)) return fail(VG_ERR_INVALID_ARGUMENT, "need an even number of doubles");
-    hipLaunchKernelGGL(vg::vg_stream_copy_kernel, dim3(2048), dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream),
-                       dst, src, (long long)(n_doubles / 2));
+    const long long n2 = n_doubles / 2;
+    const unsigned int grid = (unsigned int)((n2 + 256 * vg::kStreamUnroll - 1) / (256 * vg::kStreamUnroll));
+    if (!grid) return VG_OK;
+    hipLaunchKernelGGL(vg::vg_stream_copy_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream),
+                       dst, src, n2);
     VG_HIP(hipGetLastError());
     return VG_OK;
 }

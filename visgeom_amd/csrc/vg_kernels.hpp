@@ -54,7 +54,8 @@ struct EmitArgs {
     double *res;           // [n_blocks][2N]
     double *jac_intr;      // [n_blocks][2N][K] or NULL
     double *jac_member[kMaxChain];  // [n_blocks][2N][6] or NULL
-    unsigned long long *failed;     // device counter of failed projections (may be NULL)
+    unsigned long long *failed;     // failed-projection counter word: (epoch << 40) | count  (may be NULL)
+    unsigned long long epoch;       // evaluation number (24 bits); a stale epoch in the word means count 0
     unsigned int n_obs;    // n_blocks * N  (< 2^31 per launch; the host chunks larger problems)
     unsigned int N;
     int L;
@@ -153,8 +154,19 @@ __global__ __launch_bounds__(kEmitThreads) void vg_emit_kernel(EmitArgs a)
     if (active) reinterpret_cast<d2 *>(a.res)[o] = r;
 
     if (a.failed) {
+        // Failures are rare: the counter is never zeroed (an 8-byte hipMemsetAsync is a whole 5 us fill
+        // kernel).  The word carries the evaluation epoch; the first failing wave of an evaluation
+        // replaces a stale word, later ones add to it.
         const unsigned long long m = __ballot(active && !e.ok);
-        if (m && lane == 0) atomicAdd(a.failed, (unsigned long long)__popcll(m));
+        if (m && lane == 0) {
+            const unsigned long long n = (unsigned long long)__popcll(m);
+            unsigned long long old = *a.failed, assumed;
+            do {
+                assumed = old;
+                const unsigned long long cnt = (assumed >> 40) == a.epoch ? (assumed & ((1ull << 40) - 1)) + n : n;
+                old = atomicCAS(a.failed, assumed, (a.epoch << 40) | cnt);
+            } while (old != assumed);
+        }
     }
 
     if (WANT_JAC) {
@@ -185,8 +197,13 @@ __global__ __launch_bounds__(kEmitThreads) void vg_emit_kernel(EmitArgs a)
 }
 
 // ------------------------------------------------------------------------------------------
-// measurement helpers: pure streaming write / copy, 16 B per lane, grid-stride
+// measurement helpers: pure streaming write / copy with the emit kernel's store pattern -- every wave
+// instruction moves 1 KiB of consecutive bytes (16 B per lane) and a workgroup owns one contiguous
+// 16 KiB run.  Used to calibrate rocprofv3's FETCH_SIZE / WRITE_SIZE and as the box's measured
+// streaming rate.
 // ------------------------------------------------------------------------------------------
+constexpr int kStreamUnroll = 4;
+
 __global__ __launch_bounds__(256) void vg_stream_write_kernel(double *__restrict__ dst, long long n2, double value)
 {
     using d2 = HIP_vector_type<double, 2>;
@@ -194,8 +211,12 @@ __global__ __launch_bounds__(256) void vg_stream_write_kernel(double *__restrict
     v.x = value;
     v.y = value;
     d2 *d = reinterpret_cast<d2 *>(dst);
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long long)gridDim.x * blockDim.x)
-        d[i] = v;
+    const long long base = (long long)blockIdx.x * (256 * kStreamUnroll) + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < kStreamUnroll; k++) {
+        const long long i = base + k * 256;
+        if (i < n2) d[i] = v;
+    }
 }
 
 __global__ __launch_bounds__(256) void vg_stream_copy_kernel(double *__restrict__ dst, const double *__restrict__ src,
@@ -204,8 +225,18 @@ __global__ __launch_bounds__(256) void vg_stream_copy_kernel(double *__restrict_
     using d2 = HIP_vector_type<double, 2>;
     d2 *d = reinterpret_cast<d2 *>(dst);
     const d2 *s = reinterpret_cast<const d2 *>(src);
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long long)gridDim.x * blockDim.x)
-        d[i] = s[i];
+    const long long base = (long long)blockIdx.x * (256 * kStreamUnroll) + threadIdx.x;
+    d2 t[kStreamUnroll];
+#pragma unroll
+    for (int k = 0; k < kStreamUnroll; k++) {
+        const long long i = base + k * 256;
+        if (i < n2) t[k] = s[i];
+    }
+#pragma unroll
+    for (int k = 0; k < kStreamUnroll; k++) {
+        const long long i = base + k * 256;
+        if (i < n2) d[i] = t[k];
+    }
 }
 
 }  // namespace vg
