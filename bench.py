@@ -69,6 +69,14 @@ def cpu_baseline(d, model, budget_s):
     cores = vgo.max_threads()
     p1, t1, v1 = leg(1)
     pc, tc, vc = leg(cores)
+    # J^T J build on the CPU: evaluate (above) + per-image Gram of [J | r] + sum, all cores
+    gout = (np.empty((n, K + 7, K + 7)), np.empty((K + 7, K + 7)))
+    vgo.dataset_gram(out[0], out[1], out[2], threads=cores, out=gout)
+    reps, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < max(1.0, budget_s / 4):
+        vgo.dataset_gram(out[0], out[1], out[2], threads=cores, out=gout)
+        reps += 1
+    gram_ms = (time.perf_counter() - t0) / reps * 1e3
     cpu_model = ""
     try:
         for line in open("/proc/cpuinfo"):
@@ -80,7 +88,8 @@ def cpu_baseline(d, model, budget_s):
     return {"value": vc, "unit": "evals/s", "cores": cores, "kind": "port",
             "sample": "%d passes (%.1f s) over the same %d-image x %d-corner set with %d OpenMP threads; "
                       "single thread: %d passes (%.1f s)" % (pc, tc, n, N, cores, p1, t1),
-            "single_thread_value": v1, "cpu_model": cpu_model}
+            "single_thread_value": v1, "cpu_model": cpu_model,
+            "jtj_ms_per_iter": n * N / vc * 1e3 + gram_ms, "jtj_gram_only_ms": gram_ms}
 
 
 def main():
@@ -212,6 +221,55 @@ def main():
     roofline["measured_stream_write_GBps"] = write_gbs
     roofline["measured_stream_copy_GBps"] = copy_gbs
 
+    # ---- J^T J / J^T r build, ms per iteration (second half of BASELINE.json's metric) ----
+    # fused:    chain prep + evaluate-and-contract kernel (J stays on chip, FP64 MFMA) + fixed-order sum
+    # two-pass: chain prep + emit (J to HBM) + second pass over the materialised rows + sum
+    # N > 1: every iteration ends with ONE all-reduce (RCCL) of the W x W summed block [J^T J | J^T r | r^T r].
+    gram, gsum = p.alloc_gram(ds)
+
+    def finish():
+        p.gram_sum(ds, gram, gsum)
+        if dist is not None:
+            dist.all_reduce(gsum)
+
+    def it_fused():
+        p.prepare()
+        p.gram_fused(ds, gram)
+        finish()
+
+    def it_two_pass():
+        p.prepare()
+        p.evaluate_dataset(ds, res, ji, jm)
+        p.gram_from_rows(ds, res, ji, jm, gram)
+        finish()
+
+    def it_second_pass_only():
+        p.gram_from_rows(ds, res, ji, jm, gram)
+        finish()
+
+    def wall_ms(fn, n):
+        for _ in range(max(3, n // 10)):
+            fn()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        fence()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el / n * 1e3
+
+    W = p.gram_width(ds)
+    jtj = {"unit": "ms/iter", "gram_width": W, "images_per_gpu": n_img, "allreduce": dist is not None,
+           "fused_ms_per_iter": wall_ms(it_fused, a.steps),
+           "two_pass_ms_per_iter": wall_ms(it_two_pass, a.steps),
+           "second_pass_only_ms": wall_ms(it_second_pass_only, a.steps),
+           "fused_algorithmic_bytes_per_obs": 16 + 8.0 * W * W / N,
+           "two_pass_read_bytes_per_obs": 16 + 16 * (K + 6)}
+
     out = {
         "metric": "corner residual+Jacobian evals/sec",
         "value": value,
@@ -231,6 +289,7 @@ def main():
                    "images_per_gpu": n_img, "corners_per_image": N, "model": a.model, "chain": ["DIRECT"],
                    "seed": int(d["seed"]), "sharding": "images sharded over ranks, no data-path collective"},
         "roofline": roofline,
+        "jtj": jtj,
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(d, a.model, a.cpu_seconds)

@@ -154,6 +154,25 @@ int vg_problem_synchronize(vg_problem *p);
  * dataset; synchronises the stream.  Not in the reference. */
 int vg_dataset_failed_count(vg_problem *p, int dataset_id, int64_t *count);
 
+/* =====================================================================================
+ * 3. Normal-equation build (what Ceres does with Evaluate's output; not in the reference tree:
+ *    SURVEY section 0 fact 2, call sites src/calibration/unified_calibration.cpp:53,426,1152).
+ *    Per residual block b:  G_b = S_b^T S_b  with  S_b = [J_0 | J_1 ... J_L | r]  (2N x W, W = K + 6L + 1).
+ *    G_b holds J^T J (leading (W-1)x(W-1)), J^T r (last column) and r^T r (last entry) of the block, in
+ *    the block's own column order [intrinsics, chain member 0, ..., chain member L-1, residual].
+ * ===================================================================================== */
+int vg_dataset_gram_width(const vg_problem *p, int dataset_id); /* W */
+/* fused: evaluates residuals and Jacobian rows in registers and contracts them on the matrix cores;
+ * J is never written to HBM.  gram: device [n_blocks][W*W], row-major, full symmetric.  Needs
+ * vg_problem_prepare at the current parameters, like vg_dataset_evaluate. */
+int vg_dataset_gram_fused(vg_problem *p, int dataset_id, double *gram);
+/* two-pass: the same Gram matrices from rows already materialised by vg_dataset_evaluate
+ * (all of residuals, jac_intr and every jac_member[l] are required). */
+int vg_dataset_gram_from_rows(vg_problem *p, int dataset_id, const double *residuals, const double *jac_intr,
+                              const double *const *jac_member, double *gram);
+/* sum over the dataset's blocks in a fixed order (two-stage tree, no atomics): sum[W*W] device. */
+int vg_dataset_gram_sum(vg_problem *p, int dataset_id, const double *gram, double *sum);
+
 /* ---- measurement helpers (bench / profiling only): a pure streaming write / copy with the same
  * 16 B-per-lane access pattern as the emit kernel, to calibrate rocprofv3's WRITE_SIZE / FETCH_SIZE
  * and to measure the achievable HBM rate on the box. */

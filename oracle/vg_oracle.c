@@ -740,6 +740,27 @@ void vgo_block_gram_fast(int K, int L, int N, const double *residual, const doub
         for (int b = a + 1; b < W; b++) gram[b * W + a] = gram[a * W + b];
 }
 
+long vgo_dataset_gram(int K, int L, int N, long n_blocks, const double *residuals, const double *jac_intr,
+                      const double *const *jac_member, double *grams, double *sum, int threads)
+{
+    const int W = K + 6 * L + 1;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(threads > 1 ? threads : 1)
+#endif
+    for (long b = 0; b < n_blocks; b++) {
+        const double *jm[VGO_MAX_CHAIN];
+        for (int l = 0; l < L; l++) jm[l] = jac_member[l] + (size_t)b * 2 * N * 6;
+        vgo_block_gram_fast(K, L, N, residuals + (size_t)b * 2 * N, jac_intr + (size_t)b * 2 * N * K, jm,
+                            grams + (size_t)b * W * W);
+    }
+    if (sum) {
+        for (int e = 0; e < W * W; e++) sum[e] = 0.;
+        for (long b = 0; b < n_blocks; b++)
+            for (int e = 0; e < W * W; e++) sum[e] += grams[(size_t)b * W * W + e];
+    }
+    return n_blocks;
+}
+
 int vgo_max_threads(void)
 {
 #ifdef _OPENMP

@@ -91,6 +91,11 @@ void vgo_block_gram(int K, int L, int N, const double *residual, const double *j
 void vgo_block_gram_fast(int K, int L, int N, const double *residual, const double *jac_intr,
                          const double *const *jac_member, double *gram);
 
+/* CPU-baseline leg of the normal-equation build: per-block Gram (plain double) of every block, OpenMP over
+ * blocks, then a serial sum over blocks.  grams [n_blocks][W*W], sum [W*W] (may be NULL). */
+long vgo_dataset_gram(int K, int L, int N, long n_blocks, const double *residuals, const double *jac_intr,
+                      const double *const *jac_member, double *grams, double *sum, int threads);
+
 int vgo_max_threads(void);
 
 #ifdef __cplusplus

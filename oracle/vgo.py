@@ -70,6 +70,9 @@ def lib():
         L.vgo_intrinsic_jacobian.restype = ctypes.c_int
         L.vgo_intrinsic_jacobian.argtypes = [ctypes.c_int, _dp, _dp, _dp, _dp]
         L.vgo_max_threads.restype = ctypes.c_int
+        L.vgo_dataset_gram.restype = ctypes.c_long
+        L.vgo_dataset_gram.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_long, _dp, _dp, _dpp, _dp, _dp,
+                                       ctypes.c_int]
         _lib = L
     return _lib
 
@@ -157,6 +160,17 @@ def block_gram(residual, jac_intr, jac_members, fast=False):
     f = lib().vgo_block_gram_fast if fast else lib().vgo_block_gram
     f(K, L, N, _ptr(residual), _ptr(jac_intr), jmp, _ptr(g))
     return g
+
+
+def dataset_gram(res, jac_intr, jac_members, threads=1, out=None):
+    """per-block Gram (plain double) of every block + their sum; CPU-baseline leg of the J^T J build."""
+    nb, rows = res.shape
+    K, L = jac_intr.shape[-1], len(jac_members)
+    W = K + 6 * L + 1
+    grams, total = out if out is not None else (np.empty((nb, W, W)), np.empty((W, W)))
+    jmp = (_dp * max(L, 1))(*[_ptr(j) for j in jac_members])
+    lib().vgo_dataset_gram(K, L, rows // 2, nb, _ptr(res), _ptr(jac_intr), jmp, _ptr(grams), _ptr(total), threads)
+    return grams, total
 
 
 def compose(a, b, inverse=False):

@@ -1,0 +1,175 @@
+"""Normal-equation build on the GPU vs its mathematical definition on the oracle's rows:
+G_b = [J|r]^T [J|r] accumulated in long double ("JtJ/Jtr ... check GPU result vs a CPU
+long-double accumulation ... <= 1e-10 relative (block-norm)")."""
+import numpy as np
+import pytest
+
+from oracle import vgo
+
+pytestmark = pytest.mark.gpu
+RNG = np.random.default_rng(7)
+TOL = 1e-10
+
+
+@pytest.fixture(scope="module")
+def vg():
+    import torch
+
+    assert torch.cuda.is_available()
+    import visgeom_amd
+
+    return visgeom_amd
+
+
+def oracle_grams(model, status, board, corners, pv, intr_off, bases, strides, seq):
+    r, ji, jm = vgo.eval_dataset(vgo.MODELS[model], status, board, corners, pv, intr_off, bases, strides, seq, threads=4)
+    return np.stack([vgo.block_gram(r[b], ji[b], [m[b] for m in jm]) for b in range(r.shape[0])])
+
+
+def assert_gram_parity(G, Gref, what=""):
+    for b in range(Gref.shape[0]):
+        n = np.linalg.norm(Gref[b])
+        assert np.linalg.norm(G[b] - Gref[b]) <= TOL * n, "%s block %d norm" % (what, b)
+        d = np.sqrt(np.abs(np.diag(Gref[b])))
+        scale = np.maximum(np.outer(d, d), 1e-300)
+        assert np.max(np.abs(G[b] - Gref[b]) / scale) <= TOL, "%s block %d elementwise" % (what, b)
+        assert np.array_equal(G[b], G[b].T), "Gram must be exactly symmetric"
+
+
+def build(vg, model, n_images, chain_kind, n_points=None):
+    from visgeom_amd import synthetic as S
+
+    d = S.make_mono(model, n_images, 2)
+    board, corners = d["board"], d["corners"]
+    if n_points is not None:
+        board = np.concatenate([RNG.uniform(0, 1.1, (n_points, 1)), RNG.uniform(0, 0.7, (n_points, 1)),
+                                RNG.uniform(-0.05, 0.05, (n_points, 1))], axis=1)
+        corners = RNG.uniform(50, 1200, (n_images, n_points, 2))
+    p = vg.CalibrationProblem(0)
+    cam = p.add_camera(model, d["init_intrinsics"])
+    K = len(d["init_intrinsics"])
+    n_glob = {"D": 0, "ID": 1, "IDDID": 4}[chain_kind]
+    globs = [p.add_transform(True, np.concatenate([RNG.uniform(-0.02, 0.02, 3), RNG.uniform(-0.03, 0.03, 3)]))
+             for _ in range(n_glob)]
+    seq = p.add_transform(False, d["init_poses"])
+    if chain_kind == "D":
+        chain, status = [(seq, 0)], [0]
+    elif chain_kind == "ID":
+        chain, status = [(globs[0], 1), (seq, 0)], [1, 0]
+    else:
+        chain = [(globs[0], 1), (globs[1], 0), (seq, 0), (globs[2], 1), (globs[3], 0)]
+        status = [1, 0, 0, 1, 0]
+    ds = p.add_dataset(cam, chain, board, corners)
+    p.finalize()
+    bases = [p.transform_offset(t, 0) for t, _ in chain]
+    strides = [6 if t == seq else 0 for t, _ in chain]
+    return p, ds, status, board, corners, K, bases, strides
+
+
+CASES = [("eucm", 40, "D", None),      # W = 13, one MFMA tile           (config 2 / headline shape)
+         ("ucm", 17, "D", None),       # W = 12
+         ("mei", 23, "D", None),       # W = 17, two tiles               (config 4 shape)
+         ("eucm", 19, "ID", None),     # W = 19, stereo cam-2 shape      (config 3)
+         ("mei", 9, "IDDID", None),    # W = 41, three tiles, chain of 5
+         ("eucm", 11, "D", 7),         # odd N < wave: image rows end mid-MFMA group
+         ("ucm", 6, "ID", 65),         # N = 65: second 64-corner tile holds one corner
+         ("mei", 3, "D", 200)]
+
+
+@pytest.mark.parametrize("model,n_images,chain_kind,n_points", CASES)
+def test_gram_fused_two_pass_and_sum(vg, model, n_images, chain_kind, n_points):
+    import torch
+
+    p, ds, status, board, corners, K, bases, strides = build(vg, model, n_images, chain_kind, n_points)
+    W = p.gram_width(ds)
+    assert W == K + 6 * len(status) + 1
+    pv = p.get_parameters()
+    Gref = oracle_grams(model, status, board, corners, pv, 0, bases, strides, np.arange(n_images))
+    gram, gsum = p.alloc_gram(ds)
+    gram.fill_(float("nan"))
+    p.prepare()
+    p.gram_fused(ds, gram)
+    p.gram_sum(ds, gram, gsum)
+    p.synchronize()
+    G = gram.cpu().numpy()
+    assert_gram_parity(G, Gref, "fused")
+    # two-pass over the materialised rows gives the same matrices (same contraction order)
+    res, ji, jm = p.alloc_outputs(ds)
+    gram2 = torch.full_like(gram, float("nan"))
+    p.evaluate_dataset(ds, res, ji, jm)
+    p.gram_from_rows(ds, res, ji, jm, gram2)
+    p.synchronize()
+    assert_gram_parity(gram2.cpu().numpy(), Gref, "two-pass")
+    assert torch.equal(gram, gram2), "fused and two-pass contract the same rows in the same order"
+    # deterministic reduction over images
+    ref_sum = Gref.astype(np.longdouble).sum(axis=0).astype(np.float64)
+    S_ = gsum.cpu().numpy()
+    assert np.linalg.norm(S_ - ref_sum) <= TOL * np.linalg.norm(ref_sum)
+    gsum2 = torch.empty_like(gsum)
+    p.gram_sum(ds, gram, gsum2)
+    p.synchronize()
+    assert torch.equal(gsum, gsum2), "reduction must be run-to-run reproducible"
+    # cost = 1/2 r^T r (what Ceres reports) sits in the last entry
+    r, _, _ = vgo.eval_dataset(vgo.MODELS[model], status, board, corners, pv, 0, bases, strides, np.arange(n_images),
+                               want_jac=False)
+    assert abs(S_[-1, -1] - np.sum(r.astype(np.longdouble) ** 2)) <= 1e-12 * S_[-1, -1]
+    p.close()
+
+
+def test_gram_with_failed_projections_matches_ceres_semantics(vg):
+    """a failed EUCM projection contributes its in-band 1e15 residual pair and zero Jacobian rows
+    (calib_cost_functions.cpp:66-70): r^T r picks up 2e30 per failed corner, J^T J and J^T r nothing."""
+    from visgeom_amd import synthetic as S
+
+    d = S.make_mono("eucm", 3, 2)
+    poses = d["gt_poses"].copy()
+    poses[1] = [0, 0, -1, 0, 0, 0]
+    p = vg.CalibrationProblem(0)
+    cam = p.add_camera("eucm", d["gt_intrinsics"])
+    seq = p.add_transform(False, poses)
+    ds = p.add_dataset(cam, [(seq, 0)], d["board"], d["corners"])
+    p.finalize()
+    gram, gsum = p.alloc_gram(ds)
+    p.prepare()
+    p.gram_fused(ds, gram)
+    p.synchronize()
+    Gref = oracle_grams("eucm", [0], d["board"], d["corners"], p.get_parameters(), 0, [6], [6], np.arange(3))
+    G = gram.cpu().numpy()
+    assert_gram_parity(G, Gref)
+    assert abs(G[1][-1, -1] / (94 * 2e30) - 1) < 1e-12
+    p.close()
+
+
+def test_full_size_10k_gram_properties(vg):
+    """config-size check: 10 k images.  Oracle comparison on a strided subset of images (the long-double
+    Gram is the slow part), plus size-independent properties over all of them: exact symmetry, the sum
+    kernel equals a float64 torch sum to rounding, and permutation of images permutes the blocks bit for bit."""
+    import torch
+
+    from visgeom_amd import synthetic as S
+
+    n = 10000
+    d = S.make_mono("eucm", n, 1)
+    perm = RNG.permutation(n).astype(np.int32)
+    p = vg.CalibrationProblem(0)
+    cam = p.add_camera("eucm", d["init_intrinsics"])
+    seq = p.add_transform(False, d["init_poses"])
+    ds = p.add_dataset(cam, [(seq, 0)], d["board"], d["corners"])
+    dsp = p.add_dataset(cam, [(seq, 0)], d["board"], d["corners"][perm], image_index=perm)
+    p.finalize()
+    gram, gsum = p.alloc_gram(ds)
+    gramp, _ = p.alloc_gram(dsp)
+    p.prepare()
+    p.gram_fused(ds, gram)
+    p.gram_fused(dsp, gramp)
+    p.gram_sum(ds, gram, gsum)
+    p.synchronize()
+    assert torch.equal(gram, gram.transpose(1, 2))
+    assert torch.equal(gramp, gram[torch.as_tensor(perm.astype(np.int64), device=gram.device)])
+    tsum = gram.sum(dim=0)
+    assert torch.linalg.norm(gsum - tsum) <= 1e-13 * torch.linalg.norm(tsum)
+    sub = np.arange(0, n, 97)
+    pv = p.get_parameters()
+    Gref = oracle_grams("eucm", [0], d["board"], d["corners"][sub], pv, 0, [6], [6], sub)
+    assert_gram_parity(gram.cpu().numpy()[sub], Gref, "10k subset")
+    p.close()

@@ -59,6 +59,10 @@ SIGNATURES = {
     "vg_dataset_evaluate": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vpp]),
     "vg_problem_synchronize": (ctypes.c_int, [_vp]),
     "vg_dataset_failed_count": (ctypes.c_int, [_vp, ctypes.c_int, _i64p]),
+    "vg_dataset_gram_width": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "vg_dataset_gram_fused": (ctypes.c_int, [_vp, ctypes.c_int, _vp]),
+    "vg_dataset_gram_from_rows": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vpp, _vp]),
+    "vg_dataset_gram_sum": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp]),
     "vg_calib_stream_write": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_double]),
     "vg_calib_stream_copy": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64]),
 }

@@ -10,7 +10,7 @@
 #include <string>
 #include <vector>
 
-#include "vg_kernels.hpp"
+#include "vg_gram.hpp"
 
 namespace {
 
@@ -56,6 +56,7 @@ struct Dataset {
     double *d_board = nullptr, *d_obs = nullptr, *d_frames = nullptr;
     int32_t *d_seq = nullptr;
     unsigned long long *d_failed = nullptr;
+    double *d_partials = nullptr;  // [ceil(n_blocks / kSlab)][W*W] workspace of vg_dataset_gram_sum
     unsigned long long epoch = 0;  // evaluation counter, tags d_failed
     int frame_stride = 0;
     vg::ChainDesc chain;
@@ -103,6 +104,8 @@ void free_dataset(Dataset &d)
     if (d.d_frames) (void)hipFree(d.d_frames);
     if (d.d_seq) (void)hipFree(d.d_seq);
     if (d.d_failed) (void)hipFree(d.d_failed);
+    if (d.d_partials) (void)hipFree(d.d_partials);
+    d.d_partials = nullptr;
     d.d_board = d.d_obs = d.d_frames = nullptr;
     d.d_seq = nullptr;
     d.d_failed = nullptr;
@@ -145,6 +148,48 @@ int valid_dataset(const vg_problem *p, int d)
 {
     if (!p) return fail(VG_ERR_INVALID_ARGUMENT, "problem is NULL");
     if (d < 0 || d >= (int)p->dss.size()) return fail(VG_ERR_INVALID_ARGUMENT, "dataset id out of range");
+    return VG_OK;
+}
+
+}  // namespace
+
+namespace {
+
+void fill_gram_args(const vg_problem *p, const Dataset &d, vg::GramArgs &a, double *gram)
+{
+    const Camera &cam = p->cams[d.camera];
+    a.frames = d.d_frames;
+    a.board = d.d_board;
+    a.obs = d.d_obs;
+    a.intr = p->d_params + cam.offset;
+    a.res = nullptr;
+    a.jac_intr = nullptr;
+    for (int l = 0; l < vg::kMaxChain; l++) a.jac_member[l] = nullptr;
+    a.gram = gram;
+    a.n_blocks = (unsigned int)d.n_blocks;
+    a.N = (unsigned int)d.N;
+    a.L = d.L;
+    a.W = cam.K + 6 * d.L + 1;
+    a.frame_stride_d = d.frame_stride;
+}
+
+template <int MODEL>
+int launch_gram_fused(hipStream_t stream, const vg::GramArgs &a)
+{
+    // one LDS tile per wave (= per pair of images); as many waves per workgroup (<= 4) as fit in 64 KiB, so
+    // that at least two workgroups share a CU (160 KiB LDS) and one can contract while the other evaluates
+    const size_t tile = (size_t)vg::gram_wave_lds_doubles(a.W, a.frame_stride_d) * sizeof(double);
+    int waves = (int)((64 * 1024) / tile);
+    waves = waves < 1 ? 1 : (waves > vg::kGramMaxWavesPerBlock ? vg::kGramMaxWavesPerBlock : waves);
+    const unsigned int n_pairs = (a.n_blocks + 1) / 2;
+    const unsigned int grid = (n_pairs + waves - 1) / waves;
+    const size_t lds = (size_t)waves * tile;
+    const dim3 blk(waves * vg::kWave);
+    const int T = (a.W + 15) / 16;
+    if (T == 1) hipLaunchKernelGGL((vg::vg_gram_fused_kernel<MODEL, 1>), dim3(grid), blk, lds, stream, a);
+    else if (T == 2) hipLaunchKernelGGL((vg::vg_gram_fused_kernel<MODEL, 2>), dim3(grid), blk, lds, stream, a);
+    else hipLaunchKernelGGL((vg::vg_gram_fused_kernel<MODEL, 3>), dim3(grid), blk, lds, stream, a);
+    VG_HIP(hipGetLastError());
     return VG_OK;
 }
 
@@ -461,6 +506,91 @@ int vg_dataset_failed_count(vg_problem *p, int dataset_id, int64_t *count)
     VG_HIP(hipStreamSynchronize(p->stream));
     const Dataset &d = p->dss[dataset_id];
     *count = (v >> 40) == d.epoch ? (int64_t)(v & ((1ull << 40) - 1)) : 0;
+    return VG_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ normal equations */
+
+int vg_dataset_gram_width(const vg_problem *p, int d)
+{
+    if (valid_dataset(p, d) != VG_OK) return -1;
+    return p->cams[p->dss[d].camera].K + 6 * p->dss[d].L + 1;
+}
+
+
+int vg_dataset_gram_fused(vg_problem *p, int dataset_id, double *gram)
+{
+    int rc = valid_dataset(p, dataset_id);
+    if (rc != VG_OK) return rc;
+    if (!p->finalized) return fail(VG_ERR_STATE, "problem not finalized");
+    Dataset &d = p->dss[dataset_id];
+    if (!d.n_blocks) return VG_OK;
+    if (!gram) return fail(VG_ERR_INVALID_ARGUMENT, "gram is NULL");
+    if (d.n_blocks > 0x7fffffff) return fail(VG_ERR_INVALID_ARGUMENT, "too many blocks for one launch");
+    VG_HIP(hipSetDevice(p->device));
+    vg::GramArgs a;
+    fill_gram_args(p, d, a, gram);
+    switch (p->cams[d.camera].model) {
+    case VG_MODEL_EUCM: return launch_gram_fused<vg::kEUCM>(p->stream, a);
+    case VG_MODEL_UCM: return launch_gram_fused<vg::kUCM>(p->stream, a);
+    default: return launch_gram_fused<vg::kMEI>(p->stream, a);
+    }
+}
+
+int vg_dataset_gram_from_rows(vg_problem *p, int dataset_id, const double *residuals, const double *jac_intr,
+                              const double *const *jac_member, double *gram)
+{
+    int rc = valid_dataset(p, dataset_id);
+    if (rc != VG_OK) return rc;
+    if (!p->finalized) return fail(VG_ERR_STATE, "problem not finalized");
+    Dataset &d = p->dss[dataset_id];
+    if (!d.n_blocks) return VG_OK;
+    if (!gram || !residuals || !jac_intr || (d.L > 0 && !jac_member))
+        return fail(VG_ERR_INVALID_ARGUMENT, "two-pass Gram needs residuals and every Jacobian block");
+    for (int l = 0; l < d.L; l++)
+        if (!jac_member[l]) return fail(VG_ERR_INVALID_ARGUMENT, "two-pass Gram needs residuals and every Jacobian block");
+    if (d.n_blocks > 0x7fffffff) return fail(VG_ERR_INVALID_ARGUMENT, "too many blocks for one launch");
+    VG_HIP(hipSetDevice(p->device));
+    vg::GramArgs a;
+    fill_gram_args(p, d, a, gram);
+    a.res = residuals;
+    a.jac_intr = jac_intr;
+    for (int l = 0; l < d.L; l++) a.jac_member[l] = jac_member[l];
+    const int K = p->cams[d.camera].K;
+    const unsigned int n_pairs = (a.n_blocks + 1) / 2;
+    const unsigned int grid = (n_pairs + vg::kGramMaxWavesPerBlock - 1) / vg::kGramMaxWavesPerBlock;
+    const dim3 blk(vg::kGramMaxWavesPerBlock * vg::kWave);
+    const int T = (a.W + 15) / 16;
+    if (T == 1) hipLaunchKernelGGL((vg::vg_gram_rows_kernel<1>), dim3(grid), blk, 0, p->stream, a, K);
+    else if (T == 2) hipLaunchKernelGGL((vg::vg_gram_rows_kernel<2>), dim3(grid), blk, 0, p->stream, a, K);
+    else hipLaunchKernelGGL((vg::vg_gram_rows_kernel<3>), dim3(grid), blk, 0, p->stream, a, K);
+    VG_HIP(hipGetLastError());
+    return VG_OK;
+}
+
+int vg_dataset_gram_sum(vg_problem *p, int dataset_id, const double *gram, double *sum)
+{
+    int rc = valid_dataset(p, dataset_id);
+    if (rc != VG_OK) return rc;
+    if (!p->finalized) return fail(VG_ERR_STATE, "problem not finalized");
+    if (!sum) return fail(VG_ERR_INVALID_ARGUMENT, "sum is NULL");
+    Dataset &d = p->dss[dataset_id];
+    VG_HIP(hipSetDevice(p->device));
+    const int W = p->cams[d.camera].K + 6 * d.L + 1;
+    const int entries = W * W;
+    if (!d.n_blocks) {
+        VG_HIP(hipMemsetAsync(sum, 0, sizeof(double) * entries, p->stream));
+        return VG_OK;
+    }
+    if (!gram) return fail(VG_ERR_INVALID_ARGUMENT, "gram is NULL");
+    const unsigned int n = (unsigned int)d.n_blocks;
+    const unsigned int parts = (n + vg::kSlab - 1) / vg::kSlab;
+    if (!d.d_partials) VG_HIP(hipMalloc(&d.d_partials, sizeof(double) * (size_t)parts * entries));
+    hipLaunchKernelGGL(vg::vg_gram_slab_sum_kernel, dim3(parts), dim3(256), 0, p->stream, gram, n, entries, d.d_partials);
+    VG_HIP(hipGetLastError());
+    hipLaunchKernelGGL(vg::vg_gram_final_sum_kernel, dim3((entries + 3) / 4), dim3(256), 0, p->stream,
+                       (const double *)d.d_partials, parts, entries, sum);
+    VG_HIP(hipGetLastError());
     return VG_OK;
 }
 

@@ -1,0 +1,312 @@
+// vg_gram.hpp -- normal-equation build: per-image Gram matrices of the stacked row block
+//   S_b = [ J_0 | J_1 | ... | J_L | r ]   (2N x W,  W = K + 6L + 1)      G_b = S_b^T S_b   (W x W)
+// and their deterministic reduction over images.  J^T J, J^T r and r^T r of one residual block are the
+// sub-blocks of G_b; the arrow-structured normal equations (global block + one 6x6 block per pose) are
+// assembled from them (vg_solver).  This code has no counterpart in the reference tree: Ceres forms
+// J^T J internally (call sites src/calibration/unified_calibration.cpp:53,426,1152).
+//
+// Kernels
+//   vg_gram_fused_kernel      one WAVE per image: lanes evaluate corners (same device functions as the emit
+//                             kernel, J never leaves the CU), rows go to a wave-private LDS tile, and
+//                             v_mfma_f64_16x16x4_f64 contracts 4 rows per instruction -- the matrix core is
+//                             used as the cross-lane reduction of the Gram sum.
+//   vg_gram_rows_kernel       same contraction, rows read back from the materialised Ceres-layout J
+//                             (the "second pass" of BASELINE.json's north_star); HBM-read bound.
+//   vg_gram_reduce_kernel     fixed-order two-stage sum over images (no atomics -> run-to-run and
+//                             1/2/4/8-GPU reproducible).
+#pragma once
+
+#include "vg_kernels.hpp"
+
+namespace vg {
+
+using f64x4 = __attribute__((ext_vector_type(4))) double;
+
+constexpr int kGramMaxWavesPerBlock = 4;  // the host lowers it when 4 LDS tiles would not fit (wide W)
+constexpr int kGramRowsPerTile = 2 * kWave;  // 64 observations x 2 rows
+
+struct GramArgs {
+    const double *frames;
+    const double *board;
+    const double *obs;
+    const double *intr;
+    // two-pass source (vg_gram_rows_kernel)
+    const double *res;
+    const double *jac_intr;
+    const double *jac_member[kMaxChain];
+    double *gram;  // [n_blocks][W*W] row-major, full symmetric
+    unsigned int n_blocks;
+    unsigned int N;
+    int L;
+    int W;
+    int frame_stride_d;
+};
+
+// D(16x16) += A(16x4) * B(4x16); lane l supplies A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15].
+__device__ __forceinline__ f64x4 mfma_f64_16x16x4(double a, double b, f64x4 c)
+{
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+// Store the T x T tiles of accumulators as the full symmetric W x W matrix.
+// f64 C/D layout: lane l, register r holds D[row = (l>>4) + 4r][col = l&15].
+template <int T>
+__device__ __forceinline__ void store_gram(const f64x4 (&acc)[T][T], double *__restrict__ g, int W, int lane)
+{
+    const int col = lane & 15, row0 = lane >> 4;
+#pragma unroll
+    for (int ti = 0; ti < T; ti++)
+#pragma unroll
+        for (int tj = ti; tj < T; tj++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int i = 16 * ti + row0 + 4 * r, j = 16 * tj + col;
+                if (i < W && j < W) {
+                    g[i * W + j] = acc[ti][tj][r];
+                    if (ti != tj) g[j * W + i] = acc[ti][tj][r];
+                }
+            }
+}
+
+template <int T>
+__device__ __forceinline__ void zero_acc(f64x4 (&acc)[T][T])
+{
+#pragma unroll
+    for (int i = 0; i < T; i++)
+#pragma unroll
+        for (int j = 0; j < T; j++) acc[i][j] = f64x4{0., 0., 0., 0.};
+}
+
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ------------------------------------------------------------------------------------------
+// fused evaluate + Gram.  One wave owns TWO consecutive images, one per 32-lane half, and walks their
+// corners 32 at a time (an 8 x 12 board is 3 full steps, no idle lanes; a 64-wide step would idle a
+// quarter of them).  Per step every lane evaluates one corner and writes its two rows to the wave's LDS
+// tile (rows 0..63: image A, 64..127: image B); then v_mfma_f64_16x16x4_f64 contracts 4 rows per
+// instruction, alternating between the A and B accumulators (two independent chains).
+// dynamic LDS per wave: [128 rows][W] row tile + the two images' frames.
+// T = ceil(W / 16) column tiles.
+// ------------------------------------------------------------------------------------------
+constexpr int kGramHalf = 32;
+
+__host__ __device__ constexpr int gram_wave_lds_doubles(int W, int frame_stride_d)
+{
+    return kGramRowsPerTile * W + 2 * frame_stride_d;
+}
+
+template <int MODEL, int T>
+__global__ __launch_bounds__(kGramMaxWavesPerBlock *kWave) void vg_gram_fused_kernel(GramArgs a)
+{
+    constexpr int K = CameraTraits<MODEL>::K;
+    using d2 = HIP_vector_type<double, 2>;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned int bA = 2 * (blockIdx.x * (blockDim.x >> 6) + wave);  // wave-uniform
+    if (bA >= a.n_blocks) return;  // whole wave leaves; no workgroup barrier below
+    const int W = a.W, FS = a.frame_stride_d;
+    double *tile = smem + (size_t)wave * gram_wave_lds_doubles(W, FS);
+    double *fr_lds = tile + kGramRowsPerTile * W;
+    const int h = lane >> 5, sl = lane & (kGramHalf - 1);
+    const unsigned int b = bA + h;
+    const bool bvalid = b < a.n_blocks;
+
+    // both frames are adjacent in memory: one coalesced copy into LDS
+    {
+        const int n_fr = (a.n_blocks - bA >= 2 ? 2 : 1) * FS;
+        const double *src = a.frames + (size_t)bA * FS;
+        for (int i = lane; i < n_fr; i += kWave) fr_lds[i] = src[i];
+        wave_lds_fence();
+    }
+    const double *fr = fr_lds + (bvalid ? h : 0) * FS;
+
+    f64x4 accA[T][T], accB[T][T];
+    zero_acc<T>(accA);
+    zero_acc<T>(accB);
+    const int c16 = lane & 15, k4 = lane >> 4;
+
+    for (unsigned int c0 = 0; c0 < a.N; c0 += kGramHalf) {
+        const unsigned int c = c0 + sl;
+        const bool valid = bvalid && c < a.N;
+        const unsigned int cc = c < a.N ? c : a.N - 1;
+        const unsigned int bb = bvalid ? b : bA;
+        const double g0 = a.board[3 * cc], g1 = a.board[3 * cc + 1], g2 = a.board[3 * cc + 2];
+        const double X0 = (fr[0] * g0 + fr[1] * g1 + fr[2] * g2) + fr[9];
+        const double X1 = (fr[3] * g0 + fr[4] * g1 + fr[5] * g2) + fr[10];
+        const double X2 = (fr[6] * g0 + fr[7] * g1 + fr[8] * g2) + fr[11];
+        const d2 ob = reinterpret_cast<const d2 *>(a.obs)[(size_t)bb * a.N + cc];
+        CornerEval<K> e;
+        eval_corner<MODEL, true, true>(a.intr, X0, X1, X2, e);
+        double *ru = tile + (size_t)(kWave * h + 2 * sl) * W, *rv = ru + W;
+#pragma unroll
+        for (int i = 0; i < K; i++) {
+            ru[i] = valid ? e.Ju[i] : 0.;
+            rv[i] = valid ? e.Jv[i] : 0.;
+        }
+        for (int l = 0; l < a.L; l++) {
+            double rows[12];
+            pose_rows(e.P, X0, X1, X2, fr + 12 + 21 * l, rows);
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                ru[K + 6 * l + j] = valid ? rows[j] : 0.;
+                rv[K + 6 * l + j] = valid ? rows[6 + j] : 0.;
+            }
+        }
+        // residual column; a failed projection contributes the in-band 1e15 exactly as it would
+        // inside Ceres (calib_cost_functions.cpp:66-70)
+        ru[W - 1] = valid ? (e.ok ? e.u - ob.x : kDoubleBig) : 0.;
+        rv[W - 1] = valid ? (e.ok ? e.v - ob.y : kDoubleBig) : 0.;
+        wave_lds_fence();
+
+        // always 16 groups of 4 rows per image: rows of lanes without a corner are zero, so a ragged last
+        // step only wastes matrix-pipe time, and the fixed trip count lets the LDS reads be pipelined
+        constexpr int n_steps = kGramHalf / 2;
+        const double *rowA = tile + (size_t)k4 * W, *rowB = rowA + (size_t)kWave * W;
+#pragma unroll 4
+        for (int t = 0; t < n_steps; t++) {
+            double vA[T], vB[T];
+#pragma unroll
+            for (int j = 0; j < T; j++) {
+                const int col = 16 * j + c16;
+                vA[j] = col < W ? rowA[(size_t)(4 * t) * W + col] : 0.;
+                vB[j] = col < W ? rowB[(size_t)(4 * t) * W + col] : 0.;
+            }
+#pragma unroll
+            for (int ti = 0; ti < T; ti++)
+#pragma unroll
+                for (int tj = ti; tj < T; tj++) {
+                    accA[ti][tj] = mfma_f64_16x16x4(vA[ti], vA[tj], accA[ti][tj]);
+                    accB[ti][tj] = mfma_f64_16x16x4(vB[ti], vB[tj], accB[ti][tj]);
+                }
+        }
+        wave_lds_fence();
+    }
+    store_gram<T>(accA, a.gram + (size_t)bA * W * W, W, lane);
+    if (bA + 1 < a.n_blocks) store_gram<T>(accB, a.gram + (size_t)(bA + 1) * W * W, W, lane);
+}
+
+// ------------------------------------------------------------------------------------------
+// two-pass: Gram of the materialised rows (the "second pass" over J).  Same work split and the same
+// contraction order as the fused kernel -- one wave per pair of images, A / B accumulators alternating,
+// 4 rows per MFMA in increasing row order -- so both paths give bit-identical matrices.  Every MFMA
+// operand is gathered straight from the Ceres-layout arrays (per 4 rows: 4K, 24 and 4 consecutive
+// doubles); kRowsUnroll groups are loaded ahead of their MFMAs to keep loads in flight.
+// ------------------------------------------------------------------------------------------
+constexpr int kRowsUnroll = 8;
+
+template <int T>
+__global__ __launch_bounds__(kGramMaxWavesPerBlock *kWave) void vg_gram_rows_kernel(GramArgs a, int K)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned int bA = 2 * (blockIdx.x * (blockDim.x >> 6) + wave);
+    if (bA >= a.n_blocks) return;
+    const bool hasB = bA + 1 < a.n_blocks;
+    const int W = a.W;
+    const int c = lane & 15, k = lane >> 4;
+    const unsigned int rows = 2 * a.N;
+
+    // per column tile: which array this lane reads, its row stride and offset inside the row
+    const double *src[T];
+    int stride[T];
+    size_t img_stride[T];  // distance between image A's and image B's rows in that array
+#pragma unroll
+    for (int j = 0; j < T; j++) {
+        const int col = 16 * j + c;
+        src[j] = nullptr;
+        stride[j] = 0;
+        img_stride[j] = 0;
+        if (col < K) {
+            src[j] = a.jac_intr + (size_t)bA * rows * K + col;
+            stride[j] = K;
+        } else if (col < W - 1) {
+            const int l = (col - K) / 6;
+            src[j] = a.jac_member[l] + (size_t)bA * rows * 6 + (col - K - 6 * l);
+            stride[j] = 6;
+        } else if (col == W - 1) {
+            src[j] = a.res + (size_t)bA * rows;
+            stride[j] = 1;
+        }
+        img_stride[j] = (size_t)rows * stride[j];
+    }
+    f64x4 accA[T][T], accB[T][T];
+    zero_acc<T>(accA);
+    zero_acc<T>(accB);
+    // the fused kernel contracts each image in steps of 32 corners = 16 groups of 4 rows, zero-padded at the
+    // end of the image; reproduce exactly that sequence of (row group -> MFMA) so the sums round identically
+    const unsigned int n_chunks = (a.N + kGramHalf - 1) / kGramHalf;
+    for (unsigned int ch = 0; ch < n_chunks; ch++) {
+        const unsigned int row0 = ch * 2 * kGramHalf;
+        for (int t0 = 0; t0 < kGramHalf / 2; t0 += kRowsUnroll) {
+            double vA[kRowsUnroll][T], vB[kRowsUnroll][T];
+#pragma unroll
+            for (int u = 0; u < kRowsUnroll; u++) {
+                const unsigned int row = row0 + 4 * (t0 + u) + k;
+#pragma unroll
+                for (int j = 0; j < T; j++) {
+                    const bool ok = src[j] && row < rows;
+                    vA[u][j] = ok ? src[j][(size_t)row * stride[j]] : 0.;
+                    vB[u][j] = (ok && hasB) ? src[j][img_stride[j] + (size_t)row * stride[j]] : 0.;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kRowsUnroll; u++)
+#pragma unroll
+                for (int ti = 0; ti < T; ti++)
+#pragma unroll
+                    for (int tj = ti; tj < T; tj++) {
+                        accA[ti][tj] = mfma_f64_16x16x4(vA[u][ti], vA[u][tj], accA[ti][tj]);
+                        accB[ti][tj] = mfma_f64_16x16x4(vB[u][ti], vB[u][tj], accB[ti][tj]);
+                    }
+        }
+    }
+    store_gram<T>(accA, a.gram + (size_t)bA * W * W, W, lane);
+    if (hasB) store_gram<T>(accB, a.gram + (size_t)(bA + 1) * W * W, W, lane);
+}
+
+// ------------------------------------------------------------------------------------------
+// Deterministic sum over images, two launches, no atomics (run-to-run and 1/2/4/8-GPU reproducible):
+//   stage 1  vg_gram_slab_sum_kernel   workgroup p adds kSlab consecutive images, entry-parallel; the kSlab loads
+//                                      of a lane are independent (all in flight), the adds a fixed tree
+//   stage 2  vg_gram_final_sum_kernel  one workgroup per 4 entries: 64 lanes stride over the partials in
+//                                      a fixed order, then a fixed-order wave reduction
+// ------------------------------------------------------------------------------------------
+constexpr int kSlab = 32;
+
+__global__ __launch_bounds__(256) void vg_gram_slab_sum_kernel(const double *__restrict__ in, unsigned int n_items,
+                                                                int entries, double *__restrict__ out)
+{
+    const unsigned int i0 = blockIdx.x * kSlab;
+    for (int e = threadIdx.x; e < entries; e += blockDim.x) {
+        double v[kSlab];
+#pragma unroll
+        for (int k = 0; k < kSlab; k++) v[k] = (i0 + k < n_items) ? in[(size_t)(i0 + k) * entries + e] : 0.;
+        // fixed pairwise tree
+#pragma unroll
+        for (int w = 1; w < kSlab; w *= 2)
+#pragma unroll
+            for (int k = 0; k + w < kSlab; k += 2 * w) v[k] += v[k + w];
+        out[(size_t)blockIdx.x * entries + e] = v[0];
+    }
+}
+
+__global__ __launch_bounds__(256) void vg_gram_final_sum_kernel(const double *__restrict__ in, unsigned int n_items,
+                                                                 int entries, double *__restrict__ out)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // one wave per entry
+    if (e >= entries) return;
+    double s = 0.;
+    for (unsigned int i = lane; i < n_items; i += kWave) s += in[(size_t)i * entries + e];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, kWave);  // fixed butterfly order
+    if (lane == 0) out[e] = s;
+}
+
+}  // namespace vg

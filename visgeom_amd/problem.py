@@ -205,6 +205,35 @@ class CalibrationProblem:
                                                  ctypes.c_void_p(jac_intr.data_ptr()) if jac_intr is not None else None,
                                                  jm))
 
+    # -- normal equations ------------------------------------------------------------------
+    def gram_width(self, d):
+        return self._lib.vg_dataset_gram_width(self._h, d)
+
+    def alloc_gram(self, d):
+        torch = self._torch
+        W = self.gram_width(d)
+        dev = torch.device("cuda", self.device)
+        return (torch.empty((self.datasets[d]["n_blocks"], W, W), dtype=torch.float64, device=dev),
+                torch.empty((W, W), dtype=torch.float64, device=dev))
+
+    def gram_fused(self, d, gram):
+        """per-image Gram of [J | r], J never materialised (needs prepare() at the current parameters)."""
+        capi.check(self._lib.vg_dataset_gram_fused(self._h, d, ctypes.c_void_p(gram.data_ptr())))
+
+    def gram_from_rows(self, d, res, jac_intr, jac_member, gram):
+        """the same Gram matrices from the rows evaluate_dataset wrote (second pass)."""
+        L = self.datasets[d]["L"]
+        jm = (ctypes.c_void_p * max(L, 1))()
+        for l in range(L):
+            jm[l] = jac_member[l].data_ptr()
+        capi.check(self._lib.vg_dataset_gram_from_rows(self._h, d, ctypes.c_void_p(res.data_ptr()),
+                                                       ctypes.c_void_p(jac_intr.data_ptr()), jm,
+                                                       ctypes.c_void_p(gram.data_ptr())))
+
+    def gram_sum(self, d, gram, out):
+        capi.check(self._lib.vg_dataset_gram_sum(self._h, d, ctypes.c_void_p(gram.data_ptr()),
+                                                 ctypes.c_void_p(out.data_ptr())))
+
     def synchronize(self):
         capi.check(self._lib.vg_problem_synchronize(self._h))
 
