@@ -173,6 +173,61 @@ int vg_dataset_gram_from_rows(vg_problem *p, int dataset_id, const double *resid
 /* sum over the dataset's blocks in a fixed order (two-stage tree, no atomics): sum[W*W] device. */
 int vg_dataset_gram_sum(vg_problem *p, int dataset_id, const double *gram, double *sum);
 
+/* =====================================================================================
+ * 4. Solve -- replaces ceres::Solve(options, &globalProblem, &summary) at
+ *    src/calibration/unified_calibration.cpp:53 for problems made of GenericProjectionJac blocks.
+ *    Levenberg-Marquardt (Ceres' trust-region policy), per-pose 6x6 blocks eliminated on the GPU
+ *    (Schur complement), the small global system factored on the host.  Constant blocks stay fixed
+ *    (:604-617); non-constant intrinsics are kept inside the camera's box bounds (:621-627).
+ *    The result is written to the problem's parameter vector.
+ * ===================================================================================== */
+/* Sums host_buf[0..n) over all ranks in place (every rank must end with the same values).  NULL = one GPU. */
+typedef int (*vg_allreduce_fn)(double *host_buf, int64_t n, void *user);
+
+typedef struct vg_solve_options {
+    int max_num_iterations;             /* 1000   unified_calibration.cpp:46 */
+    double function_tolerance;          /* 1e-15  :47 */
+    double gradient_tolerance;          /* 1e-15  :48 */
+    double parameter_tolerance;         /* 1e-15  :49 */
+    double initial_trust_region_radius; /* 1e4    Ceres default (the reference does not set it) */
+    double max_trust_region_radius;     /* 1e16 */
+    double min_trust_region_radius;     /* 1e-32 */
+    double min_relative_decrease;       /* 1e-3 */
+    double min_lm_diagonal;             /* 1e-6 */
+    double max_lm_diagonal;             /* 1e32 */
+    int use_bounds;                     /* 1 */
+    int verbose;                        /* minimizer_progress_to_stdout, :51 */
+    vg_allreduce_fn allreduce;          /* multi-GPU: images sharded over ranks, global parameters replicated */
+    void *allreduce_user;
+} vg_solve_options;
+
+enum vg_termination {
+    VG_TERM_CONVERGENCE_FUNCTION = 0,
+    VG_TERM_CONVERGENCE_GRADIENT = 1,
+    VG_TERM_CONVERGENCE_PARAMETER = 2,
+    VG_TERM_NO_CONVERGENCE = 3, /* max_num_iterations reached */
+    VG_TERM_RADIUS_TOO_SMALL = 4,
+    VG_TERM_FAILURE = 5
+};
+
+typedef struct vg_solve_summary {
+    double initial_cost, final_cost; /* 1/2 sum r^2, as Ceres reports it */
+    int num_iterations, num_successful_steps, termination;
+    double gradient_max_norm, final_radius;
+    double total_seconds, evaluate_seconds, schur_seconds, host_seconds;
+    int num_global_columns;     /* G */
+    int64_t num_pose_blocks;
+    char message[160];
+} vg_solve_summary;
+
+void vg_solve_options_init(vg_solve_options *o); /* the defaults listed above */
+int vg_problem_solve(vg_problem *p, const vg_solve_options *options, vg_solve_summary *summary);
+
+/* Host-only helper of the solver, exported so the host logic can be tested without a GPU:
+ * solves the symmetric positive definite n x n system A x = b (row-major A, untouched) by Cholesky.
+ * Returns VG_ERR_NUMERIC when A is not positive definite. */
+int vg_host_cholesky_solve(int n, const double *A, const double *b, double *x);
+
 /* ---- measurement helpers (bench / profiling only): a pure streaming write / copy with the same
  * 16 B-per-lane access pattern as the emit kernel, to calibrate rocprofv3's WRITE_SIZE / FETCH_SIZE
  * and to measure the achievable HBM rate on the box. */

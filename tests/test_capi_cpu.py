@@ -105,3 +105,33 @@ def test_oracle_header_declares_itself_test_infrastructure():
     for f in ("vg_oracle.h", "vg_oracle.c", "vgo.py"):
         head = open(os.path.join(ROOT, "oracle", f)).read()[:1500].upper()
         assert "TEST INFRASTRUCTURE" in head
+
+
+def test_host_cholesky_solve(lib):
+    """host-side linear algebra of the LM driver (the G x G reduced system), no GPU needed."""
+    import numpy as np
+
+    from visgeom_amd import capi
+
+    rng = np.random.default_rng(3)
+    dp = ctypes.POINTER(ctypes.c_double)
+    for n in (1, 6, 18, 45):
+        M = rng.normal(size=(n, n))
+        A = np.ascontiguousarray(M @ M.T + n * np.eye(n))
+        b = rng.normal(size=n)
+        x = np.empty(n)
+        assert lib.vg_host_cholesky_solve(n, A.ctypes.data_as(dp), b.ctypes.data_as(dp), x.ctypes.data_as(dp)) == 0
+        assert np.max(np.abs(x - np.linalg.solve(A, b))) < 1e-10
+    A = np.ascontiguousarray(np.array([[1.0, 2.0], [2.0, 1.0]]))  # indefinite
+    b, x = np.ones(2), np.empty(2)
+    assert lib.vg_host_cholesky_solve(2, A.ctypes.data_as(dp), b.ctypes.data_as(dp), x.ctypes.data_as(dp)) == capi.ERR_NUMERIC
+
+
+def test_solve_option_defaults_mirror_the_reference(lib):
+    from visgeom_amd import capi
+
+    o = capi.SolveOptions()
+    lib.vg_solve_options_init(ctypes.byref(o))
+    # Solver::Options of GenericCameraCalibration::compute, unified_calibration.cpp:42-52
+    assert (o.max_num_iterations, o.function_tolerance, o.gradient_tolerance, o.parameter_tolerance) == (1000, 1e-15, 1e-15, 1e-15)
+    assert o.initial_trust_region_radius == 1e4 and o.use_bounds == 1 and not o.allreduce

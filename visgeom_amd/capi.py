@@ -24,6 +24,34 @@ DOUBLE_BIG = 1e15
 OK = 0
 ERR_INVALID_ARGUMENT, ERR_HIP, ERR_NO_DEVICE, ERR_STATE, ERR_ALLOC, ERR_NUMERIC = 1, 2, 3, 4, 5, 6
 
+ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, _dp, ctypes.c_int64, ctypes.c_void_p)
+
+
+class SolveOptions(ctypes.Structure):
+    """struct vg_solve_options"""
+    _fields_ = [("max_num_iterations", ctypes.c_int), ("function_tolerance", ctypes.c_double),
+                ("gradient_tolerance", ctypes.c_double), ("parameter_tolerance", ctypes.c_double),
+                ("initial_trust_region_radius", ctypes.c_double), ("max_trust_region_radius", ctypes.c_double),
+                ("min_trust_region_radius", ctypes.c_double), ("min_relative_decrease", ctypes.c_double),
+                ("min_lm_diagonal", ctypes.c_double), ("max_lm_diagonal", ctypes.c_double),
+                ("use_bounds", ctypes.c_int), ("verbose", ctypes.c_int),
+                ("allreduce", ALLREDUCE_FN), ("allreduce_user", ctypes.c_void_p)]
+
+
+class SolveSummary(ctypes.Structure):
+    """struct vg_solve_summary"""
+    _fields_ = [("initial_cost", ctypes.c_double), ("final_cost", ctypes.c_double),
+                ("num_iterations", ctypes.c_int), ("num_successful_steps", ctypes.c_int), ("termination", ctypes.c_int),
+                ("gradient_max_norm", ctypes.c_double), ("final_radius", ctypes.c_double),
+                ("total_seconds", ctypes.c_double), ("evaluate_seconds", ctypes.c_double),
+                ("schur_seconds", ctypes.c_double), ("host_seconds", ctypes.c_double),
+                ("num_global_columns", ctypes.c_int), ("num_pose_blocks", ctypes.c_int64),
+                ("message", ctypes.c_char * 160)]
+
+
+TERMINATION = {0: "CONVERGENCE_FUNCTION", 1: "CONVERGENCE_GRADIENT", 2: "CONVERGENCE_PARAMETER", 3: "NO_CONVERGENCE",
+               4: "RADIUS_TOO_SMALL", 5: "FAILURE"}
+
 # every symbol include/visgeom_amd.h declares: (restype, argtypes)
 SIGNATURES = {
     "vg_abi_version": (ctypes.c_int, []),
@@ -63,6 +91,9 @@ SIGNATURES = {
     "vg_dataset_gram_fused": (ctypes.c_int, [_vp, ctypes.c_int, _vp]),
     "vg_dataset_gram_from_rows": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vpp, _vp]),
     "vg_dataset_gram_sum": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp]),
+    "vg_solve_options_init": (None, [ctypes.POINTER(SolveOptions)]),
+    "vg_problem_solve": (ctypes.c_int, [_vp, ctypes.POINTER(SolveOptions), ctypes.POINTER(SolveSummary)]),
+    "vg_host_cholesky_solve": (ctypes.c_int, [ctypes.c_int, _dp, _dp, _dp]),
     "vg_calib_stream_write": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_double]),
     "vg_calib_stream_copy": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64]),
 }

@@ -1,87 +1,30 @@
 // vg_capi.hip -- implementation of include/visgeom_amd.h (host side + kernel launches).
 // Built with hipcc for gfx950 only.  No CPU fallback: every compute entry needs a HIP device.
-#include "../../include/visgeom_amd.h"
-
-#include <hip/hip_runtime.h>
-
 #include <cstdio>
 #include <cstring>
 #include <new>
 #include <string>
 #include <vector>
 
+#include "vg_internal.hpp"
 #include "vg_gram.hpp"
 
 namespace {
 
 thread_local std::string g_err;
 
-int fail(int code, const std::string &msg)
+}  // namespace
+
+int vgi::fail(int code, const std::string &msg)
 {
     g_err = msg;
     return code;
 }
 
-#define VG_HIP(expr)                                                                              \
-    do {                                                                                          \
-        hipError_t e_ = (expr);                                                                   \
-        if (e_ != hipSuccess) {                                                                   \
-            return fail(e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice ? VG_ERR_NO_DEVICE  \
-                                                                              : VG_ERR_HIP,       \
-                        std::string(#expr) + ": " + hipGetErrorString(e_));                       \
-        }                                                                                         \
-    } while (0)
-
-struct Camera {
-    int model = 0, K = 0;
-    bool constant = false;
-    int64_t offset = -1;
-    std::vector<double> init;
-};
-
-struct Transform {
-    bool global = true, constant = false;
-    int64_t count = 1;
-    int64_t offset = -1;
-    std::vector<double> init;
-};
-
-struct Dataset {
-    int camera = -1, L = 0, N = 0;
-    int tids[vg::kMaxChain] = {0};
-    int status[vg::kMaxChain] = {0};
-    int64_t n_blocks = 0;
-    std::vector<double> h_board, h_obs;
-    std::vector<int32_t> h_seq;
-    double *d_board = nullptr, *d_obs = nullptr, *d_frames = nullptr;
-    int32_t *d_seq = nullptr;
-    unsigned long long *d_failed = nullptr;
-    double *d_partials = nullptr;  // [ceil(n_blocks / kSlab)][W*W] workspace of vg_dataset_gram_sum
-    unsigned long long epoch = 0;  // evaluation counter, tags d_failed
-    int frame_stride = 0;
-    vg::ChainDesc chain;
-};
-
-}  // namespace
-
-struct vg_problem {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool finalized = false;
-    std::vector<Camera> cams;
-    std::vector<Transform> tfs;
-    std::vector<Dataset> dss;
-    int64_t n_params = 0;
-    double *d_params = nullptr;
-};
-
-struct vg_block {
-    vg_problem *p = nullptr;
-    int model = 0, K = 0, L = 0, N = 0;
-    double *d_res = nullptr, *d_jintr = nullptr;
-    double *d_jm[vg::kMaxChain] = {nullptr};
-    std::vector<double> h_params;
-};
+using vgi::Camera;
+using vgi::Dataset;
+using vgi::Transform;
+using vgi::fail;
 
 namespace {
 
@@ -155,13 +98,13 @@ int valid_dataset(const vg_problem *p, int d)
 
 namespace {
 
-void fill_gram_args(const vg_problem *p, const Dataset &d, vg::GramArgs &a, double *gram)
+void fill_gram_args(const vg_problem *p, const Dataset &d, vg::GramArgs &a, double *gram, const double *d_params)
 {
     const Camera &cam = p->cams[d.camera];
     a.frames = d.d_frames;
     a.board = d.d_board;
     a.obs = d.d_obs;
-    a.intr = p->d_params + cam.offset;
+    a.intr = d_params + cam.offset;
     a.res = nullptr;
     a.jac_intr = nullptr;
     for (int l = 0; l < vg::kMaxChain; l++) a.jac_member[l] = nullptr;
@@ -426,19 +369,28 @@ int vg_dataset_num_intrinsics(const vg_problem *p, int d)
     return valid_dataset(p, d) == VG_OK ? p->cams[p->dss[d].camera].K : -1;
 }
 
+}  // extern "C"
+
+int vgi::prepare_at(vg_problem *p, const double *d_params)
+{
+    for (auto &d : p->dss) {
+        if (!d.n_blocks) continue;
+        const unsigned int grid = (unsigned int)((d.n_blocks + 63) / 64);
+        hipLaunchKernelGGL(vg::vg_chain_prep_kernel, dim3(grid), dim3(64), 0, p->stream, d_params, d.chain, d.d_seq,
+                           (long long)d.n_blocks, d.d_frames, d.frame_stride);
+        VG_HIP(hipGetLastError());
+    }
+    return VG_OK;
+}
+
+extern "C" {
+
 int vg_problem_prepare(vg_problem *p)
 {
     if (!p) return fail(VG_ERR_INVALID_ARGUMENT, "problem is NULL");
     if (!p->finalized) return fail(VG_ERR_STATE, "problem not finalized");
     VG_HIP(hipSetDevice(p->device));
-    for (auto &d : p->dss) {
-        if (!d.n_blocks) continue;
-        const unsigned int grid = (unsigned int)((d.n_blocks + 63) / 64);
-        hipLaunchKernelGGL(vg::vg_chain_prep_kernel, dim3(grid), dim3(64), 0, p->stream, p->d_params, d.chain,
-                           d.d_seq, (long long)d.n_blocks, d.d_frames, d.frame_stride);
-        VG_HIP(hipGetLastError());
-    }
-    return VG_OK;
+    return vgi::prepare_at(p, p->d_params);
 }
 
 int vg_dataset_evaluate(vg_problem *p, int dataset_id, double *residuals, double *jac_intr, double *const *jac_member)
@@ -518,23 +470,32 @@ int vg_dataset_gram_width(const vg_problem *p, int d)
 }
 
 
-int vg_dataset_gram_fused(vg_problem *p, int dataset_id, double *gram)
+}  // extern "C"
+
+int vgi::gram_fused_at(vg_problem *p, int dataset_id, const double *d_params, double *gram)
 {
-    int rc = valid_dataset(p, dataset_id);
-    if (rc != VG_OK) return rc;
-    if (!p->finalized) return fail(VG_ERR_STATE, "problem not finalized");
     Dataset &d = p->dss[dataset_id];
     if (!d.n_blocks) return VG_OK;
     if (!gram) return fail(VG_ERR_INVALID_ARGUMENT, "gram is NULL");
     if (d.n_blocks > 0x7fffffff) return fail(VG_ERR_INVALID_ARGUMENT, "too many blocks for one launch");
-    VG_HIP(hipSetDevice(p->device));
     vg::GramArgs a;
-    fill_gram_args(p, d, a, gram);
+    fill_gram_args(p, d, a, gram, d_params);
     switch (p->cams[d.camera].model) {
     case VG_MODEL_EUCM: return launch_gram_fused<vg::kEUCM>(p->stream, a);
     case VG_MODEL_UCM: return launch_gram_fused<vg::kUCM>(p->stream, a);
     default: return launch_gram_fused<vg::kMEI>(p->stream, a);
     }
+}
+
+extern "C" {
+
+int vg_dataset_gram_fused(vg_problem *p, int dataset_id, double *gram)
+{
+    int rc = valid_dataset(p, dataset_id);
+    if (rc != VG_OK) return rc;
+    if (!p->finalized) return fail(VG_ERR_STATE, "problem not finalized");
+    VG_HIP(hipSetDevice(p->device));
+    return vgi::gram_fused_at(p, dataset_id, p->d_params, gram);
 }
 
 int vg_dataset_gram_from_rows(vg_problem *p, int dataset_id, const double *residuals, const double *jac_intr,
@@ -552,7 +513,7 @@ int vg_dataset_gram_from_rows(vg_problem *p, int dataset_id, const double *resid
     if (d.n_blocks > 0x7fffffff) return fail(VG_ERR_INVALID_ARGUMENT, "too many blocks for one launch");
     VG_HIP(hipSetDevice(p->device));
     vg::GramArgs a;
-    fill_gram_args(p, d, a, gram);
+    fill_gram_args(p, d, a, gram, p->d_params);
     a.res = residuals;
     a.jac_intr = jac_intr;
     for (int l = 0; l < d.L; l++) a.jac_member[l] = jac_member[l];
@@ -568,14 +529,11 @@ int vg_dataset_gram_from_rows(vg_problem *p, int dataset_id, const double *resid
     return VG_OK;
 }
 
-int vg_dataset_gram_sum(vg_problem *p, int dataset_id, const double *gram, double *sum)
+}  // extern "C"
+
+int vgi::gram_sum_into(vg_problem *p, int dataset_id, const double *gram, double *sum)
 {
-    int rc = valid_dataset(p, dataset_id);
-    if (rc != VG_OK) return rc;
-    if (!p->finalized) return fail(VG_ERR_STATE, "problem not finalized");
-    if (!sum) return fail(VG_ERR_INVALID_ARGUMENT, "sum is NULL");
     Dataset &d = p->dss[dataset_id];
-    VG_HIP(hipSetDevice(p->device));
     const int W = p->cams[d.camera].K + 6 * d.L + 1;
     const int entries = W * W;
     if (!d.n_blocks) {
@@ -592,6 +550,18 @@ int vg_dataset_gram_sum(vg_problem *p, int dataset_id, const double *gram, doubl
                        (const double *)d.d_partials, parts, entries, sum);
     VG_HIP(hipGetLastError());
     return VG_OK;
+}
+
+extern "C" {
+
+int vg_dataset_gram_sum(vg_problem *p, int dataset_id, const double *gram, double *sum)
+{
+    int rc = valid_dataset(p, dataset_id);
+    if (rc != VG_OK) return rc;
+    if (!p->finalized) return fail(VG_ERR_STATE, "problem not finalized");
+    if (!sum) return fail(VG_ERR_INVALID_ARGUMENT, "sum is NULL");
+    VG_HIP(hipSetDevice(p->device));
+    return vgi::gram_sum_into(p, dataset_id, gram, sum);
 }
 
 /* ------------------------------------------------------------------------------------------ per-block */
@@ -712,3 +682,5 @@ int vg_calib_stream_copy(void *hip_stream, double *dst, const double *src, int64
 }
 
 }  // extern "C"
+
+#include "vg_solver_impl.hpp"

@@ -1,0 +1,86 @@
+// vg_internal.hpp -- host-side state shared by the translation units of libvisgeom_amd.so (not installed).
+#pragma once
+
+#include "../../include/visgeom_amd.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "vg_kernels.hpp"
+
+namespace vgi {
+
+int fail(int code, const std::string &msg);
+
+#define VG_HIP(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            return vgi::fail(e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice ? VG_ERR_NO_DEVICE \
+                                                                                   : VG_ERR_HIP,  \
+                             std::string(#expr) + ": " + hipGetErrorString(e_));                  \
+        }                                                                                         \
+    } while (0)
+
+struct Camera {
+    int model = 0, K = 0;
+    bool constant = false;
+    int64_t offset = -1;
+    std::vector<double> init;
+};
+
+struct Transform {
+    bool global = true, constant = false;
+    int64_t count = 1;
+    int64_t offset = -1;
+    std::vector<double> init;
+};
+
+struct Dataset {
+    int camera = -1, L = 0, N = 0;
+    int tids[vg::kMaxChain] = {0};
+    int status[vg::kMaxChain] = {0};
+    int64_t n_blocks = 0;
+    std::vector<double> h_board, h_obs;
+    std::vector<int32_t> h_seq;
+    double *d_board = nullptr, *d_obs = nullptr, *d_frames = nullptr;
+    int32_t *d_seq = nullptr;
+    unsigned long long *d_failed = nullptr;
+    double *d_partials = nullptr;  // [ceil(n_blocks / kSlab)][W*W] workspace of vg_dataset_gram_sum
+    unsigned long long epoch = 0;  // evaluation counter, tags d_failed
+    int frame_stride = 0;
+    vg::ChainDesc chain;
+};
+
+}  // namespace vgi
+
+struct vg_problem {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool finalized = false;
+    std::vector<vgi::Camera> cams;
+    std::vector<vgi::Transform> tfs;
+    std::vector<vgi::Dataset> dss;
+    int64_t n_params = 0;
+    double *d_params = nullptr;
+};
+
+struct vg_block {
+    vg_problem *p = nullptr;
+    int model = 0, K = 0, L = 0, N = 0;
+    double *d_res = nullptr, *d_jintr = nullptr;
+    double *d_jm[vg::kMaxChain] = {nullptr};
+    std::vector<double> h_params;
+};
+
+
+namespace vgi {
+// kernel launches on an explicit parameter buffer (the solver evaluates candidate points without
+// touching the problem's own parameter vector); implemented in vg_capi.hip
+int prepare_at(vg_problem *p, const double *d_params);
+int gram_fused_at(vg_problem *p, int dataset_id, const double *d_params, double *gram);
+int gram_sum_into(vg_problem *p, int dataset_id, const double *gram, double *sum);
+}  // namespace vgi

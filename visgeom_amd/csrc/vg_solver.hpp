@@ -1,0 +1,256 @@
+// vg_solver.hpp -- device kernels of the Levenberg-Marquardt driver (what replaces
+// ceres::Solve at src/calibration/unified_calibration.cpp:53 for the calibration problem).
+//
+// The normal equations have arrow structure: a small dense global block (all intrinsics + global transforms,
+// G columns) and one 6x6 block per pose instance of a sequence transform, coupled only through the global block:
+//     [ U   W ] [dg]     [gg]          U = sum A^T A,  V_i = sum B^T B,  W_i = sum A^T B,   J_b = [A_b | B_b]
+//     [ W^T V ] [dp] = - [gp]
+// Every pose is eliminated on the GPU (one lane per pose): V_i' = V_i + mu*D_i = L L^T, and the six rows
+//     z_k = (L^-1 W_i^T)[k, :],   y_k = (L^-1 gp_i)[k]
+// are emitted.  The Schur complement is then a Gram sum over those rows,
+//     S = U' - sum_rows z z^T,   rhs = -gg + sum_rows z y,
+// contracted with the same fixed-order FP64-MFMA machinery as the per-image Grams.  The host factors the G x G
+// system (G <= ~50), and a second lane-per-pose kernel back-substitutes dp_i = -V_i'^-1 (gp_i + W_i^T dg).
+#pragma once
+
+#include "vg_gram.hpp"
+
+namespace vg {
+
+constexpr int kMaxLocalCols = 10 + 6 * kMaxChain;
+constexpr int kPoseRec = 34;  // per pose: L (21, packed lower) | gp (6) | diag V (6) | active (1)
+
+struct SolveDatasetDev {
+    const double *gram;  // [n_blocks][W*W] at the current point
+    int W;
+    int pose_off;        // local column of the sequence member, -1 when the chain has none
+};
+
+__device__ __forceinline__ int tri(int r, int c) { return r * (r + 1) / 2 + c; }
+
+__device__ __forceinline__ double clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// y = L^-1 w  (L packed lower 6x6)
+__device__ __forceinline__ void fwd6(const double *L, const double *w, double *y)
+{
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+        double s = w[r];
+#pragma unroll
+        for (int c = 0; c < r; c++) s -= L[tri(r, c)] * y[c];
+        y[r] = s / L[tri(r, r)];
+    }
+}
+
+// x = L^-T y
+__device__ __forceinline__ void bwd6(const double *L, const double *y, double *x)
+{
+#pragma unroll
+    for (int r = 5; r >= 0; r--) {
+        double s = y[r];
+#pragma unroll
+        for (int c = r + 1; c < 6; c++) s -= L[tri(c, r)] * x[c];
+        x[r] = s / L[tri(r, r)];
+    }
+}
+
+struct SchurArgs {
+    const SolveDatasetDev *ds;
+    const int *inv;        // [n_datasets][G]: global column -> local column of that dataset, or -1
+    const int *ref_ptr;    // [n_poses + 1]
+    const int *ref_ds;     // [n_refs]
+    const int *ref_blk;    // [n_refs]
+    const unsigned char *pose_frozen;
+    int G;
+    int n_poses;
+    double mu, dmin, dmax;
+    double *rec;           // [n_poses][kPoseRec]
+    double *rows;          // [n_poses * 6][G + 1]
+    int *bad;              // number of poses whose damped block was not positive definite
+};
+
+__global__ __launch_bounds__(64) void vg_schur_rows_kernel(SchurArgs a)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n_poses) return;
+    const int r0 = a.ref_ptr[i], r1 = a.ref_ptr[i + 1];
+    double V[21], gp[6], vd[6];
+#pragma unroll
+    for (int k = 0; k < 21; k++) V[k] = 0.;
+#pragma unroll
+    for (int k = 0; k < 6; k++) gp[k] = 0.;
+    for (int q = r0; q < r1; q++) {
+        const SolveDatasetDev D = a.ds[a.ref_ds[q]];
+        const double *Gb = D.gram + (size_t)a.ref_blk[q] * D.W * D.W;
+        const int o = D.pose_off;
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+#pragma unroll
+            for (int c = 0; c <= r; c++) V[tri(r, c)] += Gb[(o + r) * D.W + o + c];
+            gp[r] += Gb[(o + r) * D.W + D.W - 1];
+        }
+    }
+    bool active = !a.pose_frozen[i] && r1 > r0;
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+        vd[r] = V[tri(r, r)];
+        V[tri(r, r)] += a.mu * clampd(vd[r], a.dmin, a.dmax);
+    }
+    // in-place Cholesky, packed lower
+    double L[21];
+    bool pd = true;
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+#pragma unroll
+        for (int c = 0; c <= r; c++) {
+            double s = V[tri(r, c)];
+#pragma unroll
+            for (int k = 0; k < c; k++) s -= L[tri(r, k)] * L[tri(c, k)];
+            if (r == c) {
+                if (!(s > 0.)) { pd = false; s = 1.; }
+                L[tri(r, r)] = sqrt(s);
+            } else {
+                L[tri(r, c)] = s / L[tri(c, c)];
+            }
+        }
+    }
+    if (active && !pd) {
+        atomicAdd(a.bad, 1);
+        active = false;
+    }
+    double *rec = a.rec + (size_t)i * kPoseRec;
+#pragma unroll
+    for (int k = 0; k < 21; k++) rec[k] = L[k];
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        rec[21 + k] = gp[k];
+        rec[27 + k] = vd[k];
+    }
+    rec[33] = active ? 1. : 0.;
+
+    const int C = a.G + 1;
+    double *out = a.rows + (size_t)i * 6 * C;
+    for (int gcol = 0; gcol <= a.G; gcol++) {
+        double w[6], y[6];
+        if (gcol < a.G) {
+#pragma unroll
+            for (int c = 0; c < 6; c++) w[c] = 0.;
+            for (int q = r0; q < r1; q++) {
+                const int d = a.ref_ds[q];
+                const int lc = a.inv[d * a.G + gcol];
+                if (lc < 0) continue;
+                const SolveDatasetDev D = a.ds[d];
+                const double *Gb = D.gram + (size_t)a.ref_blk[q] * D.W * D.W;
+#pragma unroll
+                for (int c = 0; c < 6; c++) w[c] += Gb[lc * D.W + D.pose_off + c];
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 6; c++) w[c] = gp[c];
+        }
+        fwd6(L, w, y);
+#pragma unroll
+        for (int k = 0; k < 6; k++) out[k * C + gcol] = active ? y[k] : 0.;
+    }
+}
+
+struct BacksubArgs {
+    SchurArgs s;
+    const double *dg;              // [G] global step
+    const long long *pose_param;   // [n_poses] offset of the pose's 6-vector in the parameter vector
+    const long long *gcol_param;   // [G] offset of each global column in the parameter vector
+    double *delta;                 // parameter-layout step vector
+    double *scal;                  // [n_poses][5]: gp.dp | sum D dp^2 | max|gp| | |dp|^2 | |gp|^2
+};
+
+__global__ __launch_bounds__(64) void vg_backsub_kernel(BacksubArgs b)
+{
+    const SchurArgs &a = b.s;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < a.G) b.delta[b.gcol_param[i]] = b.dg[i];
+    if (i >= a.n_poses) return;
+    const double *rec = a.rec + (size_t)i * kPoseRec;
+    double L[21], t[6], y[6], x[6];
+#pragma unroll
+    for (int k = 0; k < 21; k++) L[k] = rec[k];
+#pragma unroll
+    for (int k = 0; k < 6; k++) t[k] = rec[21 + k];
+    const bool active = rec[33] != 0.;
+    const int r0 = a.ref_ptr[i], r1 = a.ref_ptr[i + 1];
+    for (int q = r0; q < r1; q++) {
+        const int d = a.ref_ds[q];
+        const SolveDatasetDev D = a.ds[d];
+        const double *Gb = D.gram + (size_t)a.ref_blk[q] * D.W * D.W;
+        for (int gcol = 0; gcol < a.G; gcol++) {
+            const int lc = a.inv[d * a.G + gcol];
+            if (lc < 0) continue;
+            const double dgv = b.dg[gcol];
+#pragma unroll
+            for (int c = 0; c < 6; c++) t[c] += Gb[lc * D.W + D.pose_off + c] * dgv;
+        }
+    }
+    fwd6(L, t, y);
+    bwd6(L, y, x);
+    double s0 = 0., s1 = 0., s2 = 0., s3 = 0., s4 = 0.;
+    double *dp = b.delta + b.pose_param[i];
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+        const double v = active ? -x[c] : 0.;
+        dp[c] = v;
+        const double g = rec[21 + c];
+        s0 += g * v;
+        s1 += clampd(rec[27 + c], a.dmin, a.dmax) * v * v;
+        if (active) s2 = fmax(s2, fabs(g));
+        if (active) s4 += g * g;
+        s3 += v * v;
+    }
+    double *sc = b.scal + (size_t)i * 5;
+    sc[0] = s0;
+    sc[1] = s1;
+    sc[2] = s2;
+    sc[3] = s3;
+    sc[4] = s4;
+}
+
+// x_new = clamp(x + delta, lo, hi)
+__global__ __launch_bounds__(256) void vg_apply_step_kernel(const double *__restrict__ x, const double *__restrict__ delta,
+                                                             const double *__restrict__ lo, const double *__restrict__ hi,
+                                                             long long n, double *__restrict__ x_new)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double v = x[i] + delta[i];
+    x_new[i] = v < lo[i] ? lo[i] : (v > hi[i] ? hi[i] : v);
+}
+
+// Gram of a plain row-major matrix X [n_rows][C], one wave per group of `rows_per_group` rows (a multiple of 4),
+// 4 rows per MFMA in increasing order: out[group][C*C].  Groups are then added by the slab / final sum kernels.
+template <int T>
+__global__ __launch_bounds__(256) void vg_dense_gram_kernel(const double *__restrict__ X, unsigned int n_rows, int C,
+                                                             unsigned int rows_per_group, unsigned int n_groups,
+                                                             double *__restrict__ out)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const unsigned int grp = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (grp >= n_groups) return;
+    const int c = lane & 15, k = lane >> 4;
+    const unsigned int row0 = grp * rows_per_group;
+    f64x4 acc[T][T];
+    zero_acc<T>(acc);
+    for (unsigned int t = 0; t < rows_per_group / 4; t++) {
+        const unsigned int row = row0 + 4 * t + k;
+        double v[T];
+#pragma unroll
+        for (int j = 0; j < T; j++) {
+            const int col = 16 * j + c;
+            v[j] = (col < C && row < n_rows) ? X[(size_t)row * C + col] : 0.;
+        }
+#pragma unroll
+        for (int ti = 0; ti < T; ti++)
+#pragma unroll
+            for (int tj = ti; tj < T; tj++) acc[ti][tj] = mfma_f64_16x16x4(v[ti], v[tj], acc[ti][tj]);
+    }
+    store_gram<T>(acc, out + (size_t)grp * C * C, C, lane);
+}
+
+}  // namespace vg

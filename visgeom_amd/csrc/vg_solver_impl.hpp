@@ -1,0 +1,537 @@
+// vg_solver_impl.hpp -- Levenberg-Marquardt driver with per-pose Schur elimination (see vg_solver.hpp).
+// Host orchestration + the small dense algebra; all O(images) work runs in HIP kernels.  Included at the end
+// of vg_capi.hip: the library is ONE translation unit, so the non-template kernels exist once.
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+#include "vg_internal.hpp"
+#include "vg_solver.hpp"
+
+using vgi::fail;
+
+namespace {
+
+double now_s()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// Cholesky solve of a dense SPD system, row-major; returns false when not positive definite
+bool chol_solve(int n, const double *A, const double *b, double *x)
+{
+    std::vector<double> L((size_t)n * n, 0.);
+    for (int r = 0; r < n; r++)
+        for (int c = 0; c <= r; c++) {
+            double s = A[(size_t)r * n + c];
+            for (int k = 0; k < c; k++) s -= L[(size_t)r * n + k] * L[(size_t)c * n + k];
+            if (r == c) {
+                if (!(s > 0.) || !std::isfinite(s)) return false;
+                L[(size_t)r * n + r] = std::sqrt(s);
+            } else {
+                L[(size_t)r * n + c] = s / L[(size_t)c * n + c];
+            }
+        }
+    std::vector<double> y(n);
+    for (int r = 0; r < n; r++) {
+        double s = b[r];
+        for (int c = 0; c < r; c++) s -= L[(size_t)r * n + c] * y[c];
+        y[r] = s / L[(size_t)r * n + r];
+    }
+    for (int r = n - 1; r >= 0; r--) {
+        double s = y[r];
+        for (int c = r + 1; c < n; c++) s -= L[(size_t)c * n + r] * x[c];
+        x[r] = s / L[(size_t)r * n + r];
+    }
+    return true;
+}
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    ~DevBuf()
+    {
+        if (p) (void)hipFree(p);
+    }
+    int alloc(size_t n)
+    {
+        VG_HIP(hipMalloc(&p, sizeof(T) * (n ? n : 1)));
+        return VG_OK;
+    }
+    int upload(const std::vector<T> &h)
+    {
+        int rc = alloc(h.size());
+        if (rc != VG_OK) return rc;
+        if (!h.empty()) VG_HIP(hipMemcpy(p, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice));
+        return VG_OK;
+    }
+};
+
+int launch_dense_gram(hipStream_t st, const double *X, unsigned n_rows, int C, unsigned rows_per_group, unsigned n_groups,
+                      double *out)
+{
+    const int T = (C + 15) / 16;
+    const dim3 grid((n_groups + 3) / 4), blk(256);
+    if (T == 1) hipLaunchKernelGGL((vg::vg_dense_gram_kernel<1>), grid, blk, 0, st, X, n_rows, C, rows_per_group, n_groups, out);
+    else if (T == 2) hipLaunchKernelGGL((vg::vg_dense_gram_kernel<2>), grid, blk, 0, st, X, n_rows, C, rows_per_group, n_groups, out);
+    else if (T == 3) hipLaunchKernelGGL((vg::vg_dense_gram_kernel<3>), grid, blk, 0, st, X, n_rows, C, rows_per_group, n_groups, out);
+    else hipLaunchKernelGGL((vg::vg_dense_gram_kernel<4>), grid, blk, 0, st, X, n_rows, C, rows_per_group, n_groups, out);
+    VG_HIP(hipGetLastError());
+    return VG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void vg_solve_options_init(vg_solve_options *o)
+{
+    if (!o) return;
+    o->max_num_iterations = 1000;   // unified_calibration.cpp:46
+    o->function_tolerance = 1e-15;  // :47
+    o->gradient_tolerance = 1e-15;  // :48
+    o->parameter_tolerance = 1e-15; // :49
+    o->initial_trust_region_radius = 1e4;
+    o->max_trust_region_radius = 1e16;
+    o->min_trust_region_radius = 1e-32;
+    o->min_relative_decrease = 1e-3;
+    o->min_lm_diagonal = 1e-6;
+    o->max_lm_diagonal = 1e32;
+    o->use_bounds = 1;
+    o->verbose = 0;
+    o->allreduce = nullptr;
+    o->allreduce_user = nullptr;
+}
+
+int vg_host_cholesky_solve(int n, const double *A, const double *b, double *x)
+{
+    if (n <= 0 || !A || !b || !x) return fail(VG_ERR_INVALID_ARGUMENT, "bad arguments");
+    return chol_solve(n, A, b, x) ? VG_OK : fail(VG_ERR_NUMERIC, "matrix is not positive definite");
+}
+
+int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_summary *sum)
+{
+    if (!p) return fail(VG_ERR_INVALID_ARGUMENT, "problem is NULL");
+    if (!p->finalized) return fail(VG_ERR_STATE, "problem not finalized");
+    vg_solve_options opt;
+    if (opt_in) opt = *opt_in;
+    else vg_solve_options_init(&opt);
+    VG_HIP(hipSetDevice(p->device));
+    hipStream_t st = p->stream;
+    const double t_start = now_s();
+    double t_eval = 0., t_schur = 0., t_host = 0.;
+
+    // ---------------------------------------------------------------- column / pose bookkeeping
+    const int n_ds = (int)p->dss.size();
+    const int64_t n_params = p->n_params;
+    std::vector<int> cam_goff(p->cams.size()), tf_goff(p->tfs.size(), -1);
+    std::vector<int64_t> tf_pbase(p->tfs.size(), -1);
+    int G = 0;
+    for (size_t c = 0; c < p->cams.size(); c++) { cam_goff[c] = G; G += p->cams[c].K; }
+    for (size_t t = 0; t < p->tfs.size(); t++)
+        if (p->tfs[t].global) { tf_goff[t] = G; G += 6; }
+    if (G > 63) return fail(VG_ERR_INVALID_ARGUMENT, "more than 63 global columns are not supported");
+    int64_t n_poses = 0;
+    for (size_t t = 0; t < p->tfs.size(); t++)
+        if (!p->tfs[t].global) { tf_pbase[t] = n_poses; n_poses += p->tfs[t].count; }
+    if (n_poses > 0x7fffffff / 8) return fail(VG_ERR_INVALID_ARGUMENT, "too many pose blocks");
+
+    std::vector<unsigned char> gfrozen(G, 0), pose_frozen((size_t)n_poses, 0);
+    std::vector<long long> gcol_param(G), pose_param((size_t)n_poses);
+    std::vector<double> lo((size_t)n_params, -std::numeric_limits<double>::infinity()),
+        hi((size_t)n_params, std::numeric_limits<double>::infinity());
+    for (size_t c = 0; c < p->cams.size(); c++)
+        for (int k = 0; k < p->cams[c].K; k++) {
+            gfrozen[cam_goff[c] + k] = p->cams[c].constant;
+            gcol_param[cam_goff[c] + k] = p->cams[c].offset + k;
+            if (opt.use_bounds && !p->cams[c].constant)
+                vg_intrinsic_bounds(p->cams[c].model, k, &lo[p->cams[c].offset + k], &hi[p->cams[c].offset + k]);
+        }
+    for (size_t t = 0; t < p->tfs.size(); t++) {
+        const vgi::Transform &tf = p->tfs[t];
+        if (tf.global) {
+            for (int k = 0; k < 6; k++) {
+                gfrozen[tf_goff[t] + k] = tf.constant;
+                gcol_param[tf_goff[t] + k] = tf.offset + k;
+            }
+        } else {
+            for (int64_t i = 0; i < tf.count; i++) {
+                pose_frozen[(size_t)(tf_pbase[t] + i)] = tf.constant;
+                pose_param[(size_t)(tf_pbase[t] + i)] = tf.offset + 6 * i;
+            }
+        }
+    }
+
+    // per dataset: local -> global column map, pose column offset, pose references
+    std::vector<std::vector<int>> lmap(n_ds);
+    std::vector<int> inv((size_t)n_ds * (G ? G : 1), -1), Wd(n_ds), pose_off(n_ds, -1), seq_tf(n_ds, -1);
+    int Wmax = 1;
+    for (int d = 0; d < n_ds; d++) {
+        const vgi::Dataset &D = p->dss[d];
+        const int K = p->cams[D.camera].K;
+        Wd[d] = K + 6 * D.L + 1;
+        Wmax = Wd[d] > Wmax ? Wd[d] : Wmax;
+        lmap[d].assign(Wd[d] - 1, -1);
+        for (int k = 0; k < K; k++) lmap[d][k] = cam_goff[D.camera] + k;
+        for (int l = 0; l < D.L; l++) {
+            const int t = D.tids[l];
+            if (p->tfs[t].global) {
+                for (int k = 0; k < 6; k++) lmap[d][K + 6 * l + k] = tf_goff[t] + k;
+            } else {
+                if (seq_tf[d] >= 0) return fail(VG_ERR_INVALID_ARGUMENT, "a chain may hold at most one sequence transform");
+                seq_tf[d] = t;  // exactly one is what the reference requires (unified_calibration.cpp:223-228)
+                pose_off[d] = K + 6 * l;
+            }
+        }
+        // the same global transform twice in one chain would need the two column groups merged
+        for (size_t a2 = 0; a2 < lmap[d].size(); a2++)
+            if (lmap[d][a2] >= 0) {
+                if (inv[(size_t)d * G + lmap[d][a2]] >= 0)
+                    return fail(VG_ERR_INVALID_ARGUMENT, "a transform appears twice in one chain");
+                inv[(size_t)d * G + lmap[d][a2]] = (int)a2;
+            }
+    }
+    std::vector<int> ref_ptr((size_t)n_poses + 1, 0), ref_ds, ref_blk;
+    for (int d = 0; d < n_ds; d++)
+        if (seq_tf[d] >= 0)
+            for (int64_t b = 0; b < p->dss[d].n_blocks; b++) ref_ptr[(size_t)(tf_pbase[seq_tf[d]] + p->dss[d].h_seq[(size_t)b]) + 1]++;
+    for (int64_t i = 0; i < n_poses; i++) ref_ptr[(size_t)i + 1] += ref_ptr[(size_t)i];
+    ref_ds.resize(ref_ptr.back());
+    ref_blk.resize(ref_ptr.back());
+    {
+        std::vector<int> cur(ref_ptr.begin(), ref_ptr.end() - 1);
+        for (int d = 0; d < n_ds; d++)
+            if (seq_tf[d] >= 0)
+                for (int64_t b = 0; b < p->dss[d].n_blocks; b++) {
+                    const size_t i = (size_t)(tf_pbase[seq_tf[d]] + p->dss[d].h_seq[(size_t)b]);
+                    ref_ds[cur[i]] = d;
+                    ref_blk[cur[i]++] = (int)b;
+                }
+    }
+
+    // ---------------------------------------------------------------- device state
+    const int C = G + 1;
+    const unsigned int n_rows = (unsigned int)(6 * n_poses);
+    const unsigned int rows_per_group = 384;  // 64 poses per wave
+    const unsigned int n_groups = n_rows ? (n_rows + rows_per_group - 1) / rows_per_group : 0;
+    const unsigned int n_slabs = (n_groups + vg::kSlab - 1) / vg::kSlab;
+    DevBuf<double> gramA[64], gramB[64];
+    if (n_ds > 64) return fail(VG_ERR_INVALID_ARGUMENT, "more than 64 datasets are not supported");
+    DevBuf<double> d_sums, d_x, d_xc, d_delta, d_lo, d_hi, d_rec, d_rows, d_rgroups, d_rslabs, d_rgram, d_dg, d_scal;
+    DevBuf<vg::SolveDatasetDev> d_dsA, d_dsB;
+    DevBuf<int> d_inv, d_ref_ptr, d_ref_ds, d_ref_blk, d_bad;
+    DevBuf<unsigned char> d_pf;
+    DevBuf<long long> d_pose_param, d_gcol_param;
+    int rc;
+    std::vector<vg::SolveDatasetDev> hdsA(n_ds), hdsB(n_ds);
+    for (int d = 0; d < n_ds; d++) {
+        const size_t n = (size_t)p->dss[d].n_blocks * Wd[d] * Wd[d];
+        if ((rc = gramA[d].alloc(n)) != VG_OK || (rc = gramB[d].alloc(n)) != VG_OK) return rc;
+        hdsA[d] = {gramA[d].p, Wd[d], pose_off[d]};
+        hdsB[d] = {gramB[d].p, Wd[d], pose_off[d]};
+    }
+#define VG_TRY(e) do { if ((rc = (e)) != VG_OK) return rc; } while (0)
+    VG_TRY(d_dsA.upload(hdsA));
+    VG_TRY(d_dsB.upload(hdsB));
+    VG_TRY(d_inv.upload(inv));
+    VG_TRY(d_ref_ptr.upload(ref_ptr));
+    VG_TRY(d_ref_ds.upload(ref_ds));
+    VG_TRY(d_ref_blk.upload(ref_blk));
+    VG_TRY(d_pf.upload(pose_frozen));
+    VG_TRY(d_pose_param.upload(pose_param));
+    VG_TRY(d_gcol_param.upload(gcol_param));
+    VG_TRY(d_lo.upload(lo));
+    VG_TRY(d_hi.upload(hi));
+    VG_TRY(d_sums.alloc((size_t)n_ds * Wmax * Wmax));
+    VG_TRY(d_x.alloc((size_t)n_params));
+    VG_TRY(d_xc.alloc((size_t)n_params));
+    VG_TRY(d_delta.alloc((size_t)n_params));
+    VG_TRY(d_rec.alloc((size_t)n_poses * vg::kPoseRec));
+    VG_TRY(d_rows.alloc((size_t)n_rows * C));
+    VG_TRY(d_rgroups.alloc((size_t)n_groups * C * C));
+    VG_TRY(d_rslabs.alloc((size_t)n_slabs * C * C));
+    VG_TRY(d_rgram.alloc((size_t)C * C));
+    VG_TRY(d_dg.alloc((size_t)(G ? G : 1)));
+    VG_TRY(d_scal.alloc((size_t)n_poses * 5));
+    VG_TRY(d_bad.alloc(1));
+    VG_HIP(hipMemsetAsync(d_delta.p, 0, sizeof(double) * (size_t)(n_params ? n_params : 1), st));
+    VG_HIP(hipMemcpyAsync(d_x.p, p->d_params, sizeof(double) * (size_t)n_params, hipMemcpyDeviceToDevice, st));
+
+    std::vector<double> h_sums((size_t)n_ds * Wmax * Wmax), h_rgram((size_t)C * C), h_scal((size_t)n_poses * 5);
+    std::vector<double> U((size_t)G * G), gg(G), Uc((size_t)G * G), ggc(G), S((size_t)G * G), rhs(G), dg(G), h_x((size_t)n_params);
+
+    // evaluate the Gram matrices at a device parameter buffer into gram set `set`, assemble U / gg / cost
+    auto evaluate = [&](const double *x_dev, DevBuf<double> *set, std::vector<double> &Uo, std::vector<double> &go,
+                        double &cost2) -> int {
+        const double t0 = now_s();
+        int r;
+        if ((r = vgi::prepare_at(p, x_dev)) != VG_OK) return r;
+        for (int d = 0; d < n_ds; d++) {
+            if ((r = vgi::gram_fused_at(p, d, x_dev, set[d].p)) != VG_OK) return r;
+            if ((r = vgi::gram_sum_into(p, d, set[d].p, d_sums.p + (size_t)d * Wmax * Wmax)) != VG_OK) return r;
+        }
+        VG_HIP(hipMemcpyAsync(h_sums.data(), d_sums.p, sizeof(double) * h_sums.size(), hipMemcpyDeviceToHost, st));
+        VG_HIP(hipStreamSynchronize(st));
+        std::fill(Uo.begin(), Uo.end(), 0.);
+        std::fill(go.begin(), go.end(), 0.);
+        cost2 = 0.;
+        for (int d = 0; d < n_ds; d++) {
+            const int W = Wd[d];
+            const double *Sd = h_sums.data() + (size_t)d * Wmax * Wmax;
+            for (int a2 = 0; a2 < W - 1; a2++) {
+                const int ga = lmap[d][a2];
+                if (ga < 0) continue;
+                for (int b2 = 0; b2 < W - 1; b2++) {
+                    const int gb = lmap[d][b2];
+                    if (gb >= 0) Uo[(size_t)ga * G + gb] += Sd[a2 * W + b2];
+                }
+                go[ga] += Sd[a2 * W + W - 1];
+            }
+            cost2 += Sd[W * W - 1];
+        }
+        t_eval += now_s() - t0;
+        return VG_OK;
+    };
+    // sum a packed host buffer over ranks (multi-GPU); identity on one GPU
+    auto allreduce = [&](std::vector<double> &buf) -> int {
+        if (!opt.allreduce) return VG_OK;
+        return opt.allreduce(buf.data(), (int64_t)buf.size(), opt.allreduce_user) == 0
+                   ? VG_OK
+                   : fail(VG_ERR_STATE, "allreduce callback failed");
+    };
+
+    DevBuf<double> *cur = gramA, *cand = gramB;
+    vg::SolveDatasetDev *ds_cur = d_dsA.p, *ds_cand = d_dsB.p;
+    double cost2 = 0., cost2_c = 0.;
+    VG_TRY(evaluate(d_x.p, cur, U, gg, cost2));
+    {
+        std::vector<double> pack(U);
+        pack.insert(pack.end(), gg.begin(), gg.end());
+        pack.push_back(cost2);
+        VG_TRY(allreduce(pack));
+        std::copy(pack.begin(), pack.begin() + (size_t)G * G, U.begin());
+        std::copy(pack.begin() + (size_t)G * G, pack.begin() + (size_t)G * G + G, gg.begin());
+        cost2 = pack.back();
+    }
+    VG_HIP(hipMemcpy(h_x.data(), d_x.p, sizeof(double) * (size_t)n_params, hipMemcpyDeviceToHost));
+
+    double radius = opt.initial_trust_region_radius, decrease_factor = 2.;
+    int iter = 0, n_success = 0, term = VG_TERM_NO_CONVERGENCE;
+    double grad_max = 0.;
+    const double initial_cost = 0.5 * cost2;
+    char msg[160] = "";
+    if (opt.verbose) std::printf("iter      cost      cost_change  |gradient|   |step|    tr_ratio  tr_radius\n%4d  %.6e\n", 0, initial_cost);
+
+    for (iter = 1; iter <= opt.max_num_iterations; iter++) {
+        const double mu = 1. / radius;
+        // ---- eliminate the poses: rows -> Gram -> S_sub, c
+        double t0 = now_s();
+        vg::SchurArgs sa;
+        sa.ds = ds_cur;
+        sa.inv = d_inv.p;
+        sa.ref_ptr = d_ref_ptr.p;
+        sa.ref_ds = d_ref_ds.p;
+        sa.ref_blk = d_ref_blk.p;
+        sa.pose_frozen = d_pf.p;
+        sa.G = G;
+        sa.n_poses = (int)n_poses;
+        sa.mu = mu;
+        sa.dmin = opt.min_lm_diagonal;
+        sa.dmax = opt.max_lm_diagonal;
+        sa.rec = d_rec.p;
+        sa.rows = d_rows.p;
+        sa.bad = d_bad.p;
+        std::fill(h_rgram.begin(), h_rgram.end(), 0.);
+        if (n_poses) {
+            VG_HIP(hipMemsetAsync(d_bad.p, 0, sizeof(int), st));
+            hipLaunchKernelGGL(vg::vg_schur_rows_kernel, dim3((unsigned)((n_poses + 63) / 64)), dim3(64), 0, st, sa);
+            VG_HIP(hipGetLastError());
+            VG_TRY(launch_dense_gram(st, d_rows.p, n_rows, C, rows_per_group, n_groups, d_rgroups.p));
+            hipLaunchKernelGGL(vg::vg_gram_slab_sum_kernel, dim3(n_slabs), dim3(256), 0, st, (const double *)d_rgroups.p,
+                               n_groups, C * C, d_rslabs.p);
+            VG_HIP(hipGetLastError());
+            hipLaunchKernelGGL(vg::vg_gram_final_sum_kernel, dim3((C * C + 3) / 4), dim3(256), 0, st,
+                               (const double *)d_rslabs.p, n_slabs, C * C, d_rgram.p);
+            VG_HIP(hipGetLastError());
+            VG_HIP(hipMemcpyAsync(h_rgram.data(), d_rgram.p, sizeof(double) * h_rgram.size(), hipMemcpyDeviceToHost, st));
+            VG_HIP(hipStreamSynchronize(st));
+        }
+        VG_TRY(allreduce(h_rgram));
+        t_schur += now_s() - t0;
+
+        // ---- reduced system on the host
+        t0 = now_s();
+        for (int a2 = 0; a2 < G; a2++) {
+            for (int b2 = 0; b2 < G; b2++) S[(size_t)a2 * G + b2] = U[(size_t)a2 * G + b2] - h_rgram[(size_t)a2 * C + b2];
+            const double dd = U[(size_t)a2 * G + a2];
+            S[(size_t)a2 * G + a2] += mu * (dd < opt.min_lm_diagonal ? opt.min_lm_diagonal : (dd > opt.max_lm_diagonal ? opt.max_lm_diagonal : dd));
+            rhs[a2] = -gg[a2] + h_rgram[(size_t)a2 * C + G];
+        }
+        for (int a2 = 0; a2 < G; a2++)
+            if (gfrozen[a2]) {
+                for (int b2 = 0; b2 < G; b2++) S[(size_t)a2 * G + b2] = S[(size_t)b2 * G + a2] = 0.;
+                S[(size_t)a2 * G + a2] = 1.;
+                rhs[a2] = 0.;
+            }
+        bool step_ok = G == 0 || chol_solve(G, S.data(), rhs.data(), dg.data());
+        t_host += now_s() - t0;
+
+        double model_change = 0., step2 = 0., cost_change = 0., rho = 0.;
+        if (step_ok) {
+            // ---- back-substitute, apply, evaluate the candidate
+            t0 = now_s();
+            if (G) VG_HIP(hipMemcpyAsync(d_dg.p, dg.data(), sizeof(double) * G, hipMemcpyHostToDevice, st));
+            vg::BacksubArgs ba;
+            ba.s = sa;
+            ba.dg = d_dg.p;
+            ba.pose_param = d_pose_param.p;
+            ba.gcol_param = d_gcol_param.p;
+            ba.delta = d_delta.p;
+            ba.scal = d_scal.p;
+            const int64_t nthr = n_poses > G ? n_poses : G;
+            if (nthr) {
+                hipLaunchKernelGGL(vg::vg_backsub_kernel, dim3((unsigned)((nthr + 63) / 64)), dim3(64), 0, st, ba);
+                VG_HIP(hipGetLastError());
+            }
+            if (n_params) {
+                hipLaunchKernelGGL(vg::vg_apply_step_kernel, dim3((unsigned)((n_params + 255) / 256)), dim3(256), 0, st,
+                                   (const double *)d_x.p, (const double *)d_delta.p, (const double *)d_lo.p,
+                                   (const double *)d_hi.p, (long long)n_params, d_xc.p);
+                VG_HIP(hipGetLastError());
+            }
+            if (n_poses) VG_HIP(hipMemcpyAsync(h_scal.data(), d_scal.p, sizeof(double) * h_scal.size(), hipMemcpyDeviceToHost, st));
+            VG_HIP(hipStreamSynchronize(st));
+            t_schur += now_s() - t0;
+
+            double gdp = 0., ddp = 0., gmax_p = 0., dp2 = 0., gp2 = 0.;
+            for (int64_t i = 0; i < n_poses; i++) {
+                gdp += h_scal[(size_t)i * 5];
+                ddp += h_scal[(size_t)i * 5 + 1];
+                gmax_p = h_scal[(size_t)i * 5 + 2] > gmax_p ? h_scal[(size_t)i * 5 + 2] : gmax_p;
+                dp2 += h_scal[(size_t)i * 5 + 3];
+                gp2 += h_scal[(size_t)i * 5 + 4];
+            }
+            VG_TRY(evaluate(d_xc.p, cand, Uc, ggc, cost2_c));
+            {
+                std::vector<double> pack(Uc);
+                pack.insert(pack.end(), ggc.begin(), ggc.end());
+                pack.push_back(cost2_c);
+                pack.push_back(gdp);
+                pack.push_back(ddp);
+                pack.push_back(dp2);
+                pack.push_back(gp2);
+                VG_TRY(allreduce(pack));
+                size_t o = (size_t)G * G;
+                std::copy(pack.begin(), pack.begin() + o, Uc.begin());
+                std::copy(pack.begin() + o, pack.begin() + o + G, ggc.begin());
+                o += G;
+                cost2_c = pack[o];
+                gdp = pack[o + 1];
+                ddp = pack[o + 2];
+                dp2 = pack[o + 3];
+                gp2 = pack[o + 4];
+                // The callback only sums.  With several ranks every rank must take the same branches, so the
+                // pose part of the gradient max-norm is replaced by its (summable) 2-norm, an upper bound:
+                // the gradient test can only fire later than Ceres' max-norm test, never earlier.
+                if (opt.allreduce) gmax_p = std::sqrt(gp2);
+            }
+            double gdg = 0., ddg = 0., dg2 = 0., gmax_g = 0.;
+            for (int a2 = 0; a2 < G; a2++) {
+                if (gfrozen[a2]) continue;
+                const double dd = U[(size_t)a2 * G + a2];
+                const double dcl = dd < opt.min_lm_diagonal ? opt.min_lm_diagonal : (dd > opt.max_lm_diagonal ? opt.max_lm_diagonal : dd);
+                gdg += gg[a2] * dg[a2];
+                ddg += dcl * dg[a2] * dg[a2];
+                dg2 += dg[a2] * dg[a2];
+                // projected gradient for bounded parameters: |Project(x - g) - x|
+                const double xv = h_x[(size_t)gcol_param[a2]];
+                double xg = xv - gg[a2];
+                const double l2 = lo[(size_t)gcol_param[a2]], h2 = hi[(size_t)gcol_param[a2]];
+                xg = xg < l2 ? l2 : (xg > h2 ? h2 : xg);
+                gmax_g = std::fabs(xg - xv) > gmax_g ? std::fabs(xg - xv) : gmax_g;
+            }
+            grad_max = gmax_g > gmax_p ? gmax_g : gmax_p;
+            // model decrease of the exact LM step: 1/2 delta^T (mu D delta - g)
+            model_change = 0.5 * (mu * (ddg + ddp) - (gdg + gdp));
+            step2 = dg2 + dp2;
+            cost_change = 0.5 * (cost2 - cost2_c);
+            rho = model_change > 0. ? cost_change / model_change : -1.;
+
+            if (grad_max <= opt.gradient_tolerance) {
+                term = VG_TERM_CONVERGENCE_GRADIENT;
+                std::snprintf(msg, sizeof msg, "gradient tolerance reached: max norm %.3e <= %.3e", grad_max, opt.gradient_tolerance);
+                break;
+            }
+            double xn2 = 0.;
+            for (double v : h_x) xn2 += v * v;
+            if (std::sqrt(step2) <= opt.parameter_tolerance * (std::sqrt(xn2) + opt.parameter_tolerance)) {
+                term = VG_TERM_CONVERGENCE_PARAMETER;
+                std::snprintf(msg, sizeof msg, "parameter tolerance reached: |step| %.3e", std::sqrt(step2));
+                break;
+            }
+        }
+        const bool success = step_ok && std::isfinite(cost2_c) && rho > opt.min_relative_decrease;
+        if (opt.verbose)
+            std::printf("%4d  %.6e  %10.3e  %10.3e  %9.3e  %9.3e  %9.3e %s\n", iter, 0.5 * (success ? cost2_c : cost2), cost_change,
+                        grad_max, std::sqrt(step2), rho, radius, success ? "" : "(rejected)");
+        if (success) {
+            n_success++;
+            std::swap(cur, cand);
+            std::swap(ds_cur, ds_cand);
+            std::swap(d_x.p, d_xc.p);
+            U.swap(Uc);
+            gg.swap(ggc);
+            const double prev = cost2;
+            cost2 = cost2_c;
+            VG_HIP(hipMemcpy(h_x.data(), d_x.p, sizeof(double) * (size_t)n_params, hipMemcpyDeviceToHost));
+            const double f = 1. - std::pow(2. * rho - 1., 3);
+            radius = radius / (f > 1. / 3. ? f : 1. / 3.);
+            radius = radius > opt.max_trust_region_radius ? opt.max_trust_region_radius : radius;
+            decrease_factor = 2.;
+            if (std::fabs(prev - cost2) <= opt.function_tolerance * prev) {
+                term = VG_TERM_CONVERGENCE_FUNCTION;
+                std::snprintf(msg, sizeof msg, "function tolerance reached: |cost change| / cost = %.3e",
+                              prev > 0 ? std::fabs(prev - cost2) / prev : 0.);
+                break;
+            }
+        } else {
+            radius /= decrease_factor;
+            decrease_factor *= 2.;
+            if (radius < opt.min_trust_region_radius) {
+                term = VG_TERM_RADIUS_TOO_SMALL;
+                std::snprintf(msg, sizeof msg, "trust region radius below %.1e", opt.min_trust_region_radius);
+                break;
+            }
+        }
+    }
+    if (iter > opt.max_num_iterations) {
+        iter = opt.max_num_iterations;
+        std::snprintf(msg, sizeof msg, "maximum number of iterations reached");
+    }
+    VG_HIP(hipMemcpyAsync(p->d_params, d_x.p, sizeof(double) * (size_t)n_params, hipMemcpyDeviceToDevice, st));
+    VG_HIP(hipStreamSynchronize(st));
+    if (sum) {
+        std::memset(sum, 0, sizeof *sum);
+        sum->initial_cost = initial_cost;
+        sum->final_cost = 0.5 * cost2;
+        sum->num_iterations = iter;
+        sum->num_successful_steps = n_success;
+        sum->termination = term;
+        sum->gradient_max_norm = grad_max;
+        sum->final_radius = radius;
+        sum->total_seconds = now_s() - t_start;
+        sum->evaluate_seconds = t_eval;
+        sum->schur_seconds = t_schur;
+        sum->host_seconds = t_host;
+        sum->num_global_columns = G;
+        sum->num_pose_blocks = n_poses;
+        std::snprintf(sum->message, sizeof sum->message, "%s", msg);
+    }
+#undef VG_TRY
+    return VG_OK;
+}
+
+}  // extern "C"

@@ -234,6 +234,38 @@ class CalibrationProblem:
         capi.check(self._lib.vg_dataset_gram_sum(self._h, d, ctypes.c_void_p(gram.data_ptr()),
                                                  ctypes.c_void_p(out.data_ptr())))
 
+    # -- solve ------------------------------------------------------------------------------
+    def solve(self, allreduce=None, **options):
+        """Levenberg-Marquardt with per-pose Schur elimination; replaces ceres::Solve at
+        unified_calibration.cpp:53.  options: fields of vg_solve_options (defaults = the reference's
+        Solver::Options, unified_calibration.cpp:42-52).  allreduce(np_array) sums a host buffer over ranks in
+        place (multi-GPU).  Returns the summary as a dict; the solution is in get_parameters()."""
+        opt = capi.SolveOptions()
+        self._lib.vg_solve_options_init(ctypes.byref(opt))
+        for k, v in options.items():
+            if not hasattr(opt, k):
+                raise TypeError("unknown solver option %r" % k)
+            setattr(opt, k, v)
+        keep = None
+        if allreduce is not None:
+            def _cb(buf, n, _user):
+                try:
+                    allreduce(np.ctypeslib.as_array(buf, shape=(n,)))
+                    return 0
+                except Exception:  # never let an exception cross the C boundary
+                    import traceback
+
+                    traceback.print_exc()
+                    return 1
+            keep = capi.ALLREDUCE_FN(_cb)
+            opt.allreduce = keep
+        summ = capi.SolveSummary()
+        capi.check(self._lib.vg_problem_solve(self._h, ctypes.byref(opt), ctypes.byref(summ)))
+        out = {name: getattr(summ, name) for name, _ in capi.SolveSummary._fields_}
+        out["message"] = summ.message.decode("utf-8", "replace")
+        out["termination"] = capi.TERMINATION.get(summ.termination, str(summ.termination))
+        return out
+
     def synchronize(self):
         capi.check(self._lib.vg_problem_synchronize(self._h))
 
