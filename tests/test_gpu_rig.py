@@ -1,0 +1,80 @@
+"""BASELINE config 5 as a parity / solve case: mixed UCM / EUCM / EUCM / Mei rig, one shared board, three global
+transforms used INVERSE + one per-frame pose: 45 global columns, Gram widths 12 / 19 / 19 / 23."""
+import numpy as np
+import pytest
+
+from oracle import vgo
+from tests.parity import assert_block_parity
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def vg():
+    import torch
+
+    assert torch.cuda.is_available()
+    import visgeom_amd
+
+    return visgeom_amd
+
+
+def build_rig(vg, r, use_gt=False):
+    p = vg.CalibrationProblem(0)
+    key = "gt_" if use_gt else "init_"
+    cams = [p.add_camera(m, r[key + "intrinsics"][k]) for k, m in enumerate(r["models"])]
+    x1k = [p.add_transform(True, r[key + "xi1k"][k]) for k in range(3)]
+    seq = p.add_transform(False, r[key + "poses"])
+    dss = [p.add_dataset(cams[0], [(seq, 0)], r["board"], r["corners"][0])]
+    for k in range(3):
+        dss.append(p.add_dataset(cams[k + 1], [(x1k[k], 1), (seq, 0)], r["board"], r["corners"][k + 1]))
+    p.finalize()
+    return p, cams, x1k, seq, dss
+
+
+def test_rig_parity_gram_and_solve(vg):
+    from visgeom_amd import synthetic as S
+
+    n = 120
+    r = S.make_rig(n, sigma=0.0)
+    p, cams, x1k, seq, dss = build_rig(vg, r)
+    pv = p.get_parameters()
+    assert p.num_parameters == 5 + 6 + 6 + 10 + 18 + 6 * n
+    # residual / Jacobian parity of every dataset at the perturbed point
+    p.prepare()
+    for k, ds in enumerate(dss):
+        model = r["models"][k]
+        K = len(r["gt_intrinsics"][k])
+        status = [0] if k == 0 else [1, 0]
+        bases = [p.transform_offset(seq, 0)] if k == 0 else [p.transform_offset(x1k[k - 1]), p.transform_offset(seq, 0)]
+        strides = [6] if k == 0 else [0, 6]
+        res, ji, jm = p.alloc_outputs(ds)
+        p.evaluate_dataset(ds, res, ji, jm)
+        p.synchronize()
+        rr, jir, jmr = vgo.eval_dataset(vgo.MODELS[model], status, r["board"], r["corners"][k], pv, p.camera_offset(cams[k]),
+                                        bases, strides, np.arange(n), threads=4)
+        for b in range(0, n, 7):
+            assert_block_parity(res[b].cpu().numpy(), [ji[b].cpu().numpy()] + [m[b].cpu().numpy() for m in jm],
+                                rr[b], [jir[b]] + [m[b] for m in jmr], r["corners"][k][b], "cam %d block %d" % (k, b))
+        # normal-equation blocks of the same dataset
+        gram, gsum = p.alloc_gram(ds)
+        p.gram_fused(ds, gram)
+        p.synchronize()
+        G = gram.cpu().numpy()
+        for b in range(0, n, 11):
+            ref = vgo.block_gram(rr[b], jir[b], [m[b] for m in jmr])
+            assert np.linalg.norm(G[b] - ref) <= 1e-10 * np.linalg.norm(ref)
+    # full LM loop: GPU Gram + Schur, host Cholesky of the 45 x 45 system
+    s = p.solve(max_num_iterations=100)
+    x = p.get_parameters()
+    print("rig", s["termination"], s["num_iterations"], "cost %.3e -> %.3e" % (s["initial_cost"], s["final_cost"]))
+    assert s["num_global_columns"] == 45 and s["num_pose_blocks"] == n
+    assert s["final_cost"] < 1e-12 * s["initial_cost"]
+    for k in range(4):
+        o = p.camera_offset(cams[k])
+        gt = r["gt_intrinsics"][k]
+        assert np.max(np.abs(x[o:o + len(gt)] - gt) / np.maximum(np.abs(gt), 1.0)) < 1e-6, "camera %d" % k
+    for k in range(3):
+        o = p.transform_offset(x1k[k])
+        assert np.max(np.abs(x[o:o + 6] - r["gt_xi1k"][k])) < 1e-6
+    p.close()

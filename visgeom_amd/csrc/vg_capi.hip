@@ -1,6 +1,7 @@
 // vg_capi.hip -- implementation of include/visgeom_amd.h (host side + kernel launches).
 // Built with hipcc for gfx950 only.  No CPU fallback: every compute entry needs a HIP device.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -124,6 +125,7 @@ int launch_gram_fused(hipStream_t stream, const vg::GramArgs &a)
     const size_t tile = (size_t)vg::gram_wave_lds_doubles(a.W, a.frame_stride_d) * sizeof(double);
     int waves = (int)((64 * 1024) / tile);
     waves = waves < 1 ? 1 : (waves > vg::kGramMaxWavesPerBlock ? vg::kGramMaxWavesPerBlock : waves);
+    if (const char *e = getenv("VG_GRAM_WAVES")) waves = atoi(e) > 0 && atoi(e) <= 4 ? atoi(e) : waves;  // tuning knob
     const unsigned int n_pairs = (a.n_blocks + 1) / 2;
     const unsigned int grid = (n_pairs + waves - 1) / waves;
     const size_t lds = (size_t)waves * tile;

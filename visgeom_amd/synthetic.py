@@ -226,3 +226,31 @@ def make_stereo(n_pairs, config_index=3, sigma=0.1):
             "init_intrinsics1": INIT["eucm"].copy(), "init_intrinsics2": INIT["eucm"].copy(),
             "init_xi12": GT_XI_CAM12 + _perturb(seed, 1, 6, salt=1)[0],
             "init_poses": poses + _perturb(seed, n_pairs, 6), "seed": seed}
+
+
+def make_rig(n_frames, config_index=5, sigma=0.1):
+    """Config 5: a forward-facing 2 x 2 rig [UCM, EUCM, EUCM, Mei] with 0.15 m baselines, one board seen by all
+    four cameras.  Global transforms xiCam1k (k = 2..4, used INVERSE, like xiCam12 of the stereo example) and one
+    per-frame xiRigBoard (DIRECT): camera 1 chain [xiRigBoard D], camera k chain [xiCam1k I, xiRigBoard D]."""
+    seed = BASE_SEED + config_index
+    board = board_points()
+    models = ["ucm", "eucm", "eucm", "mei"]
+    gts = [GT_UCM.copy(), GT_EUCM_CAM1.copy(), GT_EUCM_CAM2.copy(), GT_MEI.copy()]
+    xi1k = [np.array([0.15, 0.0, 0.0, 0.004, -0.006, 0.002]),     # pose of camera k in camera 1's frame
+            np.array([0.0, 0.15, 0.0, -0.005, 0.003, -0.004]),
+            np.array([0.15, 0.15, 0.0, 0.002, 0.005, 0.006])]
+    cams = [(models[0], gts[0], np.eye(3), np.zeros(3))]
+    for k in range(3):
+        R = rodrigues(xi1k[k][3:])
+        cams.append((models[k + 1], gts[k + 1], R.T, -R.T @ xi1k[k][:3]))   # X_k = R^T (X_1 - t)
+    poses = make_poses(seed, n_frames, cams, board)
+    X1 = np.einsum("nij,kj->nki", rodrigues(poses[:, 3:]), board) + poses[:, None, :3]
+    corners = []
+    for k, (m, intr, Rc, tc) in enumerate(cams):
+        uv, ok = project(m, intr, np.einsum("ij,nkj->nki", Rc, X1) + tc)
+        assert ok.all()
+        corners.append(uv + _noise(seed + 101 * k, n_frames, board.shape[0], sigma))
+    return {"board": board, "models": models, "corners": corners, "gt_intrinsics": gts,
+            "init_intrinsics": [INIT[m].copy() for m in models], "gt_xi1k": xi1k,
+            "init_xi1k": [x + _perturb(seed, 1, 6, salt=2 + k)[0] for k, x in enumerate(xi1k)],
+            "gt_poses": poses, "init_poses": poses + _perturb(seed, n_frames, 6), "seed": seed}
