@@ -100,7 +100,11 @@ def test_gram_fused_two_pass_and_sum(vg, model, n_images, chain_kind, n_points):
     p.gram_from_rows(ds, res, ji, jm, gram2)
     p.synchronize()
     assert_gram_parity(gram2.cpu().numpy(), Gref, "two-pass")
-    assert torch.equal(gram, gram2), "fused and two-pass contract the same rows in the same order"
+    # same contraction order; the fused kernel evaluates its rows with shared reciprocals and FMA contraction
+    # (a few ulp per entry), the two-pass kernel reads the reference-order rows of the emit kernel
+    G2 = gram2.cpu().numpy()
+    dscale = np.sqrt(np.abs(np.einsum("bii->bi", Gref)))
+    assert np.max(np.abs(G - G2) / np.maximum(dscale[:, :, None] * dscale[:, None, :], 1e-300)) <= 1e-12
     # deterministic reduction over images
     ref_sum = Gref.astype(np.longdouble).sum(axis=0).astype(np.float64)
     S_ = gsum.cpu().numpy()

@@ -12,7 +12,7 @@ LIB_DIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIB_DIR, "libvisgeom_amd.so")
 
 # -ffp-contract=off: keep the per-corner arithmetic in the reference's evaluation order (no FMA
-# fusion), so that GPU and oracle differ only through libm-vs-ocml trig in the chain prep.  The emit
+# fusion), so that GPU and CPU checker differ only through libm-vs-ocml trig in the chain prep.  The emit
 # kernel is HBM bound, the extra VALU instructions are not on the critical path.
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
                "-fno-fast-math", "-Wall", "-Wno-unused-function"]

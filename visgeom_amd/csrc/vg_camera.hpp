@@ -246,6 +246,175 @@ VG_HD void eval_corner(const double *__restrict__ p, double x, double y, double 
     eval_corner<WANT_P, WANT_I>(p, x, y, z, e, std::integral_constant<int, MODEL>{});
 }
 
+// ------------------------------------------------------------------------------------------
+// FAST variants, used only by the compute-bound fused Gram kernel (vg_gram.hpp): the same formulas with FMA
+// contraction allowed and, for EUCM, the twelve IEEE divisions replaced by two shared reciprocals (1/eta, 1/rho).
+// Results differ from the reference-order evaluation above by a few ulp; the rows never leave the CU and the
+// Gram matrices are checked (tests/test_gpu_gram.py) against a long-double Gram of reference-order rows at 1e-10.
+// ------------------------------------------------------------------------------------------
+VG_HD void eval_corner_fast(const double *__restrict__ p, double x, double y, double z, CornerEval<6> &e,
+                            std::integral_constant<int, kEUCM>)
+{
+#pragma clang fp contract(fast)
+    const double alpha = p[0], beta = p[1], fu = p[2], fv = p[3], u0 = p[4], v0 = p[5];
+    const double x2y2 = x * x + y * y;
+    const double rho = sqrt(z * z + beta * x2y2);
+    const double gamma = 1. - alpha;
+    const double eta = alpha * rho + gamma * z;
+    const double ie = 1. / eta, ir = 1. / rho;
+    bool ok = !(eta < 1e-3);
+    if (alpha > 0.5) {
+        const double C = (alpha - 1.) / (alpha + alpha - 1.);
+        if (z * ie < C) ok = false;
+    }
+    e.ok = ok;
+    const double xn = x * ie, yn = y * ie;
+    e.u = fu * xn + u0;
+    e.v = fv * yn + v0;
+    const double k = ie * ie;
+    const double abrho = alpha * beta * ir;
+    const double Jxy = k * abrho * x * y;
+    const double Jz = k * (gamma + alpha * z * ir);
+    const double Jx = gamma * z + alpha * rho;
+    const double m = ok ? 1. : 0.;  // failed projection -> zero rows (eucm.h:141-150,198-206)
+    const double fuk = m * fu * k, fvk = m * fv * k;
+    e.P[0] = fuk * (Jx - abrho * x * x);
+    e.P[1] = -m * fu * Jxy;
+    e.P[2] = -m * fu * x * Jz;
+    e.P[3] = -m * fv * Jxy;
+    e.P[4] = fvk * (Jx - abrho * y * y);
+    e.P[5] = -m * fv * y * Jz;
+    const double db = 0.5 * alpha * x2y2 * k * ir;
+    e.Ju[0] = -fuk * x * (rho - z);
+    e.Ju[1] = -m * fu * x * db;
+    e.Ju[2] = m * xn;
+    e.Ju[3] = 0.;
+    e.Ju[4] = m;
+    e.Ju[5] = 0.;
+    e.Jv[0] = -fvk * y * (rho - z);
+    e.Jv[1] = -m * fv * y * db;
+    e.Jv[2] = 0.;
+    e.Jv[3] = m * yn;
+    e.Jv[4] = 0.;
+    e.Jv[5] = m;
+}
+
+VG_HD void eval_corner_fast(const double *__restrict__ p, double x, double y, double z, CornerEval<5> &e,
+                            std::integral_constant<int, kUCM>)
+{
+#pragma clang fp contract(fast)
+    const double xi = p[0], fu = p[1], fv = p[2], u0 = p[3], v0 = p[4];
+    const double xx = x * x, yy = y * y;
+    const double rho = sqrt(xx + yy + z * z);
+    const double ri = 1. / rho, di = 1. / (xi * rho + z);
+    const double d2 = di * di;
+    const double xn = x * di, yn = y * di;
+    e.ok = true;
+    e.u = fu * xn + u0;
+    e.v = fv * yn + v0;
+    const double den = xi * rho + z, cxy = -xi * x * y * ri * d2, cz = (1. + xi * z * ri) * d2;
+    e.P[0] = fu * (den - xi * xx * ri) * d2;
+    e.P[1] = fu * cxy;
+    e.P[2] = -fu * x * cz;
+    e.P[3] = fv * cxy;
+    e.P[4] = fv * (den - xi * yy * ri) * d2;
+    e.P[5] = -fv * y * cz;
+    e.Ju[0] = -fu * xn * di * rho;
+    e.Ju[1] = xn;
+    e.Ju[2] = 0.;
+    e.Ju[3] = 1.;
+    e.Ju[4] = 0.;
+    e.Jv[0] = -fv * yn * di * rho;
+    e.Jv[1] = 0.;
+    e.Jv[2] = yn;
+    e.Jv[3] = 0.;
+    e.Jv[4] = 1.;
+}
+
+VG_HD void eval_corner_fast(const double *__restrict__ p, double x, double y, double z, CornerEval<10> &e,
+                            std::integral_constant<int, kMEI>)
+{
+#pragma clang fp contract(fast)
+    const double xi = p[0], k1 = p[1], k2 = p[2], k3 = p[3], k4 = p[4], k5 = p[5];
+    const double fu = p[6], fv = p[7], u0 = p[8], v0 = p[9];
+    const double xx = x * x, yy = y * y;
+    const double rho = sqrt(xx + yy + z * z);
+    const double ri = 1. / rho, di = 1. / (xi * rho + z);
+    const double d2 = di * di;
+    const double xn = x * di, yn = y * di;
+    const double xxn = xn * xn, yyn = yn * yn, xyn = xn * yn;
+    const double r2 = xxn + yyn;
+    const double D = 1. + r2 * (k1 + r2 * (k2 + r2 * k3));
+    const double dD = k1 + r2 * (2. * k2 + 3. * k3 * r2);
+    const double deltax = 2. * k4 * xyn + k5 * (r2 + 2. * xxn);
+    const double deltay = 2. * k5 * xyn + k4 * (r2 + 2. * yyn);
+    const double xd = xn * D + deltax, yd = yn * D + deltay;
+    e.ok = true;
+    e.u = fu * xd + u0;
+    e.v = fv * yd + v0;
+    const double den = xi * rho + z, cxy = -xi * x * y * ri * d2, cz = (1. + xi * z * ri) * d2;
+    const double dm0 = (den - xi * xx * ri) * d2, dm2 = -x * cz, dm4 = (den - xi * yy * ri) * d2, dm5 = -y * cz;
+    const double a0 = fu * (D + 2. * xxn * dD + 2. * k4 * yn + 6. * k5 * xn);
+    const double a1 = fu * (2. * xyn * dD + 2. * k4 * xn + 2. * k5 * yn);
+    const double b0 = fv * (2. * xyn * dD + 2. * k5 * yn + 2. * k4 * xn);
+    const double b1 = fv * (D + 2. * yyn * dD + 2. * k5 * xn + 6. * k4 * yn);
+    e.P[0] = a0 * dm0 + a1 * cxy;
+    e.P[1] = a0 * cxy + a1 * dm4;
+    e.P[2] = a0 * dm2 + a1 * dm5;
+    e.P[3] = b0 * dm0 + b1 * cxy;
+    e.P[4] = b0 * cxy + b1 * dm4;
+    e.P[5] = b0 * dm2 + b1 * dm5;
+    const double dxi = -di * rho;  // d(xn)/d(xi) = xn * dxi
+    const double r4 = r2 * r2;
+    e.Ju[0] = (a0 * xn + a1 * yn) * dxi;
+    e.Ju[1] = fu * xn * r2;
+    e.Ju[2] = fu * xn * r4;
+    e.Ju[3] = fu * xn * r4 * r2;
+    e.Ju[4] = 2. * fu * xyn;
+    e.Ju[5] = fu * (r2 + 2. * xxn);
+    e.Ju[6] = xd;
+    e.Ju[7] = 0.;
+    e.Ju[8] = 1.;
+    e.Ju[9] = 0.;
+    e.Jv[0] = (b0 * xn + b1 * yn) * dxi;
+    e.Jv[1] = fv * yn * r2;
+    e.Jv[2] = fv * yn * r4;
+    e.Jv[3] = fv * yn * r4 * r2;
+    e.Jv[4] = fv * (r2 + 2. * yyn);
+    e.Jv[5] = 2. * fv * xyn;
+    e.Jv[6] = 0.;
+    e.Jv[7] = yd;
+    e.Jv[8] = 0.;
+    e.Jv[9] = 1.;
+}
+
+template <int MODEL>
+VG_HD void eval_corner_fast(const double *__restrict__ p, double x, double y, double z,
+                            CornerEval<CameraTraits<MODEL>::K> &e)
+{
+    eval_corner_fast(p, x, y, z, e, std::integral_constant<int, MODEL>{});
+}
+
+// pose rows with FMA contraction (same formula as pose_rows)
+VG_HD void pose_rows_fast(const double *P, double X0, double X1, double X2, const double *fm, double *out)
+{
+#pragma clang fp contract(fast)
+    const double *R12 = fm, *M12 = fm + 9, *t13 = fm + 18;
+    const double a = X0 - t13[0], b = X1 - t13[1], c = X2 - t13[2];
+#pragma unroll
+    for (int row = 0; row < 2; row++) {
+        const double *p = P + 3 * row;
+        double *o = out + 6 * row;
+#pragma unroll
+        for (int j = 0; j < 3; j++) o[j] = p[0] * R12[0 + j] + p[1] * R12[3 + j] + p[2] * R12[6 + j];
+        // (-p) * hat(t3X): [-(p1*c - p2*b), -(p2*a - p0*c), -(p0*b - p1*a)]
+        const double t0 = p[2] * b - p[1] * c, t1 = p[0] * c - p[2] * a, t2 = p[1] * a - p[0] * b;
+#pragma unroll
+        for (int j = 0; j < 3; j++) o[3 + j] = t0 * M12[0 + j] + t1 * M12[3 + j] + t2 * M12[6 + j];
+    }
+}
+
+
 // InterJacobian::dpdxi  jacobian.h:155-171 : the 2x6 pose-Jacobian rows of chain member `fm`
 // (R12[9], M12[9], t13[3]) for a corner with camera-frame point X and projection Jacobian P.
 //   out[0..5] = [P0*R12 | ((-P0)*hat(X - t13))*M12],  out[6..11] likewise with P1.

@@ -120,17 +120,16 @@ void fill_gram_args(const vg_problem *p, const Dataset &d, vg::GramArgs &a, doub
 template <int MODEL>
 int launch_gram_fused(hipStream_t stream, const vg::GramArgs &a)
 {
-    // one LDS tile per wave (= per pair of images); as many waves per workgroup (<= 4) as fit in 64 KiB, so
-    // that at least two workgroups share a CU (160 KiB LDS) and one can contract while the other evaluates
+    const int T = (a.W + 15) / 16;
+    // one LDS tile per wave (= per pair of images); as many waves per workgroup (<= 4) as fit in 80 KiB, so
+    // that two workgroups share a CU (160 KiB LDS) and one can contract while the other evaluates
     const size_t tile = (size_t)vg::gram_wave_lds_doubles(a.W, a.frame_stride_d) * sizeof(double);
-    int waves = (int)((64 * 1024) / tile);
+    int waves = (int)((80 * 1024) / tile);
     waves = waves < 1 ? 1 : (waves > vg::kGramMaxWavesPerBlock ? vg::kGramMaxWavesPerBlock : waves);
-    if (const char *e = getenv("VG_GRAM_WAVES")) waves = atoi(e) > 0 && atoi(e) <= 4 ? atoi(e) : waves;  // tuning knob
     const unsigned int n_pairs = (a.n_blocks + 1) / 2;
     const unsigned int grid = (n_pairs + waves - 1) / waves;
     const size_t lds = (size_t)waves * tile;
     const dim3 blk(waves * vg::kWave);
-    const int T = (a.W + 15) / 16;
     if (T == 1) hipLaunchKernelGGL((vg::vg_gram_fused_kernel<MODEL, 1>), dim3(grid), blk, lds, stream, a);
     else if (T == 2) hipLaunchKernelGGL((vg::vg_gram_fused_kernel<MODEL, 2>), dim3(grid), blk, lds, stream, a);
     else hipLaunchKernelGGL((vg::vg_gram_fused_kernel<MODEL, 3>), dim3(grid), blk, lds, stream, a);

@@ -84,6 +84,7 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+
 // ------------------------------------------------------------------------------------------
 // fused evaluate + Gram.  One wave owns TWO consecutive images, one per 32-lane half, and walks their
 // corners 32 at a time (an 8 x 12 board is 3 full steps, no idle lanes; a 64-wide step would idle a
@@ -142,26 +143,35 @@ __global__ __launch_bounds__(kGramMaxWavesPerBlock *kWave) void vg_gram_fused_ke
         const double X2 = (fr[6] * g0 + fr[7] * g1 + fr[8] * g2) + fr[11];
         const d2 ob = reinterpret_cast<const d2 *>(a.obs)[(size_t)bb * a.N + cc];
         CornerEval<K> e;
-        eval_corner<MODEL, true, true>(a.intr, X0, X1, X2, e);
+        eval_corner_fast<MODEL>(a.intr, X0, X1, X2, e);
+
+        // rows are written unconditionally; lanes without a corner then overwrite theirs with zeros (a branch
+        // no lane takes on full boards) -- cheaper than a select per element
         double *ru = tile + (size_t)(kWave * h + 2 * sl) * W, *rv = ru + W;
 #pragma unroll
         for (int i = 0; i < K; i++) {
-            ru[i] = valid ? e.Ju[i] : 0.;
-            rv[i] = valid ? e.Jv[i] : 0.;
+            ru[i] = e.Ju[i];
+            rv[i] = e.Jv[i];
         }
         for (int l = 0; l < a.L; l++) {
             double rows[12];
-            pose_rows(e.P, X0, X1, X2, fr + 12 + 21 * l, rows);
+            pose_rows_fast(e.P, X0, X1, X2, fr + 12 + 21 * l, rows);
 #pragma unroll
             for (int j = 0; j < 6; j++) {
-                ru[K + 6 * l + j] = valid ? rows[j] : 0.;
-                rv[K + 6 * l + j] = valid ? rows[6 + j] : 0.;
+                ru[K + 6 * l + j] = rows[j];
+                rv[K + 6 * l + j] = rows[6 + j];
             }
         }
         // residual column; a failed projection contributes the in-band 1e15 exactly as it would
         // inside Ceres (calib_cost_functions.cpp:66-70)
-        ru[W - 1] = valid ? (e.ok ? e.u - ob.x : kDoubleBig) : 0.;
-        rv[W - 1] = valid ? (e.ok ? e.v - ob.y : kDoubleBig) : 0.;
+        ru[W - 1] = e.ok ? e.u - ob.x : kDoubleBig;
+        rv[W - 1] = e.ok ? e.v - ob.y : kDoubleBig;
+        if (!valid) {
+            for (int i = 0; i < W; i++) {
+                ru[i] = 0.;
+                rv[i] = 0.;
+            }
+        }
         wave_lds_fence();
 
         // always 16 groups of 4 rows per image: rows of lanes without a corner are zero, so a ragged last
