@@ -228,6 +228,34 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *options, vg_solve_su
  * Returns VG_ERR_NUMERIC when A is not positive definite. */
 int vg_host_cholesky_solve(int n, const double *A, const double *b, double *x);
 
+/* =====================================================================================
+ * 5. Calibration-JSON front end -- class GenericCameraCalibration
+ *    (include/calibration/unified_calibration.h:91-180): same schema (README.md:36-223), same parse order
+ *    (parseTransforms :91-132, parseCameras :134-180, parseData :632-831), same pose initialisation
+ *    (initTransforms :431-512, estimateInitialGrid :1066-1158, getInitTransform :311-348, initGlobalTransform
+ *    :358-429), same report and image_error_<i>.txt formats.  Grid-reprojection datasets only: "ir_data", and
+ *    "images" with pre-extracted corners ("corners_file", same layout as ir_data's "data_file").
+ * ===================================================================================== */
+typedef struct vg_calibration vg_calibration;
+int vg_calibration_create(vg_calibration **out, int device);
+void vg_calibration_destroy(vg_calibration *c);
+/* addResiduals(infoFileName), :350-356.  Parsing runs on the host; initialising a transform ("init" != "none")
+ * refines the poses on the GPU unless the dataset carries the "do_not_solve" flag. */
+int vg_calibration_add_file(vg_calibration *c, const char *json_path);
+/* compute(), :39-89: assemble the problem, solve (options NULL = the reference's Solver::Options, :42-52). */
+int vg_calibration_compute(vg_calibration *c, const vg_solve_options *options, vg_solve_summary *summary);
+/* the text compute() prints (:56-83) / the parse-time messages; return the size needed including the NUL */
+int64_t vg_calibration_report(vg_calibration *c, char *buf, int64_t size);
+int64_t vg_calibration_log(vg_calibration *c, char *buf, int64_t size);
+int vg_calibration_num_datasets(const vg_calibration *c);
+int vg_calibration_get_intrinsics(vg_calibration *c, const char *camera, double *out, int *count);
+int vg_calibration_get_transform(vg_calibration *c, const char *name, int64_t index, double *out6, int64_t *count);
+/* writeImageResidual(dataVec[dataset], path), :1186-1292.  sigma_out: one value per image of the dataset (NULL ok). */
+int vg_calibration_write_residuals(vg_calibration *c, int dataset, const char *path, double *sigma_out,
+                                   int64_t *outliers_out);
+/* transformFromData, include/json.h:36-67: 3 [x,y,theta] / 6 [t,rotvec] / 7 [t,qx,qy,qz,qw] / 12 row-major [R|t] */
+int vg_transform_from_values(int n, const double *values, double *out6);
+
 /* ---- measurement helpers (bench / profiling only): a pure streaming write / copy with the same
  * 16 B-per-lane access pattern as the emit kernel, to calibrate rocprofv3's WRITE_SIZE / FETCH_SIZE
  * and to measure the achievable HBM rate on the box. */

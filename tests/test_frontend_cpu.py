@@ -1,0 +1,115 @@
+"""Host logic of the calibration-JSON front end (no GPU): schema parsing, transform literal formats, the
+reference's parse-time errors.  The numerical part (pose initialisation refinement, solve) is in test_gpu_frontend."""
+import json
+
+import numpy as np
+import pytest
+
+from visgeom_amd import capi, synthetic as S
+from visgeom_amd.calibration import GenericCameraCalibration, transform_from_values
+
+
+def test_transform_literal_formats():
+    """transformFromData, include/json.h:36-67 (README.md:160-173)"""
+    assert np.array_equal(transform_from_values([1.0, 2.0, 0.5]), [1, 2, 0, 0, 0, 0.5])                 # x, y, theta
+    v6 = [0.1, -0.2, 0.3, 0.3, -0.4, 0.1]
+    assert np.array_equal(transform_from_values(v6), v6)                                                  # t, rotvec
+    r = np.array([0.3, -0.4, 0.1])
+    th = np.linalg.norm(r)
+    q = np.concatenate([r / th * np.sin(th / 2), [np.cos(th / 2)]])
+    out = transform_from_values(np.concatenate([[1, 2, 3], q]))                                           # t, quaternion xyzw
+    assert np.allclose(out[:3], [1, 2, 3]) and np.allclose(out[3:], r, atol=1e-15)
+    R = S.rodrigues(r)
+    m = np.concatenate([np.concatenate([R, [[1], [2], [3]]], axis=1).ravel()])                            # row-major [R | t]
+    out = transform_from_values(m)
+    assert np.allclose(out[:3], [1, 2, 3]) and np.allclose(out[3:], r, atol=1e-14)
+    with pytest.raises(capi.VisgeomError) as e:
+        transform_from_values([1, 2, 3, 4])
+    assert "invalid trasformation format" in str(e.value)   # the reference's message, typo included
+
+
+def _write(tmp_path, prior=True, **kw):
+    d = S.make_mono("eucm", 5, 0)
+    return d, S.write_calibration_json(str(tmp_path), d, "eucm", prior=prior, **kw)
+
+
+def test_parse_with_priors_needs_no_gpu(tmp_path):
+    d, path = _write(tmp_path, prior=True, flags=["_check_extraction", "do_not_solve"], skip=(2,))
+    c = GenericCameraCalibration()
+    assert c.addResiduals(path)
+    assert c.num_datasets() == 1
+    assert np.array_equal(c.intrinsics("cam"), d["init_intrinsics"])
+    assert np.array_equal(c.transform("xiCamBoard"), d["init_poses"])
+    log = c.log()
+    assert "Model : EUCM" in log and "Camera : cam" in log and "Transformations : xiCamBoard" in log
+    assert "WARNING : UNKNOWN FLAG -- _check_extraction" in log   # disabled flags are tolerated
+    c.close()
+
+
+def _mutate(path, fn):
+    root = json.load(open(path))
+    fn(root)
+    json.dump(root, open(path, "w"))
+
+
+@pytest.mark.parametrize("what,msg", [
+    ("constant_no_prior", "is constant but there is no prior"),
+    ("bad_model", "invalid camera model name"),
+    ("bad_count", "invalid number of intrinsic parameters"),
+    ("two_sequences", "not one sequences in a transform chain"),
+    ("unknown_type", "is not supported"),
+    ("images_without_corners", "corner detector is out of scope"),
+    ("bad_literal", "invalid trasformation format"),
+    ("init_has_prior", "has a prior value"),
+    ("missing_key", "No such node"),
+])
+def test_parse_errors_mirror_the_reference(tmp_path, what, msg):
+    d, path = _write(tmp_path, prior=True)
+
+    def fn(r):
+        if what == "constant_no_prior":
+            r["transformations"][0].update(prior=False, constant=True)
+        elif what == "bad_model":
+            r["cameras"][0]["type"] = "pinhole"
+        elif what == "bad_count":
+            r["cameras"][0]["value"] = r["cameras"][0]["value"][:5]
+        elif what == "two_sequences":
+            r["transformations"].append({"name": "other", "global": False, "prior": True, "constant": False,
+                                         "value": r["transformations"][0]["value"]})
+            r["data"][0]["transform_chain"].append({"name": "other", "direct": True})
+        elif what == "unknown_type":
+            r["data"][0]["type"] = "odometry"
+        elif what == "images_without_corners":
+            r["data"][0].update(type="images", object={"cols": 12, "rows": 8, "size": 0.1})
+        elif what == "bad_literal":
+            r["transformations"][0]["value"][1] = [1, 2, 3, 4, 5]
+        elif what == "init_has_prior":
+            r["data"][0]["init"] = "xiCamBoard"
+        elif what == "missing_key":
+            del r["cameras"][0]["constant"]
+
+    _mutate(path, fn)
+    c = GenericCameraCalibration()
+    with pytest.raises(capi.VisgeomError) as e:
+        c.addResiduals(path)
+    assert msg in str(e.value)
+    c.close()
+
+
+def test_images_entry_with_corners_file(tmp_path):
+    d = S.make_mono("eucm", 4, 0)
+    path = S.write_calibration_json(str(tmp_path), d, "eucm", prior=True, as_images=True)
+    c = GenericCameraCalibration()
+    c.addResiduals(path)
+    assert c.num_datasets() == 1
+    c.close()
+
+
+def test_cli_is_built_and_prints_usage():
+    import subprocess
+
+    from visgeom_amd import _build
+
+    _build.build()
+    r = subprocess.run([_build.CLI], capture_output=True, text=True)
+    assert r.returncode == 2 and "usage: calib file1.json" in r.stderr

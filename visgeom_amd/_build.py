@@ -26,13 +26,13 @@ def _deps():
     out = []
     for d in (CSRC, os.path.join(ROOT, "include")):
         for f in os.listdir(d):
-            if f.endswith((".hip", ".hpp", ".h")):
+            if f.endswith((".hip", ".hpp", ".h", ".cpp")):
                 out.append(os.path.join(d, f))
     return out
 
 
 def up_to_date():
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(os.path.join(PKG, "bin", "calib")):
         return False
     t = os.path.getmtime(LIB)
     return all(os.path.getmtime(f) <= t for f in _deps())
@@ -49,7 +49,23 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
+    build_cli(verbose)
     return LIB
+
+
+BIN_DIR = os.path.join(PKG, "bin")
+CLI = os.path.join(BIN_DIR, "calib")
+
+
+def build_cli(verbose=False):
+    """the reference's `calib file1.json [file2.json ...]` entry point: a host-only C++ program on the C ABI"""
+    os.makedirs(BIN_DIR, exist_ok=True)
+    cmd = ["g++", "-O2", "-std=c++17", "-Wall", os.path.join(CSRC, "calib_main.cpp"), "-o", CLI,
+           "-L" + LIB_DIR, "-lvisgeom_amd", "-Wl,-rpath," + LIB_DIR, "-Wl,-rpath,/opt/rocm/lib"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return CLI
 
 
 if __name__ == "__main__":

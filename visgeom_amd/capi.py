@@ -94,6 +94,17 @@ SIGNATURES = {
     "vg_solve_options_init": (None, [ctypes.POINTER(SolveOptions)]),
     "vg_problem_solve": (ctypes.c_int, [_vp, ctypes.POINTER(SolveOptions), ctypes.POINTER(SolveSummary)]),
     "vg_host_cholesky_solve": (ctypes.c_int, [ctypes.c_int, _dp, _dp, _dp]),
+    "vg_calibration_create": (ctypes.c_int, [_vpp, ctypes.c_int]),
+    "vg_calibration_destroy": (None, [_vp]),
+    "vg_calibration_add_file": (ctypes.c_int, [_vp, ctypes.c_char_p]),
+    "vg_calibration_compute": (ctypes.c_int, [_vp, ctypes.POINTER(SolveOptions), ctypes.POINTER(SolveSummary)]),
+    "vg_calibration_report": (ctypes.c_int64, [_vp, ctypes.c_char_p, ctypes.c_int64]),
+    "vg_calibration_log": (ctypes.c_int64, [_vp, ctypes.c_char_p, ctypes.c_int64]),
+    "vg_calibration_num_datasets": (ctypes.c_int, [_vp]),
+    "vg_calibration_get_intrinsics": (ctypes.c_int, [_vp, ctypes.c_char_p, _dp, _ip]),
+    "vg_calibration_get_transform": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_int64, _dp, _i64p]),
+    "vg_calibration_write_residuals": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_char_p, _dp, _i64p]),
+    "vg_transform_from_values": (ctypes.c_int, [ctypes.c_int, _dp, _dp]),
     "vg_calib_stream_write": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_double]),
     "vg_calib_stream_copy": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64]),
 }

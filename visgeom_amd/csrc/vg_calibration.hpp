@@ -1,0 +1,834 @@
+// vg_calibration.hpp -- the calibration-JSON front end: the host-side mirror of class GenericCameraCalibration
+// (include/calibration/unified_calibration.h:91-180, src/calibration/unified_calibration.cpp) for problems made of
+// grid-reprojection residual blocks.  Same JSON schema (README.md:36-223), same parse order and error behaviour,
+// same pose-initialisation recipe, same report / image_error_<i>.txt formats; the numerical work (pose refinement,
+// the solve) goes through the C ABI of this library to the GPU.  Included at the end of vg_capi.hip.
+//
+// Differences from the reference, all stated in DESIGN.md section 8:
+//   * "images" datasets need pre-extracted corners ("corners_file", same layout as ir_data's "data_file"): the
+//     corner detector (OpenCV) is out of scope.  "ir_data" is read exactly as the reference reads it.
+//   * odometry / odometry_intrinsic / transformation_prior entries are rejected (other cost functions).
+//   * the per-image and global-transform initial refinements use plain least squares (the reference wraps them
+//     in SoftLOneLoss(25) / SoftLOneLoss(1)); the main solve has no loss function in the reference either (:539-564).
+#pragma once
+
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "vg_internal.hpp"
+#include "vg_json.hpp"
+
+namespace vgcal {
+
+using Array6d = std::array<double, 6>;  // include/std.h:43
+
+// ------------------------------------------------------------------ host-side Transformation<double> pieces
+inline vg::Quat quat_of(const double *rot)
+{
+    const vg::RotTrig g = vg::rot_trig(rot, false, true);
+    return vg::quat_from_rotvec(rot, g);
+}
+
+// Transformation::compose  transformation.h:80-88
+inline Array6d compose(const Array6d &a, const Array6d &b)
+{
+    const vg::Quat q1 = quat_of(a.data() + 3), q2 = quat_of(b.data() + 3);
+    double rt[3];
+    vg::quat_rotate(q1, b.data(), rt);
+    Array6d r;
+    for (int i = 0; i < 3; i++) r[i] = rt[i] + a[i];
+    vg::quat_to_rotvec(vg::quat_mul(q1, q2), r.data() + 3);
+    return r;
+}
+
+// Transformation::inverseCompose  transformation.h:90-99   (a^-1 o b)
+inline Array6d inverse_compose(const Array6d &a, const Array6d &b)
+{
+    const vg::Quat q1 = quat_of(a.data() + 3), q2 = quat_of(b.data() + 3);
+    const vg::Quat q1inv = {-q1.x, -q1.y, -q1.z, q1.w};
+    const double d[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
+    Array6d r;
+    vg::quat_rotate(q1inv, d, r.data());
+    vg::quat_to_rotvec(vg::quat_mul(q1inv, q2), r.data() + 3);
+    return r;
+}
+
+// Transformation::composeInverse  transformation.h:101-110   (a o b^-1)
+inline Array6d compose_inverse(const Array6d &a, const Array6d &b)
+{
+    const vg::Quat q1 = quat_of(a.data() + 3), q2 = quat_of(b.data() + 3);
+    const vg::Quat q2inv = {-q2.x, -q2.y, -q2.z, q2.w};
+    const vg::Quat qres = vg::quat_mul(q1, q2inv);
+    double rt[3];
+    vg::quat_rotate(qres, b.data(), rt);
+    Array6d r;
+    for (int i = 0; i < 3; i++) r[i] = a[i] - rt[i];
+    vg::quat_to_rotvec(qres, r.data() + 3);
+    return r;
+}
+
+// Transformation::inverse  transformation.h:112-119
+inline Array6d inverse(const Array6d &a)
+{
+    const double neg[3] = {-a[3], -a[4], -a[5]};
+    const vg::RotTrig g = vg::rot_trig(a.data() + 3, true, false);
+    double R[9];
+    vg::rotation_matrix(a.data() + 3, -1., g, R);  // rotMatInv
+    Array6d r;
+    for (int i = 0; i < 3; i++) r[i] = -(R[3 * i] * a[0] + R[3 * i + 1] * a[1] + R[3 * i + 2] * a[2]);
+    r[3] = neg[0]; r[4] = neg[1]; r[5] = neg[2];
+    return r;
+}
+
+// rotationVector(R) = Quaternion(R).toRotationVector()   geometry_core.h:120-124, quaternion.h:52-59
+// (assumes 1 + trace(R) > 0, like the reference: SURVEY D10)
+inline void rotvec_from_matrix(const double *R, double *rot)
+{
+    vg::Quat q;
+    q.w = std::sqrt(1.0 + (R[0] + R[4] + R[8])) / 2.0;
+    const double w4 = 4.0 * q.w;
+    q.x = (R[7] - R[5]) / w4;
+    q.y = (R[2] - R[6]) / w4;
+    q.z = (R[3] - R[1]) / w4;
+    vg::quat_to_rotvec(q, rot);
+}
+
+// transformFromData  include/json.h:36-67 : 3 [x,y,theta] / 6 [t,rotvec] / 7 [t,quat xyzw] / 12 row-major [R|t]
+inline bool transform_from_values(const std::vector<double> &v, Array6d &out, std::string &err)
+{
+    if (v.size() == 3) {
+        out = {v[0], v[1], 0, 0, 0, v[2]};
+    } else if (v.size() == 6) {
+        for (int i = 0; i < 6; i++) out[i] = v[i];
+    } else if (v.size() == 7) {
+        out[0] = v[0]; out[1] = v[1]; out[2] = v[2];
+        const vg::Quat q = {v[3], v[4], v[5], v[6]};
+        vg::quat_to_rotvec(q, out.data() + 3);
+    } else if (v.size() == 12) {
+        const double R[9] = {v[0], v[1], v[2], v[4], v[5], v[6], v[8], v[9], v[10]};
+        out[0] = v[3]; out[1] = v[7]; out[2] = v[11];
+        rotvec_from_matrix(R, out.data() + 3);
+    } else {
+        err = "invalid trasformation format. must be 3, 6, or 12 values; " + std::to_string(v.size()) + " are given.";
+        return false;
+    }
+    return true;
+}
+
+// ICamera::reconstructPoint  eucm.h:85-106, ucm.h:81-103, mei.h:90-112
+inline bool reconstruct_point(int model, const double *p, const double *uv, double *X)
+{
+    if (model == VG_MODEL_EUCM) {
+        const double alpha = p[0], beta = p[1], fu = p[2], fv = p[3], u0 = p[4], v0 = p[5];
+        const double xn = (uv[0] - u0) / fu, yn = (uv[1] - v0) / fv;
+        const double u2 = xn * xn + yn * yn;
+        const double gamma = 1. - alpha;
+        const double num = 1. - u2 * alpha * alpha * beta;
+        const double det = 1 - (alpha - gamma) * beta * u2;
+        if (det < 0) return false;
+        const double denom = gamma + alpha * std::sqrt(det);
+        X[0] = xn; X[1] = yn; X[2] = num / denom;
+        return true;
+    }
+    const double xi = p[0];
+    const double fu = model == VG_MODEL_UCM ? p[1] : p[6], fv = model == VG_MODEL_UCM ? p[2] : p[7];
+    const double u0 = model == VG_MODEL_UCM ? p[3] : p[8], v0 = model == VG_MODEL_UCM ? p[4] : p[9];
+    const double xn = (uv[0] - u0) / fu, yn = (uv[1] - v0) / fv;
+    const double u2 = xn * xn + yn * yn;
+    const double gamma = std::sqrt(1. + u2 * (1 - xi * xi));
+    const double etanum = -gamma - xi * u2;
+    const double etadenom = xi * xi * u2 - 1;
+    X[0] = xn; X[1] = yn; X[2] = etadenom / (etadenom + xi * etanum);
+    return true;
+}
+
+struct TransformInfo {  // unified_calibration.h:38-44
+    bool global = true, prior = false, constant = false, initialized = false;
+};
+
+struct ImageData {  // unified_calibration.h:46-87 (the fields the grid residuals need)
+    std::string cameraName;
+    std::vector<std::string> transNameVec;
+    std::vector<int> transStatusVec;
+    bool doNotSolve = false, doNotSolveGlobal = false;
+    std::vector<std::string> unknownFlags;
+    std::vector<std::array<double, 3>> board;
+    int Nx = 0, Ny = 0, idxUL = 0, idxUR = 0, idxBL = 0, idxBR = 0;
+    double sqSize = -1;
+    int imageWidth = 0, imageHeight = 0;
+    std::vector<std::vector<double>> detectedCornersVec;  // per image: 2N doubles or empty
+    int getFirstExtractedIdx() const
+    {
+        size_t i = 0;
+        while (i < detectedCornersVec.size() && detectedCornersVec[i].empty()) i++;
+        return (int)i;
+    }
+};
+
+// Eigen's default stream format of a row vector: "%g"-style 6 significant digits, coefficients right-aligned to
+// the widest one, separated by one space
+inline std::string fmt_vec(const double *v, int n)
+{
+    std::vector<std::string> s(n);
+    size_t w = 0;
+    for (int i = 0; i < n; i++) {
+        std::ostringstream o;
+        o << v[i];
+        s[i] = o.str();
+        w = s[i].size() > w ? s[i].size() : w;
+    }
+    std::string out;
+    for (int i = 0; i < n; i++) {
+        if (i) out += " ";
+        out += std::string(w - s[i].size(), ' ') + s[i];
+    }
+    return out;
+}
+
+inline std::string fmt_transf(const Array6d &x)  // operator<<(Transformation), transformation.h:141-145
+{
+    return fmt_vec(x.data(), 3) + " " + fmt_vec(x.data() + 3, 3);
+}
+
+}  // namespace vgcal
+
+struct vg_calibration {
+    int device = 0;
+    std::map<std::string, vgcal::TransformInfo> transformInfoMap;
+    std::map<std::string, vgcal::Array6d> globalTransformMap;
+    std::map<std::string, std::vector<vgcal::Array6d>> sequenceTransformMap;
+    std::map<std::string, std::vector<bool>> sequenceInitMap;
+    std::map<std::string, std::vector<double>> intrinsicMap;
+    std::map<std::string, int> cameraModelMap;
+    std::map<std::string, bool> cameraConstantMap;
+    std::vector<vgcal::ImageData> dataVec;
+    std::string log;  // what the reference prints to stdout while parsing / solving
+
+    vgcal::Array6d &getTransformData(const std::string &name, int idx)  // unified_calibration.h:161-165
+    {
+        if (transformInfoMap[name].global) return globalTransformMap[name];
+        return sequenceTransformMap[name][(size_t)idx];
+    }
+};
+
+namespace vgcal {
+
+struct Error {
+    int code;
+    std::string msg;
+};
+
+// One sub-problem on the GPU through the public C ABI: the dataset's chain with a chosen set of constant blocks.
+// Used for the two initial refinements (estimateInitialGrid :1137-1155 and initGlobalTransform :358-429).
+inline void refine_on_gpu(vg_calibration *c, const ImageData &data, const std::vector<int> &images,
+                          const std::vector<std::string> &chain_names, const std::vector<int> &chain_status,
+                          const std::vector<std::vector<Array6d> *> &chain_values,  // per member: pointer to values
+                          const std::vector<bool> &chain_is_seq, const std::vector<bool> &chain_const, int max_iter)
+{
+    vg_problem *p = nullptr;
+    auto chk = [&](int rc) {
+        if (rc != VG_OK) {
+            const std::string m = vg_last_error();
+            if (p) vg_problem_destroy(p);
+            throw Error{rc, m};
+        }
+    };
+    chk(vg_problem_create(&p, c->device, nullptr));
+    int cam = -1;
+    chk(vg_problem_add_camera(p, c->cameraModelMap[data.cameraName], c->intrinsicMap[data.cameraName].data(), 1, &cam));
+    std::vector<int> tids(chain_names.size());
+    const int N = (int)data.board.size();
+    for (size_t l = 0; l < chain_names.size(); l++) {
+        std::vector<double> vals;
+        if (chain_is_seq[l]) {
+            for (int img : images)
+                for (int k = 0; k < 6; k++) vals.push_back((*chain_values[l])[(size_t)img][k]);
+            chk(vg_problem_add_transform(p, 0, chain_const[l], (int)images.size(), vals.data(), &tids[l]));
+        } else {
+            for (int k = 0; k < 6; k++) vals.push_back((*chain_values[l])[0][k]);
+            chk(vg_problem_add_transform(p, 1, chain_const[l], 1, vals.data(), &tids[l]));
+        }
+    }
+    std::vector<double> board, corners;
+    for (auto &pt : data.board) board.insert(board.end(), pt.begin(), pt.end());
+    for (int img : images) corners.insert(corners.end(), data.detectedCornersVec[(size_t)img].begin(), data.detectedCornersVec[(size_t)img].end());
+    int ds = -1;
+    chk(vg_problem_add_dataset(p, cam, (int)chain_names.size(), tids.data(), chain_status.data(), N, board.data(),
+                               (int64_t)images.size(), nullptr, corners.data(), &ds));
+    chk(vg_problem_finalize(p));
+    vg_solve_options o;
+    vg_solve_options_init(&o);
+    o.max_num_iterations = max_iter;
+    // Ceres' own defaults for these sub-solves (the reference only sets max_num_iterations = 500)
+    o.function_tolerance = 1e-6;
+    o.gradient_tolerance = 1e-10;
+    o.parameter_tolerance = 1e-8;
+    vg_solve_summary s;
+    chk(vg_problem_solve(p, &o, &s));
+    std::vector<double> x((size_t)vg_problem_num_parameters(p));
+    chk(vg_problem_get_parameters(p, x.data()));
+    for (size_t l = 0; l < chain_names.size(); l++) {
+        if (chain_const[l]) continue;
+        if (chain_is_seq[l]) {
+            for (size_t i = 0; i < images.size(); i++) {
+                const int64_t off = vg_problem_transform_offset(p, tids[l], (int64_t)i);
+                for (int k = 0; k < 6; k++) (*chain_values[l])[(size_t)images[i]][k] = x[(size_t)off + k];
+            }
+        } else {
+            const int64_t off = vg_problem_transform_offset(p, tids[l], 0);
+            for (int k = 0; k < 6; k++) (*chain_values[l])[0][k] = x[(size_t)off + k];
+        }
+    }
+    vg_problem_destroy(p);
+}
+
+// geometric part of estimateInitialGrid  unified_calibration.cpp:1066-1135
+inline Array6d estimate_initial_grid_geometric(vg_calibration *c, const ImageData &data, int gridIdx)
+{
+    const std::vector<double> &cv = data.detectedCornersVec[(size_t)gridIdx];
+    const int model = c->cameraModelMap[data.cameraName];
+    const double *intr = c->intrinsicMap[data.cameraName].data();
+    auto recon = [&](int idx, double *X) {
+        reconstruct_point(model, intr, &cv[2 * (size_t)idx], X);
+        const double n = std::sqrt(X[0] * X[0] + X[1] * X[1] + X[2] * X[2]);
+        for (int k = 0; k < 3; k++) X[k] /= n;
+    };
+    double XUL[3], XUR[3], XBL[3], XBR[3];
+    recon(data.idxUL, XUL);
+    recon(data.idxUR, XUR);
+    recon(data.idxBL, XBL);
+    recon(data.idxBR, XBR);
+    auto dist3 = [](const double *a, const double *b) {
+        return std::sqrt((a[0] - b[0]) * (a[0] - b[0]) + (a[1] - b[1]) * (a[1] - b[1]) + (a[2] - b[2]) * (a[2] - b[2]));
+    };
+    const double *bUL = data.board[(size_t)data.idxUL].data(), *bUR = data.board[(size_t)data.idxUR].data();
+    const double *bBL = data.board[(size_t)data.idxBL].data(), *bBR = data.board[(size_t)data.idxBR].data();
+    const double scaleXU = dist3(bUR, bUL) / dist3(XUR, XUL);
+    const double scaleXB = dist3(bBR, bBL) / dist3(XBR, XBL);
+    const double scaleYL = dist3(bBL, bUL) / dist3(XBL, XUL);
+    const double scaleYR = dist3(bBR, bUR) / dist3(XBR, XUR);
+    Array6d xi = {0, 0, 1, 0, 0, 0};
+    double pos[3], posx[3], posy[3], ex[3], ey[3], ez[3];
+    for (int k = 0; k < 3; k++) {
+        pos[k] = XUL[k] * std::min(scaleXU, scaleYL);
+        posx[k] = XUR[k] * std::min(scaleXU, scaleYR);
+        posy[k] = XBL[k] * std::min(scaleXB, scaleYL);
+        xi[k] = pos[k];
+        ex[k] = posx[k] - pos[k];
+        ey[k] = posy[k] - pos[k];
+    }
+    double n = std::sqrt(ex[0] * ex[0] + ex[1] * ex[1] + ex[2] * ex[2]);
+    for (int k = 0; k < 3; k++) ex[k] /= n;
+    const double d = ex[0] * ey[0] + ex[1] * ey[1] + ex[2] * ey[2];  // ey = (I - ex ex^T) ey
+    for (int k = 0; k < 3; k++) ey[k] -= ex[k] * d;
+    n = std::sqrt(ey[0] * ey[0] + ey[1] * ey[1] + ey[2] * ey[2]);
+    for (int k = 0; k < 3; k++) ey[k] /= n;
+    ez[0] = ex[1] * ey[2] - ex[2] * ey[1];
+    ez[1] = ex[2] * ey[0] - ex[0] * ey[2];
+    ez[2] = ex[0] * ey[1] - ex[1] * ey[0];
+    const double R[9] = {ex[0], ey[0], ez[0], ex[1], ey[1], ez[1], ex[2], ey[2], ez[2]};  // R << ex, ey, ez (columns)
+    rotvec_from_matrix(R, xi.data() + 3);
+    return xi;
+}
+
+// getInitTransform  unified_calibration.cpp:311-348 : peel the other chain members off the camera-frame pose
+inline Array6d get_init_transform(vg_calibration *c, Array6d xi, const std::string &initName, const ImageData &data,
+                                  int transfIdx)
+{
+    for (size_t i = 0; i < data.transNameVec.size(); i++) {
+        const std::string &name = data.transNameVec[i];
+        if (name == initName) break;
+        else if (data.transStatusVec[i] == VG_TRANSFORM_DIRECT) xi = inverse_compose(c->getTransformData(name, transfIdx), xi);
+        else xi = compose(c->getTransformData(name, transfIdx), xi);
+    }
+    for (int i = (int)data.transNameVec.size() - 1; i >= 0; i--) {
+        const std::string &name = data.transNameVec[(size_t)i];
+        if (name == initName) {
+            if (data.transStatusVec[(size_t)i] == VG_TRANSFORM_INVERSE) xi = inverse(xi);
+            break;
+        } else if (data.transStatusVec[(size_t)i] == VG_TRANSFORM_DIRECT) xi = compose_inverse(xi, c->getTransformData(name, transfIdx));
+        else xi = compose(xi, c->getTransformData(name, transfIdx));
+    }
+    return xi;
+}
+
+// estimateInitialGrid for a set of images at once: geometric estimate, then (unless do_not_solve) ONE batched
+// refinement of all camera-frame poses with the intrinsics held constant (the reference runs one tiny Ceres
+// problem per image, :1137-1155 -- 10 k sequential solves at the benchmark scale)
+inline std::vector<Array6d> estimate_initial_grids(vg_calibration *c, const ImageData &data, const std::vector<int> &images)
+{
+    std::vector<Array6d> cam_pose(data.detectedCornersVec.size(), Array6d{0, 0, 1, 0, 0, 0});
+    for (int img : images) cam_pose[(size_t)img] = estimate_initial_grid_geometric(c, data, img);
+    if (!data.doNotSolve && !images.empty())
+        refine_on_gpu(c, data, images, {"__camera_frame__"}, {VG_TRANSFORM_DIRECT}, {&cam_pose}, {true}, {false}, 500);
+    return cam_pose;
+}
+
+// initTransforms  unified_calibration.cpp:431-512
+inline void init_transforms(vg_calibration *c, ImageData &data, const std::string &initName)
+{
+    if (initName == "none") return;
+    if (c->transformInfoMap.find(initName) == c->transformInfoMap.end())
+        throw Error{VG_ERR_INVALID_ARGUMENT, initName + " does not exist, impossible to initialize"};
+    if (std::find(data.transNameVec.begin(), data.transNameVec.end(), initName) == data.transNameVec.end())
+        throw Error{VG_ERR_INVALID_ARGUMENT, initName + " does not belong to the transform chain"};
+    if (c->transformInfoMap[initName].prior) throw Error{VG_ERR_INVALID_ARGUMENT, initName + " has a prior value"};
+    c->transformInfoMap[initName].initialized = true;
+    for (auto &x : data.transNameVec)
+        if (!(c->transformInfoMap[x].prior ^ c->transformInfoMap[x].initialized))
+            throw Error{VG_ERR_INVALID_ARGUMENT, x + " is not initialized. Cannot initialize more than one transform at a time"};
+
+    if (!c->transformInfoMap[initName].global) {
+        auto &seq = c->sequenceTransformMap[initName];
+        auto &done = c->sequenceInitMap[initName];
+        const bool IS_ALLOCATED = !seq.empty();
+        std::vector<int> todo;
+        for (size_t transfIdx = 0; transfIdx < data.detectedCornersVec.size(); transfIdx++) {
+            if (!IS_ALLOCATED) {
+                seq.push_back(Array6d{0, 0, 1, 0, 0, 0});
+                done.push_back(false);
+            }
+            if (transfIdx < seq.size() && !data.detectedCornersVec[transfIdx].empty() && !done[transfIdx]) todo.push_back((int)transfIdx);
+        }
+        const std::vector<Array6d> cam_pose = estimate_initial_grids(c, data, todo);
+        for (int transfIdx : todo) {
+            seq[(size_t)transfIdx] = get_init_transform(c, cam_pose[(size_t)transfIdx], initName, data, transfIdx);
+            done[(size_t)transfIdx] = true;
+        }
+    } else {
+        const int transfIdx = data.getFirstExtractedIdx();
+        if (transfIdx >= (int)data.detectedCornersVec.size())
+            throw Error{VG_ERR_INVALID_ARGUMENT, "no extracted grid to initialize " + initName};
+        const std::vector<Array6d> cam_pose = estimate_initial_grids(c, data, {transfIdx});
+        c->log += "INITI VALUE IN CAMERA FRAME \n" + fmt_transf(cam_pose[(size_t)transfIdx]) + "\n";
+        const Array6d xi = get_init_transform(c, cam_pose[(size_t)transfIdx], initName, data, transfIdx);
+        c->log += "INITI TRANSFORM \n" + fmt_transf(xi) + "\n";
+        c->globalTransformMap[initName] = xi;
+        if (data.detectedCornersVec.size() > 1 && !data.doNotSolve) {
+            // initGlobalTransform :358-429: all images, everything constant except `initName`
+            std::vector<int> images;
+            for (size_t i = 0; i < data.detectedCornersVec.size(); i++)
+                if (!data.detectedCornersVec[i].empty()) images.push_back((int)i);
+            std::vector<std::vector<Array6d>> glob_store(data.transNameVec.size());
+            std::vector<std::vector<Array6d> *> vals;
+            std::vector<bool> is_seq, is_const;
+            for (size_t l = 0; l < data.transNameVec.size(); l++) {
+                const std::string &nm = data.transNameVec[l];
+                const bool seq = !c->transformInfoMap[nm].global;
+                is_seq.push_back(seq);
+                is_const.push_back(nm != initName);
+                if (seq) vals.push_back(&c->sequenceTransformMap[nm]);
+                else {
+                    glob_store[l] = {c->globalTransformMap[nm]};
+                    vals.push_back(&glob_store[l]);
+                }
+            }
+            refine_on_gpu(c, data, images, data.transNameVec, data.transStatusVec, vals, is_seq, is_const, 500);
+            for (size_t l = 0; l < data.transNameVec.size(); l++)
+                if (data.transNameVec[l] == initName) c->globalTransformMap[initName] = glob_store[l][0];
+        }
+    }
+}
+
+inline void parse_transforms(vg_calibration *c, const vgjson::Value &root)  // :91-132
+{
+    for (auto &ti : root.at("transformations").arr) {
+        const std::string name = ti.at("name").as_string();
+        c->transformInfoMap[name] = TransformInfo();
+        auto &info = c->transformInfoMap[name];
+        info.global = ti.at("global").as_bool();
+        info.prior = ti.at("prior").as_bool();
+        info.constant = ti.at("constant").as_bool();
+        if (info.constant && !info.prior) throw Error{VG_ERR_INVALID_ARGUMENT, name + " is constant but there is no prior"};
+        info.initialized = false;
+        std::string err;
+        if (info.global) {
+            c->globalTransformMap[name] = Array6d{0, 0, 0, 0, 0, 0};
+            if (info.prior && !transform_from_values(ti.at("value").as_vector(), c->globalTransformMap[name], err))
+                throw Error{VG_ERR_INVALID_ARGUMENT, err};
+        } else {
+            c->sequenceTransformMap[name] = std::vector<Array6d>();
+            c->sequenceInitMap[name] = std::vector<bool>();
+            if (info.prior)
+                for (auto &val : ti.at("value").arr) {
+                    Array6d x;
+                    if (!transform_from_values(val.as_vector(), x, err)) throw Error{VG_ERR_INVALID_ARGUMENT, err};
+                    c->sequenceTransformMap[name].push_back(x);
+                }
+        }
+    }
+}
+
+inline void parse_cameras(vg_calibration *c, const vgjson::Value &root)  // :134-180
+{
+    for (auto &ci : root.at("cameras").arr) {
+        const std::string name = ci.at("name").as_string();
+        c->cameraConstantMap[name] = ci.at("constant").as_bool();
+        c->intrinsicMap[name] = ci.at("value").as_vector();
+        const std::string type = ci.at("type").as_string();
+        int model = -1;
+        if (type == "eucm") { c->log += "Model : EUCM\n"; model = VG_MODEL_EUCM; }
+        else if (type == "ucm") { c->log += "Model : UCM\n"; model = VG_MODEL_UCM; }
+        else if (type == "mei") { c->log += "Model : MEI\n"; model = VG_MODEL_MEI; }
+        else throw Error{VG_ERR_INVALID_ARGUMENT, "invalid camera model name"};
+        if ((int)c->intrinsicMap[name].size() != vg::num_intrinsics(model))
+            throw Error{VG_ERR_INVALID_ARGUMENT, "invalid number of intrinsic parameters"};
+        c->cameraModelMap[name] = model;
+    }
+}
+
+inline void init_chain_info(vg_calibration *c, ImageData &data, const vgjson::Value &node)  // :182-231
+{
+    data.cameraName = node.at("camera").as_string();
+    if (c->intrinsicMap.find(data.cameraName) == c->intrinsicMap.end())
+        throw Error{VG_ERR_INVALID_ARGUMENT, "unknown camera " + data.cameraName};
+    for (auto &flag : node.at("parameters").arr) {
+        const std::string f = flag.as_string();
+        if (f == "do_not_solve") data.doNotSolve = true;
+        else if (f == "do_not_solve_global") data.doNotSolveGlobal = true;
+        else if (f == "check_extraction" || f == "improve_detection" || f == "show_outliers" || f == "user_guided" ||
+                 f == "save_outlire_images" || f == "draw_improved") {
+            // detector / GUI flags: nothing to do without images
+        } else {
+            c->log += "WARNING : UNKNOWN FLAG -- " + f + "\n";  // :200-203, tolerated
+            data.unknownFlags.push_back(f);
+        }
+    }
+    c->log += "Camera : " + data.cameraName + "\nTransformations : ";
+    for (auto &ti : node.at("transform_chain").arr) {
+        data.transNameVec.push_back(ti.at("name").as_string());
+        c->log += data.transNameVec.back();
+        if (c->transformInfoMap.find(data.transNameVec.back()) == c->transformInfoMap.end())
+            throw Error{VG_ERR_INVALID_ARGUMENT, "unknown transformation " + data.transNameVec.back()};
+        if (ti.at("direct").as_bool()) data.transStatusVec.push_back(VG_TRANSFORM_DIRECT);
+        else {
+            data.transStatusVec.push_back(VG_TRANSFORM_INVERSE);
+            c->log += "_inv";
+        }
+        c->log += "   ";
+    }
+    int sequenceCount = 0;
+    for (auto &name : data.transNameVec)
+        if (!c->transformInfoMap[name].global) sequenceCount++;
+    if (sequenceCount != 1) throw Error{VG_ERR_INVALID_ARGUMENT, "not one sequences in a transform chain"};  // :223-228
+    if (data.transNameVec.size() > VG_MAX_CHAIN)
+        throw Error{VG_ERR_INVALID_ARGUMENT, "the transform chain is too long (5 transforms at max are supproted)"};  // :566-567
+    c->log += "\n";
+}
+
+// readCorners :252-277 : a JSON array of frames, each an array of {camera, points}
+inline void read_corners(ImageData &data, const std::string &file, const std::string &cameraID)
+{
+    const vgjson::Value df = vgjson::parse_file(file);
+    for (auto &frame : df.arr) {
+        data.detectedCornersVec.emplace_back();
+        auto &cv = data.detectedCornersVec.back();
+        for (auto &x : frame.arr)
+            if (x.at("camera").as_string() == cameraID) {
+                for (auto &y : x.at("points").arr) {
+                    const std::vector<double> pt = y.as_vector();
+                    cv.push_back(pt.at(0));
+                    cv.push_back(pt.at(1));
+                }
+                break;
+            }
+        // a non-empty list must have exactly one entry per board point
+        if (!cv.empty() && cv.size() != 2 * data.board.size())
+            throw Error{VG_ERR_INVALID_ARGUMENT, "a frame has " + std::to_string(cv.size() / 2) + " corners, the board has " +
+                                                     std::to_string(data.board.size())};
+    }
+}
+
+inline std::string dirname_of(const std::string &path)
+{
+    const size_t s = path.find_last_of('/');
+    return s == std::string::npos ? std::string() : path.substr(0, s + 1);
+}
+
+inline void parse_data(vg_calibration *c, const vgjson::Value &root, const std::string &base_dir)  // :632-831
+{
+    for (auto &di : root.at("data").arr) {
+        const std::string type = di.at("type").as_string();
+        if (type == "images" || type == "ir_data") {
+            c->dataVec.emplace_back();
+            ImageData &data = c->dataVec.back();
+            init_chain_info(c, data, di);
+            std::string file;
+            if (type == "ir_data") {  // initGridIR :234-250
+                data.Nx = data.Ny = 2;
+                data.idxUL = (int)di.at("object.corner_ul").as_number();
+                data.idxUR = (int)di.at("object.corner_ur").as_number();
+                data.idxBL = (int)di.at("object.corner_bl").as_number();
+                data.idxBR = (int)di.at("object.corner_br").as_number();
+                for (auto &x : di.at("object.points").arr) {
+                    const std::vector<double> pt = x.as_vector();
+                    data.board.push_back({pt.at(0), pt.at(1), pt.at(2)});
+                }
+                data.imageWidth = (int)di.at("image_width").as_number();
+                data.imageHeight = (int)di.at("image_height").as_number();
+                file = di.at("data_file").as_string();
+            } else {  // initGrid :279-309, corners from a file instead of the detector
+                data.Nx = (int)di.at("object.cols").as_number();
+                data.Ny = (int)di.at("object.rows").as_number();
+                data.sqSize = di.at("object.size").as_number();
+                for (int i = 0; i < data.Ny; i++)
+                    for (int j = 0; j < data.Nx; j++) data.board.push_back({data.sqSize * j, data.sqSize * i, 0.});
+                data.idxUL = 0;
+                data.idxUR = data.Nx - 1;
+                data.idxBL = data.Nx * (data.Ny - 1);
+                data.idxBR = data.Nx * data.Ny - 1;
+                if (!di.has("corners_file"))
+                    throw Error{VG_ERR_INVALID_ARGUMENT,
+                                "\"images\" datasets need pre-extracted corners (\"corners_file\"): the corner detector is out of scope"};
+                file = di.at("corners_file").as_string();
+            }
+            const int nb = (int)data.board.size();
+            for (int idx : {data.idxUL, data.idxUR, data.idxBL, data.idxBR})
+                if (idx < 0 || idx >= nb) throw Error{VG_ERR_INVALID_ARGUMENT, "board corner index out of range"};
+            if (!file.empty() && file[0] != '/') file = base_dir + file;
+            read_corners(data, file, data.cameraName);
+            init_transforms(c, data, di.at("init").as_string());
+            // addGridResidualBlocks (:514-630) happens when the GPU problem is assembled, in compute()
+        } else {
+            throw Error{VG_ERR_INVALID_ARGUMENT, "data type \"" + type + "\" is not supported (grid reprojection residuals only)"};
+        }
+    }
+}
+
+}  // namespace vgcal
+
+extern "C" {
+
+int vg_transform_from_values(int n, const double *values, double *out6)
+{
+    if (n < 0 || !values || !out6) return vgi::fail(VG_ERR_INVALID_ARGUMENT, "NULL argument");
+    vgcal::Array6d x;
+    std::string err;
+    if (!vgcal::transform_from_values(std::vector<double>(values, values + n), x, err)) return vgi::fail(VG_ERR_INVALID_ARGUMENT, err);
+    std::memcpy(out6, x.data(), sizeof(double) * 6);
+    return VG_OK;
+}
+
+int vg_calibration_create(vg_calibration **out, int device)
+{
+    if (!out) return vgi::fail(VG_ERR_INVALID_ARGUMENT, "out is NULL");
+    *out = new (std::nothrow) vg_calibration();
+    if (!*out) return vgi::fail(VG_ERR_ALLOC, "out of host memory");
+    (*out)->device = device;
+    return VG_OK;
+}
+
+void vg_calibration_destroy(vg_calibration *c) { delete c; }
+
+int vg_calibration_add_file(vg_calibration *c, const char *json_path)  // addResiduals :350-356
+{
+    if (!c || !json_path) return vgi::fail(VG_ERR_INVALID_ARGUMENT, "NULL argument");
+    try {
+        const vgjson::Value root = vgjson::parse_file(json_path);
+        vgcal::parse_transforms(c, root);
+        vgcal::parse_cameras(c, root);
+        vgcal::parse_data(c, root, vgcal::dirname_of(json_path));
+    } catch (const vgcal::Error &e) {
+        return vgi::fail(e.code, e.msg);
+    } catch (const std::exception &e) {
+        return vgi::fail(VG_ERR_INVALID_ARGUMENT, e.what());
+    }
+    return VG_OK;
+}
+
+int vg_calibration_compute(vg_calibration *c, const vg_solve_options *options, vg_solve_summary *summary)  // compute :39-89
+{
+    if (!c) return vgi::fail(VG_ERR_INVALID_ARGUMENT, "calibration is NULL");
+    vg_problem *p = nullptr;
+    int rc = vg_problem_create(&p, c->device, nullptr);
+    if (rc != VG_OK) return rc;
+    auto bail = [&](int code) {
+        vg_problem_destroy(p);
+        return code;
+    };
+    std::map<std::string, int> camId, tfId;
+    for (auto &x : c->intrinsicMap)
+        if ((rc = vg_problem_add_camera(p, c->cameraModelMap[x.first], x.second.data(), c->cameraConstantMap[x.first], &camId[x.first])) != VG_OK)
+            return bail(rc);
+    for (auto &x : c->transformInfoMap) {
+        const std::string &name = x.first;
+        if (x.second.global) {
+            rc = vg_problem_add_transform(p, 1, x.second.constant, 1, c->globalTransformMap[name].data(), &tfId[name]);
+        } else {
+            std::vector<double> vals;
+            for (auto &v : c->sequenceTransformMap[name]) vals.insert(vals.end(), v.begin(), v.end());
+            rc = vg_problem_add_transform(p, 0, x.second.constant, (int)c->sequenceTransformMap[name].size(), vals.data(), &tfId[name]);
+        }
+        if (rc != VG_OK) return bail(rc);
+    }
+    for (auto &data : c->dataVec) {  // addGridResidualBlocks :514-630
+        std::vector<int> tids;
+        for (auto &n : data.transNameVec) tids.push_back(tfId[n]);
+        std::vector<double> board, corners;
+        std::vector<int32_t> idx;
+        for (auto &pt : data.board) board.insert(board.end(), pt.begin(), pt.end());
+        for (size_t i = 0; i < data.detectedCornersVec.size(); i++)
+            if (!data.detectedCornersVec[i].empty()) {  // :520
+                idx.push_back((int32_t)i);
+                corners.insert(corners.end(), data.detectedCornersVec[i].begin(), data.detectedCornersVec[i].end());
+            }
+        if ((rc = vg_problem_add_dataset(p, camId[data.cameraName], (int)tids.size(), tids.data(), data.transStatusVec.data(),
+                                         (int)data.board.size(), board.data(), (int64_t)idx.size(), idx.data(),
+                                         corners.data(), nullptr)) != VG_OK)
+            return bail(rc);
+    }
+    if ((rc = vg_problem_finalize(p)) != VG_OK) return bail(rc);
+    vg_solve_summary local;
+    if ((rc = vg_problem_solve(p, options, summary ? summary : &local)) != VG_OK) return bail(rc);
+    std::vector<double> x((size_t)vg_problem_num_parameters(p));
+    if ((rc = vg_problem_get_parameters(p, x.data())) != VG_OK) return bail(rc);
+    for (auto &kv : c->intrinsicMap) {
+        const int64_t off = vg_problem_camera_offset(p, camId[kv.first]);
+        for (size_t k = 0; k < kv.second.size(); k++) kv.second[k] = x[(size_t)off + k];
+    }
+    for (auto &kv : c->transformInfoMap) {
+        if (kv.second.global) {
+            const int64_t off = vg_problem_transform_offset(p, tfId[kv.first], 0);
+            for (int k = 0; k < 6; k++) c->globalTransformMap[kv.first][k] = x[(size_t)off + k];
+        } else {
+            auto &seq = c->sequenceTransformMap[kv.first];
+            for (size_t i = 0; i < seq.size(); i++) {
+                const int64_t off = vg_problem_transform_offset(p, tfId[kv.first], (int64_t)i);
+                for (int k = 0; k < 6; k++) seq[i][k] = x[(size_t)off + k];
+            }
+        }
+    }
+    vg_problem_destroy(p);
+    return VG_OK;
+}
+
+/* the stdout report of compute(), unified_calibration.cpp:56-83; returns the needed size (incl. NUL) */
+int64_t vg_calibration_report(vg_calibration *c, char *buf, int64_t size)
+{
+    if (!c) return -1;
+    std::ostringstream o;
+    o << "Intrinsic parameters :\n";
+    for (auto &x : c->intrinsicMap) {
+        o << x.first << " : ";
+        for (double v : x.second) o << v << "  ";
+        o << "\n";
+    }
+    o << "Local extrinsic parameters :\n";
+    for (auto &s : c->sequenceTransformMap) {
+        o << "Sequence : " << s.first << "\n";
+        int i = 0;
+        for (auto &x : s.second) o << i++ << " : " << vgcal::fmt_transf(x) << "\n";
+    }
+    o << "Global extrinsic parameters :\n";
+    for (auto &x : c->globalTransformMap) o << x.first << " : " << vgcal::fmt_transf(x.second) << "\n";
+    const std::string s = o.str();
+    if (buf && size > 0) {
+        const size_t n = (size_t)size - 1 < s.size() ? (size_t)size - 1 : s.size();
+        std::memcpy(buf, s.data(), n);
+        buf[n] = 0;
+    }
+    return (int64_t)s.size() + 1;
+}
+
+int64_t vg_calibration_log(vg_calibration *c, char *buf, int64_t size)
+{
+    if (!c) return -1;
+    if (buf && size > 0) {
+        const size_t n = (size_t)size - 1 < c->log.size() ? (size_t)size - 1 : c->log.size();
+        std::memcpy(buf, c->log.data(), n);
+        buf[n] = 0;
+    }
+    return (int64_t)c->log.size() + 1;
+}
+
+int vg_calibration_num_datasets(const vg_calibration *c) { return c ? (int)c->dataVec.size() : -1; }
+
+int vg_calibration_get_intrinsics(vg_calibration *c, const char *camera, double *out, int *count)
+{
+    if (!c || !camera) return vgi::fail(VG_ERR_INVALID_ARGUMENT, "NULL argument");
+    auto it = c->intrinsicMap.find(camera);
+    if (it == c->intrinsicMap.end()) return vgi::fail(VG_ERR_INVALID_ARGUMENT, std::string("unknown camera ") + camera);
+    if (count) *count = (int)it->second.size();
+    if (out) std::memcpy(out, it->second.data(), sizeof(double) * it->second.size());
+    return VG_OK;
+}
+
+/* count = 1 for a global transform, the sequence length otherwise; out6 may be NULL */
+int vg_calibration_get_transform(vg_calibration *c, const char *name, int64_t index, double *out6, int64_t *count)
+{
+    if (!c || !name) return vgi::fail(VG_ERR_INVALID_ARGUMENT, "NULL argument");
+    auto it = c->transformInfoMap.find(name);
+    if (it == c->transformInfoMap.end()) return vgi::fail(VG_ERR_INVALID_ARGUMENT, std::string("unknown transformation ") + name);
+    const int64_t n = it->second.global ? 1 : (int64_t)c->sequenceTransformMap[name].size();
+    if (count) *count = n;
+    if (out6) {
+        if (index < 0 || index >= n) return vgi::fail(VG_ERR_INVALID_ARGUMENT, "transform index out of range");
+        std::memcpy(out6, c->getTransformData(name, (int)index).data(), sizeof(double) * 6);
+    }
+    return VG_OK;
+}
+
+/* writeImageResidual, unified_calibration.cpp:1186-1292: one line per corner of every image that has corners,
+ *   err.x err.y   proj.x proj.y   tx ty tz rx ry rz        (err = detected - projected, :1210-1213)
+ * The residuals come from the GPU (vg_block_evaluate on the composed chain).  sigma_out[n_images] (may be NULL)
+ * receives sqrt(sum |err|^2 / (N - 2)) per image (:1217), 0 for skipped images. */
+int vg_calibration_write_residuals(vg_calibration *c, int dataset, const char *path, double *sigma_out, int64_t *outliers_out)
+{
+    if (!c || !path) return vgi::fail(VG_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (dataset < 0 || dataset >= (int)c->dataVec.size()) return vgi::fail(VG_ERR_INVALID_ARGUMENT, "dataset index out of range");
+    const vgcal::ImageData &data = c->dataVec[(size_t)dataset];
+    std::ofstream f(path);
+    if (!f) return vgi::fail(VG_ERR_INVALID_ARGUMENT, std::string("cannot write ") + path);
+    const int N = (int)data.board.size();
+    std::vector<double> board;
+    for (auto &pt : data.board) board.insert(board.end(), pt.begin(), pt.end());
+    const int st[1] = {VG_TRANSFORM_DIRECT};
+    std::vector<double> res(2 * (size_t)N), zeros(2 * (size_t)N, 0.);
+    int64_t outliers = 0;
+    vg_block *blk = nullptr;
+    // projecting = evaluating the residual against zero observations: r = proj - 0
+    int rc = vg_block_create(&blk, c->device, c->cameraModelMap[data.cameraName], 1, st, N, board.data(), zeros.data());
+    if (rc != VG_OK) return rc;
+    for (size_t transfIdx = 0; transfIdx < data.detectedCornersVec.size(); transfIdx++) {
+        if (sigma_out) sigma_out[transfIdx] = 0.;
+        if (data.detectedCornersVec[transfIdx].empty()) continue;
+        vgcal::Array6d xi = {0, 0, 0, 0, 0, 0};  // computeTransforms :1160-1183
+        for (size_t i = 0; i < data.transNameVec.size(); i++) {
+            const vgcal::Array6d &t = c->getTransformData(data.transNameVec[i], (int)transfIdx);
+            xi = data.transStatusVec[i] == VG_TRANSFORM_DIRECT ? vgcal::compose(xi, t) : vgcal::compose_inverse(xi, t);
+        }
+        const double *params[2] = {c->intrinsicMap[data.cameraName].data(), xi.data()};
+        if ((rc = vg_block_evaluate(blk, params, res.data(), nullptr)) != VG_OK) {
+            vg_block_destroy(blk);
+            return rc;
+        }
+        double stdAcc = 0;
+        const std::vector<double> &det = data.detectedCornersVec[transfIdx];
+        for (int i = 0; i < N; i++) {
+            const double proj[2] = {res[2 * (size_t)i], res[2 * (size_t)i + 1]};
+            const double err[2] = {det[2 * (size_t)i] - proj[0], det[2 * (size_t)i + 1] - proj[1]};
+            f << vgcal::fmt_vec(err, 2) << "   " << vgcal::fmt_vec(proj, 2) << "   " << vgcal::fmt_transf(xi) << "\n";
+            stdAcc += err[0] * err[0] + err[1] * err[1];
+        }
+        const double sigma = std::sqrt(stdAcc / (N - 2));
+        if (sigma_out) sigma_out[transfIdx] = sigma;
+        for (int i = 0; i < N; i++) {
+            const double ex = det[2 * (size_t)i] - res[2 * (size_t)i], ey = det[2 * (size_t)i + 1] - res[2 * (size_t)i + 1];
+            const double en = std::sqrt(ex * ex + ey * ey);
+            if (!(en < 3.6 * sigma && en < 1.)) outliers++;  // :1222
+        }
+    }
+    vg_block_destroy(blk);
+    if (outliers_out) *outliers_out = outliers;
+    return VG_OK;
+}
+
+}  // extern "C"

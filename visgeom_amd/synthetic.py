@@ -254,3 +254,39 @@ def make_rig(n_frames, config_index=5, sigma=0.1):
             "init_intrinsics": [INIT[m].copy() for m in models], "gt_xi1k": xi1k,
             "init_xi1k": [x + _perturb(seed, 1, 6, salt=2 + k)[0] for k, x in enumerate(xi1k)],
             "gt_poses": poses, "init_poses": poses + _perturb(seed, n_frames, 6), "seed": seed}
+
+
+def write_calibration_json(directory, d, model, name="calib", camera="cam", sequence="xiCamBoard", prior=False,
+                           init=True, flags=(), as_images=False, skip=()):
+    """Config 1: write <name>.json (+ <name>_corners.json) in the reference's calibration schema (README.md:36-223,
+    style of data/calib_example.json) for a mono set made by make_mono.  Corners travel as an ir_data-style data
+    file: a list of frames, each a list of {camera, points}; frames in `skip` carry no entry for this camera
+    (an empty corner list -> the image is skipped everywhere, unified_calibration.cpp:363,520,1198)."""
+    import json
+    import os
+
+    board = d["board"]
+    n = d["corners"].shape[0]
+    frames = [[] if i in skip else [{"camera": camera, "points": d["corners"][i].tolist()}] for i in range(n)]
+    corners_file = name + "_corners.json"
+    with open(os.path.join(directory, corners_file), "w") as f:
+        json.dump(frames, f)
+    tf = {"name": sequence, "global": False, "prior": bool(prior), "constant": False}
+    if prior:
+        tf["value"] = d["init_poses"].tolist()
+    data = {"camera": camera, "parameters": list(flags), "transform_chain": [{"name": sequence, "direct": True}],
+            "init": sequence if (init and not prior) else "none"}
+    if as_images:
+        data.update({"type": "images", "object": {"type": "checkboard", "cols": BOARD_COLS, "rows": BOARD_ROWS,
+                                                   "size": BOARD_SIZE}, "corners_file": corners_file})
+    else:
+        data.update({"type": "ir_data", "image_width": IMAGE_W, "image_height": IMAGE_H, "data_file": corners_file,
+                     "object": {"points": board.tolist(), "corner_ul": 0, "corner_ur": BOARD_COLS - 1,
+                                "corner_bl": BOARD_COLS * (BOARD_ROWS - 1), "corner_br": BOARD_COLS * BOARD_ROWS - 1}})
+    root = {"transformations": [tf],
+            "cameras": [{"name": camera, "type": model, "constant": False, "value": d["init_intrinsics"].tolist()}],
+            "data": [data]}
+    path = os.path.join(directory, name + ".json")
+    with open(path, "w") as f:
+        json.dump(root, f, indent=1)
+    return path
