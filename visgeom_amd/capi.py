@@ -130,8 +130,11 @@ def load():
     if _lib is not None:
         return _lib
     if not os.path.exists(_build.LIB):
-        raise ImportError("%s is missing: run `python -m visgeom_amd._build` (needs hipcc). "
-                          "visgeom_amd is HIP-only and has no CPU fallback." % _build.LIB)
+        try:  # build the HIP library in-tree (hipcc cross-compiles); never substitute anything for it
+            _build.build()
+        except Exception as e:
+            raise ImportError("%s is missing and could not be built (%s): run `python -m visgeom_amd._build` "
+                              "(needs hipcc). visgeom_amd is HIP-only and has no CPU fallback." % (_build.LIB, e))
     try:  # make torch's bundled HIP runtime the one this process uses (same SONAME, libamdhip64.so.7)
         import torch  # noqa: F401
     except Exception:  # the library also works stand-alone against /opt/rocm

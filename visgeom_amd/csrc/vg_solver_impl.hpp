@@ -406,6 +406,11 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             VG_HIP(hipStreamSynchronize(st));
             t_schur += now_s() - t0;
 
+            // |x|^2 of this rank's pose parameters (summed over ranks below) and of the replicated global block
+            double xg2 = 0., xp2 = 0.;
+            for (int a2 = 0; a2 < G; a2++) xg2 += h_x[(size_t)gcol_param[a2]] * h_x[(size_t)gcol_param[a2]];
+            for (int64_t i = 0; i < n_poses; i++)
+                for (int k = 0; k < 6; k++) xp2 += h_x[(size_t)pose_param[(size_t)i] + k] * h_x[(size_t)pose_param[(size_t)i] + k];
             double gdp = 0., ddp = 0., gmax_p = 0., dp2 = 0., gp2 = 0.;
             for (int64_t i = 0; i < n_poses; i++) {
                 gdp += h_scal[(size_t)i * 5];
@@ -423,6 +428,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
                 pack.push_back(ddp);
                 pack.push_back(dp2);
                 pack.push_back(gp2);
+                pack.push_back(xp2);
                 VG_TRY(allreduce(pack));
                 size_t o = (size_t)G * G;
                 std::copy(pack.begin(), pack.begin() + o, Uc.begin());
@@ -433,6 +439,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
                 ddp = pack[o + 2];
                 dp2 = pack[o + 3];
                 gp2 = pack[o + 4];
+                xp2 = pack[o + 5];
                 // The callback only sums.  With several ranks every rank must take the same branches, so the
                 // pose part of the gradient max-norm is replaced by its (summable) 2-norm, an upper bound:
                 // the gradient test can only fire later than Ceres' max-norm test, never earlier.
@@ -465,8 +472,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
                 std::snprintf(msg, sizeof msg, "gradient tolerance reached: max norm %.3e <= %.3e", grad_max, opt.gradient_tolerance);
                 break;
             }
-            double xn2 = 0.;
-            for (double v : h_x) xn2 += v * v;
+            const double xn2 = xg2 + xp2;  // identical on every rank
             if (std::sqrt(step2) <= opt.parameter_tolerance * (std::sqrt(xn2) + opt.parameter_tolerance)) {
                 term = VG_TERM_CONVERGENCE_PARAMETER;
                 std::snprintf(msg, sizeof msg, "parameter tolerance reached: |step| %.3e", std::sqrt(step2));
