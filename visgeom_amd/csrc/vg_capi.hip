@@ -196,6 +196,7 @@ void vg_problem_destroy(vg_problem *p)
     (void)hipSetDevice(p->device);
     for (auto &d : p->dss) free_dataset(d);
     if (p->d_params) (void)hipFree(p->d_params);
+    if (p->d_prep) (void)hipFree(p->d_prep);
     delete p;
 }
 
@@ -319,6 +320,27 @@ int vg_problem_finalize(vg_problem *p)
         // host copies are no longer needed; everything stays resident in HBM
         std::vector<double>().swap(d.h_obs);
     }
+    // descriptors of the merged chain-prep launch
+    std::vector<vg::PrepDataset> prep;
+    int64_t first = 0;
+    for (auto &d : p->dss) {
+        if (!d.n_blocks) continue;
+        vg::PrepDataset pd;
+        pd.chain = d.chain;
+        pd.seq_index = d.d_seq;
+        pd.frames = d.d_frames;
+        pd.first = first;
+        pd.count = d.n_blocks;
+        pd.frame_stride_d = d.frame_stride;
+        prep.push_back(pd);
+        first += d.n_blocks;
+    }
+    p->n_prep = (int)prep.size();
+    p->prep_blocks = first;
+    if (!prep.empty()) {
+        VG_HIP(hipMalloc(&p->d_prep, sizeof(vg::PrepDataset) * prep.size()));
+        VG_HIP(hipMemcpy(p->d_prep, prep.data(), sizeof(vg::PrepDataset) * prep.size(), hipMemcpyHostToDevice));
+    }
     p->finalized = true;
     return VG_OK;
 }
@@ -374,13 +396,11 @@ int vg_dataset_num_intrinsics(const vg_problem *p, int d)
 
 int vgi::prepare_at(vg_problem *p, const double *d_params)
 {
-    for (auto &d : p->dss) {
-        if (!d.n_blocks) continue;
-        const unsigned int grid = (unsigned int)((d.n_blocks + 63) / 64);
-        hipLaunchKernelGGL(vg::vg_chain_prep_kernel, dim3(grid), dim3(64), 0, p->stream, d_params, d.chain, d.d_seq,
-                           (long long)d.n_blocks, d.d_frames, d.frame_stride);
-        VG_HIP(hipGetLastError());
-    }
+    if (!p->prep_blocks) return VG_OK;
+    const unsigned int grid = (unsigned int)((p->prep_blocks + 63) / 64);
+    hipLaunchKernelGGL(vg::vg_chain_prep_multi_kernel, dim3(grid), dim3(64), 0, p->stream, d_params,
+                       (const vg::PrepDataset *)p->d_prep, p->n_prep, (long long)p->prep_blocks);
+    VG_HIP(hipGetLastError());
     return VG_OK;
 }
 

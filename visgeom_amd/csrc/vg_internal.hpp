@@ -66,6 +66,9 @@ struct vg_problem {
     std::vector<vgi::Dataset> dss;
     int64_t n_params = 0;
     double *d_params = nullptr;
+    vg::PrepDataset *d_prep = nullptr;  // one descriptor per non-empty dataset (vg_chain_prep_multi_kernel)
+    int n_prep = 0;
+    int64_t prep_blocks = 0;
 };
 
 struct vg_block {

@@ -69,7 +69,8 @@ struct SchurArgs {
     int *bad;              // number of poses whose damped block was not positive definite
 };
 
-__global__ __launch_bounds__(64) void vg_schur_rows_kernel(SchurArgs a)
+// step 1 of the elimination, one lane per pose: V_i, g_i from the Gram blocks, damping, 6x6 Cholesky -> rec
+__global__ __launch_bounds__(64) void vg_pose_factor_kernel(SchurArgs a)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n_poses) return;
@@ -127,31 +128,41 @@ __global__ __launch_bounds__(64) void vg_schur_rows_kernel(SchurArgs a)
         rec[27 + k] = vd[k];
     }
     rec[33] = active ? 1. : 0.;
+}
 
+// step 2, one lane per (pose, global column): column gcol of the six rows  L^-1 W_i^T  (gcol == G: L^-1 g_i)
+__global__ __launch_bounds__(256) void vg_schur_rows_kernel(SchurArgs a)
+{
     const int C = a.G + 1;
-    double *out = a.rows + (size_t)i * 6 * C;
-    for (int gcol = 0; gcol <= a.G; gcol++) {
-        double w[6], y[6];
-        if (gcol < a.G) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)a.n_poses * C) return;
+    const int i = (int)(t / C), gcol = (int)(t - (long long)i * C);
+    const double *rec = a.rec + (size_t)i * kPoseRec;
+    double L[21], w[6], y[6];
 #pragma unroll
-            for (int c = 0; c < 6; c++) w[c] = 0.;
-            for (int q = r0; q < r1; q++) {
-                const int d = a.ref_ds[q];
-                const int lc = a.inv[d * a.G + gcol];
-                if (lc < 0) continue;
-                const SolveDatasetDev D = a.ds[d];
-                const double *Gb = D.gram + (size_t)a.ref_blk[q] * D.W * D.W;
+    for (int k = 0; k < 21; k++) L[k] = rec[k];
+    const bool active = rec[33] != 0.;
+    if (gcol < a.G) {
 #pragma unroll
-                for (int c = 0; c < 6; c++) w[c] += Gb[lc * D.W + D.pose_off + c];
-            }
-        } else {
+        for (int c = 0; c < 6; c++) w[c] = 0.;
+        const int r0 = a.ref_ptr[i], r1 = a.ref_ptr[i + 1];
+        for (int q = r0; q < r1; q++) {
+            const int d = a.ref_ds[q];
+            const int lc = a.inv[d * a.G + gcol];
+            if (lc < 0) continue;
+            const SolveDatasetDev D = a.ds[d];
+            const double *Gb = D.gram + (size_t)a.ref_blk[q] * D.W * D.W;
 #pragma unroll
-            for (int c = 0; c < 6; c++) w[c] = gp[c];
+            for (int c = 0; c < 6; c++) w[c] += Gb[lc * D.W + D.pose_off + c];
         }
-        fwd6(L, w, y);
+    } else {
 #pragma unroll
-        for (int k = 0; k < 6; k++) out[k * C + gcol] = active ? y[k] : 0.;
+        for (int c = 0; c < 6; c++) w[c] = rec[21 + c];
     }
+    fwd6(L, w, y);
+    double *out = a.rows + (size_t)i * 6 * C + gcol;
+#pragma unroll
+    for (int k = 0; k < 6; k++) out[k * C] = active ? y[k] : 0.;
 }
 
 struct BacksubArgs {
@@ -160,56 +171,73 @@ struct BacksubArgs {
     const long long *pose_param;   // [n_poses] offset of the pose's 6-vector in the parameter vector
     const long long *gcol_param;   // [G] offset of each global column in the parameter vector
     double *delta;                 // parameter-layout step vector
-    double *scal;                  // [n_poses][5]: gp.dp | sum D dp^2 | max|gp| | |dp|^2 | |gp|^2
+    double *scal;                  // [n_workgroups][5] partial sums: gp.dp | sum D dp^2 | |dp|^2 | |gp|^2 | |x_pose|^2
+    unsigned long long *gmax_bits; // max |gp| over active poses, as the bit pattern of a non-negative double
+    const double *x;               // current parameter vector
+    double *xg;                    // [G] current values of the global columns (gathered for the host)
 };
 
+// dp_i = -V_i'^-1 (g_i + W_i^T dg) = -L^-T (L^-1 g_i + (L^-1 W_i^T) dg): everything needed is already in the
+// six rows of the pose (last column = L^-1 g_i), no second gather from the Gram blocks.  The per-pose terms of the
+// model decrease / norms are reduced per wave (fixed butterfly), one partial per 64 poses.
 __global__ __launch_bounds__(64) void vg_backsub_kernel(BacksubArgs b)
 {
     const SchurArgs &a = b.s;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < a.G) b.delta[b.gcol_param[i]] = b.dg[i];
-    if (i >= a.n_poses) return;
-    const double *rec = a.rec + (size_t)i * kPoseRec;
-    double L[21], t[6], y[6], x[6];
+    if (i < a.G) {
+        b.delta[b.gcol_param[i]] = b.dg[i];
+        b.xg[i] = b.x[b.gcol_param[i]];
+    }
+    double s0 = 0., s1 = 0., s2 = 0., s3 = 0., s4 = 0., s5 = 0.;
+    if (i < a.n_poses) {
+        const double *rec = a.rec + (size_t)i * kPoseRec;
+        double L[21], y[6], x[6];
 #pragma unroll
-    for (int k = 0; k < 21; k++) L[k] = rec[k];
+        for (int k = 0; k < 21; k++) L[k] = rec[k];
+        const bool active = rec[33] != 0.;
+        const int C = a.G + 1;
+        const double *rows = a.rows + (size_t)i * 6 * C;
 #pragma unroll
-    for (int k = 0; k < 6; k++) t[k] = rec[21 + k];
-    const bool active = rec[33] != 0.;
-    const int r0 = a.ref_ptr[i], r1 = a.ref_ptr[i + 1];
-    for (int q = r0; q < r1; q++) {
-        const int d = a.ref_ds[q];
-        const SolveDatasetDev D = a.ds[d];
-        const double *Gb = D.gram + (size_t)a.ref_blk[q] * D.W * D.W;
-        for (int gcol = 0; gcol < a.G; gcol++) {
-            const int lc = a.inv[d * a.G + gcol];
-            if (lc < 0) continue;
-            const double dgv = b.dg[gcol];
+        for (int k = 0; k < 6; k++) {
+            double s = rows[k * C + a.G];
+            for (int g = 0; g < a.G; g++) s += rows[k * C + g] * b.dg[g];
+            y[k] = s;
+        }
+        bwd6(L, y, x);
+        double *dp = b.delta + b.pose_param[i];
+        const double *xp = b.x + b.pose_param[i];
 #pragma unroll
-            for (int c = 0; c < 6; c++) t[c] += Gb[lc * D.W + D.pose_off + c] * dgv;
+        for (int c = 0; c < 6; c++) {
+            const double v = active ? -x[c] : 0.;
+            dp[c] = v;
+            const double g = rec[21 + c];
+            s0 += g * v;
+            s1 += clampd(rec[27 + c], a.dmin, a.dmax) * v * v;
+            if (active) s2 = fmax(s2, fabs(g));
+            if (active) s4 += g * g;
+            s3 += v * v;
+            s5 += xp[c] * xp[c];
         }
     }
-    fwd6(L, t, y);
-    bwd6(L, y, x);
-    double s0 = 0., s1 = 0., s2 = 0., s3 = 0., s4 = 0.;
-    double *dp = b.delta + b.pose_param[i];
+    if ((int)(blockIdx.x * blockDim.x) >= a.n_poses) return;  // workgroups that only carry global columns
 #pragma unroll
-    for (int c = 0; c < 6; c++) {
-        const double v = active ? -x[c] : 0.;
-        dp[c] = v;
-        const double g = rec[21 + c];
-        s0 += g * v;
-        s1 += clampd(rec[27 + c], a.dmin, a.dmax) * v * v;
-        if (active) s2 = fmax(s2, fabs(g));
-        if (active) s4 += g * g;
-        s3 += v * v;
+    for (int off = 32; off >= 1; off >>= 1) {
+        s0 += __shfl_xor(s0, off, kWave);
+        s1 += __shfl_xor(s1, off, kWave);
+        s3 += __shfl_xor(s3, off, kWave);
+        s4 += __shfl_xor(s4, off, kWave);
+        s5 += __shfl_xor(s5, off, kWave);
+        s2 = fmax(s2, __shfl_xor(s2, off, kWave));
     }
-    double *sc = b.scal + (size_t)i * 5;
-    sc[0] = s0;
-    sc[1] = s1;
-    sc[2] = s2;
-    sc[3] = s3;
-    sc[4] = s4;
+    if (threadIdx.x == 0) {
+        double *sc = b.scal + (size_t)blockIdx.x * 5;
+        sc[0] = s0;
+        sc[1] = s1;
+        sc[2] = s3;
+        sc[3] = s4;
+        sc[4] = s5;
+        atomicMax(b.gmax_bits, (unsigned long long)__double_as_longlong(s2));  // order preserving for s2 >= 0
+    }
 }
 
 // x_new = clamp(x + delta, lo, hi)

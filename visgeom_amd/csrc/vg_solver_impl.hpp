@@ -70,6 +70,22 @@ struct DevBuf {
     }
 };
 
+// pinned host memory: small per-iteration transfers go straight over DMA instead of through a staging copy kernel
+struct PinnedBuf {
+    double *p = nullptr;
+    size_t n = 0;
+    ~PinnedBuf()
+    {
+        if (p) (void)hipHostFree(p);
+    }
+    int alloc(size_t count)
+    {
+        n = count;
+        VG_HIP(hipHostMalloc(reinterpret_cast<void **>(&p), sizeof(double) * (count ? count : 1), hipHostMallocDefault));
+        return VG_OK;
+    }
+};
+
 int launch_dense_gram(hipStream_t st, const double *X, unsigned n_rows, int C, unsigned rows_per_group, unsigned n_groups,
                       double *out)
 {
@@ -215,7 +231,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
     // ---------------------------------------------------------------- device state
     const int C = G + 1;
     const unsigned int n_rows = (unsigned int)(6 * n_poses);
-    const unsigned int rows_per_group = 384;  // 64 poses per wave
+    const unsigned int rows_per_group = 96;  // 16 poses per wave: enough waves to fill the chip at 5 k poses
     const unsigned int n_groups = n_rows ? (n_rows + rows_per_group - 1) / rows_per_group : 0;
     const unsigned int n_slabs = (n_groups + vg::kSlab - 1) / vg::kSlab;
     DevBuf<double> gramA[64], gramB[64];
@@ -255,13 +271,23 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
     VG_TRY(d_rslabs.alloc((size_t)n_slabs * C * C));
     VG_TRY(d_rgram.alloc((size_t)C * C));
     VG_TRY(d_dg.alloc((size_t)(G ? G : 1)));
-    VG_TRY(d_scal.alloc((size_t)n_poses * 5));
+    const unsigned int n_bs_groups = (unsigned int)((n_poses + 63) / 64);
+    DevBuf<double> d_scal_sum, d_xg;
+    DevBuf<unsigned long long> d_gmax;
+    VG_TRY(d_scal.alloc((size_t)n_bs_groups * 5));
+    VG_TRY(d_scal_sum.alloc(5));
+    VG_TRY(d_xg.alloc((size_t)(G ? G : 1)));
+    VG_TRY(d_gmax.alloc(1));
     VG_TRY(d_bad.alloc(1));
     VG_HIP(hipMemsetAsync(d_delta.p, 0, sizeof(double) * (size_t)(n_params ? n_params : 1), st));
     VG_HIP(hipMemcpyAsync(d_x.p, p->d_params, sizeof(double) * (size_t)n_params, hipMemcpyDeviceToDevice, st));
 
-    std::vector<double> h_sums((size_t)n_ds * Wmax * Wmax), h_rgram((size_t)C * C), h_scal((size_t)n_poses * 5);
-    std::vector<double> U((size_t)G * G), gg(G), Uc((size_t)G * G), ggc(G), S((size_t)G * G), rhs(G), dg(G), h_x((size_t)n_params);
+    std::vector<double> h_sums((size_t)n_ds * Wmax * Wmax), h_rgram((size_t)C * C);
+    std::vector<double> U((size_t)G * G), gg(G), Uc((size_t)G * G), ggc(G), S((size_t)G * G), rhs(G), dg(G), h_xg(G);
+    PinnedBuf pin_sums, pin_rgram, pin_small;  // pin_small: [dg (G) | scalars (5) | gmax (1) | xg (G)]
+    VG_TRY(pin_sums.alloc(h_sums.size()));
+    VG_TRY(pin_rgram.alloc(h_rgram.size()));
+    VG_TRY(pin_small.alloc((size_t)2 * G + 8));
 
     // evaluate the Gram matrices at a device parameter buffer into gram set `set`, assemble U / gg / cost
     auto evaluate = [&](const double *x_dev, DevBuf<double> *set, std::vector<double> &Uo, std::vector<double> &go,
@@ -273,8 +299,9 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             if ((r = vgi::gram_fused_at(p, d, x_dev, set[d].p)) != VG_OK) return r;
             if ((r = vgi::gram_sum_into(p, d, set[d].p, d_sums.p + (size_t)d * Wmax * Wmax)) != VG_OK) return r;
         }
-        VG_HIP(hipMemcpyAsync(h_sums.data(), d_sums.p, sizeof(double) * h_sums.size(), hipMemcpyDeviceToHost, st));
+        VG_HIP(hipMemcpyAsync(pin_sums.p, d_sums.p, sizeof(double) * h_sums.size(), hipMemcpyDeviceToHost, st));
         VG_HIP(hipStreamSynchronize(st));
+        std::memcpy(h_sums.data(), pin_sums.p, sizeof(double) * h_sums.size());
         std::fill(Uo.begin(), Uo.end(), 0.);
         std::fill(go.begin(), go.end(), 0.);
         cost2 = 0.;
@@ -316,8 +343,6 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
         std::copy(pack.begin() + (size_t)G * G, pack.begin() + (size_t)G * G + G, gg.begin());
         cost2 = pack.back();
     }
-    VG_HIP(hipMemcpy(h_x.data(), d_x.p, sizeof(double) * (size_t)n_params, hipMemcpyDeviceToHost));
-
     double radius = opt.initial_trust_region_radius, decrease_factor = 2.;
     int iter = 0, n_success = 0, term = VG_TERM_NO_CONVERGENCE;
     double grad_max = 0.;
@@ -347,7 +372,9 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
         std::fill(h_rgram.begin(), h_rgram.end(), 0.);
         if (n_poses) {
             VG_HIP(hipMemsetAsync(d_bad.p, 0, sizeof(int), st));
-            hipLaunchKernelGGL(vg::vg_schur_rows_kernel, dim3((unsigned)((n_poses + 63) / 64)), dim3(64), 0, st, sa);
+            hipLaunchKernelGGL(vg::vg_pose_factor_kernel, dim3((unsigned)((n_poses + 63) / 64)), dim3(64), 0, st, sa);
+            VG_HIP(hipGetLastError());
+            hipLaunchKernelGGL(vg::vg_schur_rows_kernel, dim3((unsigned)((n_poses * C + 255) / 256)), dim3(256), 0, st, sa);
             VG_HIP(hipGetLastError());
             VG_TRY(launch_dense_gram(st, d_rows.p, n_rows, C, rows_per_group, n_groups, d_rgroups.p));
             hipLaunchKernelGGL(vg::vg_gram_slab_sum_kernel, dim3(n_slabs), dim3(256), 0, st, (const double *)d_rgroups.p,
@@ -356,8 +383,9 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             hipLaunchKernelGGL(vg::vg_gram_final_sum_kernel, dim3((C * C + 3) / 4), dim3(256), 0, st,
                                (const double *)d_rslabs.p, n_slabs, C * C, d_rgram.p);
             VG_HIP(hipGetLastError());
-            VG_HIP(hipMemcpyAsync(h_rgram.data(), d_rgram.p, sizeof(double) * h_rgram.size(), hipMemcpyDeviceToHost, st));
+            VG_HIP(hipMemcpyAsync(pin_rgram.p, d_rgram.p, sizeof(double) * h_rgram.size(), hipMemcpyDeviceToHost, st));
             VG_HIP(hipStreamSynchronize(st));
+            std::memcpy(h_rgram.data(), pin_rgram.p, sizeof(double) * h_rgram.size());
         }
         VG_TRY(allreduce(h_rgram));
         t_schur += now_s() - t0;
@@ -383,7 +411,11 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
         if (step_ok) {
             // ---- back-substitute, apply, evaluate the candidate
             t0 = now_s();
-            if (G) VG_HIP(hipMemcpyAsync(d_dg.p, dg.data(), sizeof(double) * G, hipMemcpyHostToDevice, st));
+            if (G) {
+                std::memcpy(pin_small.p, dg.data(), sizeof(double) * G);
+                VG_HIP(hipMemcpyAsync(d_dg.p, pin_small.p, sizeof(double) * G, hipMemcpyHostToDevice, st));
+            }
+            VG_HIP(hipMemsetAsync(d_gmax.p, 0, sizeof(unsigned long long), st));
             vg::BacksubArgs ba;
             ba.s = sa;
             ba.dg = d_dg.p;
@@ -391,9 +423,17 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             ba.gcol_param = d_gcol_param.p;
             ba.delta = d_delta.p;
             ba.scal = d_scal.p;
+            ba.gmax_bits = d_gmax.p;
+            ba.x = d_x.p;
+            ba.xg = d_xg.p;
             const int64_t nthr = n_poses > G ? n_poses : G;
             if (nthr) {
                 hipLaunchKernelGGL(vg::vg_backsub_kernel, dim3((unsigned)((nthr + 63) / 64)), dim3(64), 0, st, ba);
+                VG_HIP(hipGetLastError());
+            }
+            if (n_bs_groups) {  // fixed-order sum of the per-workgroup partials
+                hipLaunchKernelGGL(vg::vg_gram_final_sum_kernel, dim3(2), dim3(256), 0, st, (const double *)d_scal.p, n_bs_groups, 5,
+                                   d_scal_sum.p);
                 VG_HIP(hipGetLastError());
             }
             if (n_params) {
@@ -402,23 +442,21 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
                                    (const double *)d_hi.p, (long long)n_params, d_xc.p);
                 VG_HIP(hipGetLastError());
             }
-            if (n_poses) VG_HIP(hipMemcpyAsync(h_scal.data(), d_scal.p, sizeof(double) * h_scal.size(), hipMemcpyDeviceToHost, st));
+            double *ps = pin_small.p + G;  // [scalars 5 | gmax 1 | xg G]
+            for (int k = 0; k < 6; k++) ps[k] = 0.;
+            if (n_poses) {
+                VG_HIP(hipMemcpyAsync(ps, d_scal_sum.p, sizeof(double) * 5, hipMemcpyDeviceToHost, st));
+                VG_HIP(hipMemcpyAsync(ps + 5, d_gmax.p, sizeof(double), hipMemcpyDeviceToHost, st));
+            }
+            if (G) VG_HIP(hipMemcpyAsync(ps + 6, d_xg.p, sizeof(double) * G, hipMemcpyDeviceToHost, st));
             VG_HIP(hipStreamSynchronize(st));
             t_schur += now_s() - t0;
 
             // |x|^2 of this rank's pose parameters (summed over ranks below) and of the replicated global block
-            double xg2 = 0., xp2 = 0.;
-            for (int a2 = 0; a2 < G; a2++) xg2 += h_x[(size_t)gcol_param[a2]] * h_x[(size_t)gcol_param[a2]];
-            for (int64_t i = 0; i < n_poses; i++)
-                for (int k = 0; k < 6; k++) xp2 += h_x[(size_t)pose_param[(size_t)i] + k] * h_x[(size_t)pose_param[(size_t)i] + k];
-            double gdp = 0., ddp = 0., gmax_p = 0., dp2 = 0., gp2 = 0.;
-            for (int64_t i = 0; i < n_poses; i++) {
-                gdp += h_scal[(size_t)i * 5];
-                ddp += h_scal[(size_t)i * 5 + 1];
-                gmax_p = h_scal[(size_t)i * 5 + 2] > gmax_p ? h_scal[(size_t)i * 5 + 2] : gmax_p;
-                dp2 += h_scal[(size_t)i * 5 + 3];
-                gp2 += h_scal[(size_t)i * 5 + 4];
-            }
+            for (int a2 = 0; a2 < G; a2++) h_xg[a2] = ps[6 + a2];
+            double xg2 = 0.;
+            for (int a2 = 0; a2 < G; a2++) xg2 += h_xg[a2] * h_xg[a2];
+            double gdp = ps[0], ddp = ps[1], dp2 = ps[2], gp2 = ps[3], xp2 = ps[4], gmax_p = ps[5];
             VG_TRY(evaluate(d_xc.p, cand, Uc, ggc, cost2_c));
             {
                 std::vector<double> pack(Uc);
@@ -454,7 +492,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
                 ddg += dcl * dg[a2] * dg[a2];
                 dg2 += dg[a2] * dg[a2];
                 // projected gradient for bounded parameters: |Project(x - g) - x|
-                const double xv = h_x[(size_t)gcol_param[a2]];
+                const double xv = h_xg[a2];
                 double xg = xv - gg[a2];
                 const double l2 = lo[(size_t)gcol_param[a2]], h2 = hi[(size_t)gcol_param[a2]];
                 xg = xg < l2 ? l2 : (xg > h2 ? h2 : xg);
@@ -492,7 +530,6 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             gg.swap(ggc);
             const double prev = cost2;
             cost2 = cost2_c;
-            VG_HIP(hipMemcpy(h_x.data(), d_x.p, sizeof(double) * (size_t)n_params, hipMemcpyDeviceToHost));
             const double f = 1. - std::pow(2. * rho - 1., 3);
             radius = radius / (f > 1. / 3. ? f : 1. / 3.);
             radius = radius > opt.max_trust_region_radius ? opt.max_trust_region_radius : radius;
