@@ -131,6 +131,8 @@ int launch_gram_fused(hipStream_t stream, const vg::GramArgs &a)
     const size_t lds = (size_t)waves * tile;
     const dim3 blk(waves * vg::kWave);
     if (T == 1) hipLaunchKernelGGL((vg::vg_gram_fused_kernel<MODEL, 1>), dim3(grid), blk, lds, stream, a);
+    else if (T == 2 && a.W - 16 <= vg::kCornerMax)
+        hipLaunchKernelGGL((vg::vg_gram_fused_kernel<MODEL, 2, true>), dim3(grid), blk, lds, stream, a);
     else if (T == 2) hipLaunchKernelGGL((vg::vg_gram_fused_kernel<MODEL, 2>), dim3(grid), blk, lds, stream, a);
     else hipLaunchKernelGGL((vg::vg_gram_fused_kernel<MODEL, 3>), dim3(grid), blk, lds, stream, a);
     VG_HIP(hipGetLastError());

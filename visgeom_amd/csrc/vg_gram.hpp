@@ -50,14 +50,15 @@ __device__ __forceinline__ f64x4 mfma_f64_16x16x4(double a, double b, f64x4 c)
 
 // Store the T x T tiles of accumulators as the full symmetric W x W matrix.
 // f64 C/D layout: lane l, register r holds D[row = (l>>4) + 4r][col = l&15].
-template <int T>
+template <int T, bool SKIP_LAST_DIAGONAL = false>
 __device__ __forceinline__ void store_gram(const f64x4 (&acc)[T][T], double *__restrict__ g, int W, int lane)
 {
     const int col = lane & 15, row0 = lane >> 4;
 #pragma unroll
     for (int ti = 0; ti < T; ti++)
 #pragma unroll
-        for (int tj = ti; tj < T; tj++)
+        for (int tj = ti; tj < T; tj++) {
+            if (SKIP_LAST_DIAGONAL && ti == T - 1 && tj == T - 1) continue;  // written by the caller
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int i = 16 * ti + row0 + 4 * r, j = 16 * tj + col;
@@ -66,6 +67,7 @@ __device__ __forceinline__ void store_gram(const f64x4 (&acc)[T][T], double *__r
                     if (ti != tj) g[j * W + i] = acc[ti][tj][r];
                 }
             }
+        }
 }
 
 template <int T>
@@ -101,9 +103,15 @@ __host__ __device__ constexpr int gram_wave_lds_doubles(int W, int frame_stride_
     return kGramRowsPerTile * W + 2 * frame_stride_d;
 }
 
-template <int MODEL, int T>
+// CORNER (only with T == 2, W <= 20): the small (W-16) x (W-16) corner of the Gram matrix -- the 1 x 1 r^T r of Mei
+// mono (W = 17), the 3 x 3 of the stereo chain (W = 19) -- would cost a whole third MFMA per 4 rows; it is
+// accumulated by the lanes instead (<= 10 products per row) and reduced once per image with shuffles.
+constexpr int kCornerMax = 4;
+
+template <int MODEL, int T, bool CORNER = false>
 __global__ __launch_bounds__(kGramMaxWavesPerBlock *kWave) void vg_gram_fused_kernel(GramArgs a)
 {
+    static_assert(!CORNER || T == 2, "the VALU corner only exists for two column tiles");
     constexpr int K = CameraTraits<MODEL>::K;
     using d2 = HIP_vector_type<double, 2>;
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -130,6 +138,10 @@ __global__ __launch_bounds__(kGramMaxWavesPerBlock *kWave) void vg_gram_fused_ke
     f64x4 accA[T][T], accB[T][T];
     zero_acc<T>(accA);
     zero_acc<T>(accB);
+    double cacc[kCornerMax * (kCornerMax + 1) / 2];
+#pragma unroll
+    for (int q = 0; q < kCornerMax * (kCornerMax + 1) / 2; q++) cacc[q] = 0.;
+    const int Wc = CORNER ? W - 16 : 0;  // 1 .. kCornerMax
     const int c16 = lane & 15, k4 = lane >> 4;
 
     for (unsigned int c0 = 0; c0 < a.N; c0 += kGramHalf) {
@@ -172,6 +184,19 @@ __global__ __launch_bounds__(kGramMaxWavesPerBlock *kWave) void vg_gram_fused_ke
                 rv[i] = 0.;
             }
         }
+        if (CORNER) {
+            // this lane's own two rows, columns 16 .. W-1 (just written; DS ops of a wave execute in order)
+            double cu[kCornerMax], cv[kCornerMax];
+#pragma unroll
+            for (int q = 0; q < kCornerMax; q++) {
+                cu[q] = q < Wc ? ru[16 + q] : 0.;
+                cv[q] = q < Wc ? rv[16 + q] : 0.;
+            }
+#pragma unroll
+            for (int r = 0, q = 0; r < kCornerMax; r++)
+#pragma unroll
+                for (int c = r; c < kCornerMax; c++, q++) cacc[q] += cu[r] * cu[c] + cv[r] * cv[c];
+        }
         wave_lds_fence();
 
         // always 16 groups of 4 rows per image: rows of lanes without a corner are zero, so a ragged last
@@ -191,14 +216,33 @@ __global__ __launch_bounds__(kGramMaxWavesPerBlock *kWave) void vg_gram_fused_ke
             for (int ti = 0; ti < T; ti++)
 #pragma unroll
                 for (int tj = ti; tj < T; tj++) {
+                    if (CORNER && ti == 1) continue;  // the corner tile is accumulated by the lanes
                     accA[ti][tj] = mfma_f64_16x16x4(vA[ti], vA[tj], accA[ti][tj]);
                     accB[ti][tj] = mfma_f64_16x16x4(vB[ti], vB[tj], accB[ti][tj]);
                 }
         }
         wave_lds_fence();
     }
-    store_gram<T>(accA, a.gram + (size_t)bA * W * W, W, lane);
-    if (bA + 1 < a.n_blocks) store_gram<T>(accB, a.gram + (size_t)(bA + 1) * W * W, W, lane);
+    store_gram<T, CORNER>(accA, a.gram + (size_t)bA * W * W, W, lane);
+    if (bA + 1 < a.n_blocks) store_gram<T, CORNER>(accB, a.gram + (size_t)(bA + 1) * W * W, W, lane);
+    if (CORNER) {
+        // sum over the 32 lanes of each image (fixed butterfly inside the half-wave), lane 0 of the half stores
+#pragma unroll
+        for (int q = 0; q < kCornerMax * (kCornerMax + 1) / 2; q++)
+#pragma unroll
+            for (int off = 16; off >= 1; off >>= 1) cacc[q] += __shfl_xor(cacc[q], off, kWave);
+        if (sl == 0 && bvalid) {
+            double *g = a.gram + (size_t)b * W * W;
+#pragma unroll
+            for (int r = 0, q = 0; r < kCornerMax; r++)
+#pragma unroll
+                for (int c = r; c < kCornerMax; c++, q++)
+                    if (c < Wc) {
+                        g[(16 + r) * W + 16 + c] = cacc[q];
+                        g[(16 + c) * W + 16 + r] = cacc[q];
+                    }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
