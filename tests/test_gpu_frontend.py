@@ -81,3 +81,58 @@ def test_calib_cli_end_to_end(gpu, tmp_path):
     vals = np.array([float(v) for v in line.split(":")[1].split()])
     assert rel(vals, d["gt_intrinsics"]) < 1e-5                    # printed with 6 significant digits
     assert os.path.exists(tmp_path / "image_error_0.txt")
+
+
+def test_stereo_example_structure(gpu, tmp_path):
+    """the shape of the reference's data/calib_stereo_example.json: two EUCM cameras, a global xiCam12 with a prior,
+    a stereo pose sequence initialised through camera 1 and re-used by camera 2 ("init": "none", chain
+    [xiCam12 inverse, xiCamBoardStereo direct], :51-53,88-91), plus one mono dataset per camera with its own sequence;
+    all four are "images" entries (here with corners_file instead of image files)."""
+    import json
+
+    from visgeom_amd import synthetic as S
+    from visgeom_amd.calibration import GenericCameraCalibration
+
+    st = S.make_stereo(40, sigma=0.0)
+    m1 = S.make_mono("eucm", 25, 6, sigma=0.0, gt=S.GT_EUCM_CAM1)
+    m2 = S.make_mono("eucm", 25, 7, sigma=0.0, gt=S.GT_EUCM_CAM2)
+
+    def corners(name, cam, arr):
+        json.dump([[{"camera": cam, "points": a.tolist()}] for a in arr], open(tmp_path / name, "w"))
+        return name
+
+    obj = {"type": "checkboard", "cols": 12, "rows": 8, "size": 0.1}
+    flags = ["_check_extraction", "show_outliers", "_user_guided", "improve_detection"]
+
+    def entry(cam, init, chain, file):
+        return {"type": "images", "camera": cam, "init": init, "parameters": flags, "object": obj,
+                "transform_chain": [{"name": n, "direct": d} for n, d in chain], "corners_file": file,
+                "images": {"prefix": "/nowhere/", "names": []}}
+
+    root = {
+        "transformations": [{"name": n, "global": False, "constant": False, "prior": False}
+                            for n in ("xiCamBoard1", "xiCamBoard2", "xiCamBoardStereo")] +
+                           [{"name": "xiCam12", "global": True, "constant": False, "prior": True,
+                             "value": (st["gt_xi12"] + 0.005).tolist()}],
+        "cameras": [{"name": "camera1", "type": "eucm", "constant": False, "value": S.INIT["eucm"].tolist()},
+                    {"name": "camera2", "type": "eucm", "constant": False, "value": S.INIT["eucm"].tolist()}],
+        "data": [entry("camera1", "xiCamBoardStereo", [("xiCamBoardStereo", True)], corners("s1.json", "camera1", st["corners1"])),
+                 entry("camera2", "none", [("xiCam12", False), ("xiCamBoardStereo", True)], corners("s2.json", "camera2", st["corners2"])),
+                 entry("camera1", "xiCamBoard1", [("xiCamBoard1", True)], corners("m1.json", "camera1", m1["corners"])),
+                 entry("camera2", "xiCamBoard2", [("xiCamBoard2", True)], corners("m2.json", "camera2", m2["corners"]))]}
+    path = tmp_path / "stereo.json"
+    json.dump(root, open(path, "w"))
+    c = GenericCameraCalibration()
+    c.addResiduals(path)
+    assert c.num_datasets() == 4
+    c.compute(max_num_iterations=200)
+    print("stereo example", c.summary["termination"], c.summary["num_iterations"], c.summary["num_global_columns"])
+    assert c.summary["num_global_columns"] == 18 and c.summary["num_pose_blocks"] == 40 + 25 + 25
+    assert rel(c.intrinsics("camera1"), S.GT_EUCM_CAM1) < 1e-6 and rel(c.intrinsics("camera2"), S.GT_EUCM_CAM2) < 1e-6
+    assert np.max(np.abs(c.transform("xiCam12")[0] - st["gt_xi12"])) < 1e-6
+    assert np.max(np.abs(c.transform("xiCamBoardStereo") - st["gt_poses"])) < 1e-6
+    assert np.max(np.abs(c.transform("xiCamBoard2") - m2["gt_poses"])) < 1e-6
+    for i in range(4):
+        sig, outl = c.writeImageResidual(i, tmp_path / ("image_error_%d.txt" % i), n_images=[40, 40, 25, 25][i])
+        assert np.all(sig < 1e-6) and outl == 0
+    c.close()

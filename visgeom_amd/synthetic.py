@@ -186,12 +186,12 @@ def _perturb(seed, n_images, cols, lo=-0.01, hi=0.01, salt=0, first=0):
     return (lo + (hi - lo) * uniform(seed, stream, k)).reshape(n_images, cols)
 
 
-def make_mono(model, n_images, config_index, sigma=0.1, first_image=0):
+def make_mono(model, n_images, config_index, sigma=0.1, first_image=0, gt=None):
     """Configs 2 / 4: one camera, chain [xiCamBoard DIRECT].  first_image offsets the per-image streams, so a
     rank can generate images [first_image, first_image + n_images) of a larger set (multi-GPU shards)."""
     seed = BASE_SEED + config_index
     board = board_points()
-    gt = GT[model]
+    gt = GT[model] if gt is None else np.asarray(gt, dtype=np.float64)
     poses = make_poses(seed, n_images, [(model, gt, np.eye(3), np.zeros(3))], board, first=first_image)
     X = np.einsum("nij,kj->nki", rodrigues(poses[:, 3:]), board) + poses[:, None, :3]
     uv, ok = project(model, gt, X)
