@@ -118,6 +118,12 @@ int vg_problem_add_transform(vg_problem *p, int is_global, int constant, int cou
 int vg_problem_add_dataset(vg_problem *p, int camera_id, int chain_len, const int *transform_ids,
                            const int *status, int n_points, const double *board, int64_t n_images,
                            const int32_t *image_index, const double *corners, int *dataset_id);
+/* TransformationPrior (include/calibration/calib_cost_functions.h:79-103, .cpp:214-228; parseData :808-829): six
+ * residuals A * [R e_t; R e_r], e = prior^-1 o xi, pulling a transform towards the value it has NOW (the reference
+ * requires the transform to have a prior value and uses it).  stiffness: the 6 diagonal weights.  Global transforms
+ * only (the reference also allows element 0 of a sequence).  Seen by vg_problem_solve, not by the per-dataset
+ * evaluation entries. */
+int vg_problem_add_transformation_prior(vg_problem *p, int transform_id, const double *stiffness);
 /* freezes the layout, uploads everything, allocates per-block frames. */
 int vg_problem_finalize(vg_problem *p);
 

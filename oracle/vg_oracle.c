@@ -761,6 +761,48 @@ long vgo_dataset_gram(int K, int L, int N, long n_blocks, const double *residual
     return n_blocks;
 }
 
+/* TransformationPrior: ctor include/calibration/calib_cost_functions.h:79-103, Evaluate src/.../calib_cost_functions.cpp:214-228 */
+static void inverse_compose(const double a[6], const double b[6], double out[6]) /* transformation.h:90-99 */
+{
+    double q1[4], q2[4], q1inv[4], qres[4];
+    vgo_quat_from_rotvec(a + 3, q1);
+    vgo_quat_from_rotvec(b + 3, q2);
+    q1inv[0] = -q1[0]; q1inv[1] = -q1[1]; q1inv[2] = -q1[2]; q1inv[3] = q1[3];
+    double d[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
+    quat_rotate(q1inv, d, out);
+    quat_mul(q1inv, q2, qres);
+    vgo_quat_to_rotvec(qres, out + 3);
+}
+
+void vgo_transformation_prior(const double stiffness[6], const double xi_prior[6], const double xi[6],
+                              double residual[6], double jac[36])
+{
+    double A[36], R[9], M[9];
+    for (int i = 0; i < 36; i++) A[i] = 0.;
+    for (int i = 0; i < 6; i++) A[6 * i + i] = stiffness[i];
+    vgo_rotation_matrix(xi_prior + 3, R);
+    vgo_inter_omega_rot(xi_prior + 3, M);
+    /* _A.bottomRightCorner<3,3>() = _A.bottomRightCorner<3,3>() * M */
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) {
+            double s = 0.;
+            for (int k = 0; k < 3; k++) s += (r == k ? stiffness[3 + r] : 0.) * M[3 * k + c];
+            A[6 * (3 + r) + 3 + c] = s;
+        }
+    double err[6], e2[6];
+    inverse_compose(xi_prior, xi, err);
+    for (int i = 0; i < 3; i++) {
+        e2[i] = R[3 * i] * err[0] + R[3 * i + 1] * err[1] + R[3 * i + 2] * err[2];
+        e2[3 + i] = R[3 * i] * err[3] + R[3 * i + 1] * err[4] + R[3 * i + 2] * err[5];
+    }
+    for (int i = 0; i < 6; i++) {
+        double s = 0.;
+        for (int k = 0; k < 6; k++) s += A[6 * i + k] * e2[k];
+        residual[i] = s;
+    }
+    if (jac) memcpy(jac, A, sizeof A);
+}
+
 int vgo_max_threads(void)
 {
 #ifdef _OPENMP

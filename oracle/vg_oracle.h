@@ -96,6 +96,11 @@ void vgo_block_gram_fast(int K, int L, int N, const double *residual, const doub
 long vgo_dataset_gram(int K, int L, int N, long n_blocks, const double *residuals, const double *jac_intr,
                       const double *const *jac_member, double *grams, double *sum, int threads);
 
+/* TransformationPrior::Evaluate (calib_cost_functions.h:79-103, .cpp:214-228): residual[6] = A [R e_t; R e_r],
+ * e = xi_prior^-1 o xi; jac (may be NULL) = A, row-major 6x6 (the reference's constant Jacobian). */
+void vgo_transformation_prior(const double stiffness[6], const double xi_prior[6], const double xi[6],
+                              double residual[6], double jac[36]);
+
 int vgo_max_threads(void);
 
 #ifdef __cplusplus

@@ -73,6 +73,8 @@ def lib():
         L.vgo_dataset_gram.restype = ctypes.c_long
         L.vgo_dataset_gram.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_long, _dp, _dp, _dpp, _dp, _dp,
                                        ctypes.c_int]
+        L.vgo_transformation_prior.restype = None
+        L.vgo_transformation_prior.argtypes = [_dp, _dp, _dp, _dp, _dp]
         _lib = L
     return _lib
 
@@ -171,6 +173,14 @@ def dataset_gram(res, jac_intr, jac_members, threads=1, out=None):
     jmp = (_dp * max(L, 1))(*[_ptr(j) for j in jac_members])
     lib().vgo_dataset_gram(K, L, rows // 2, nb, _ptr(res), _ptr(jac_intr), jmp, _ptr(grams), _ptr(total), threads)
     return grams, total
+
+
+def transformation_prior(stiffness, xi_prior, xi):
+    """TransformationPrior::Evaluate -> (residual[6], jacobian[6,6])"""
+    st, xp, x = _c(stiffness), _c(xi_prior), _c(xi)
+    r, J = np.empty(6), np.empty((6, 6))
+    lib().vgo_transformation_prior(_ptr(st), _ptr(xp), _ptr(x), _ptr(r), _ptr(J))
+    return r, J
 
 
 def compose(a, b, inverse=False):

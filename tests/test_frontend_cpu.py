@@ -113,3 +113,34 @@ def test_cli_is_built_and_prints_usage():
     _build.build()
     r = subprocess.run([_build.CLI], capture_output=True, text=True)
     assert r.returncode == 2 and "usage: calib file1.json" in r.stderr
+
+
+def test_transformation_prior_entries(tmp_path):
+    """parseData :808-829: the transform must exist and have a prior value; here it must also be global"""
+    d, path = _write(tmp_path, prior=True)
+
+    def add(r, name="xiRig", with_prior=True, is_global=True):
+        tf = {"name": name, "global": is_global, "prior": with_prior, "constant": False}
+        if with_prior:
+            tf["value"] = [0.1, 0, 0, 0, 0, 0] if is_global else [[0, 0, 1, 0, 0, 0]]
+        r["transformations"].append(tf)
+        r["data"].append({"type": "transformation_prior", "transform": name, "stiffness": [10, 10, 10, 5, 5, 5]})
+
+    _mutate(path, lambda r: add(r))
+    c = GenericCameraCalibration()
+    c.addResiduals(path)
+    c.close()
+    for kw, msg in (({"with_prior": False}, "must have a prior value"), ({"is_global": False}, "sequence transform is not supported")):
+        d, path = _write(tmp_path, prior=True)
+        _mutate(path, lambda r: add(r, **kw))
+        c = GenericCameraCalibration()
+        with pytest.raises(capi.VisgeomError) as e:
+            c.addResiduals(path)
+        assert msg in str(e.value)
+        c.close()
+    d, path = _write(tmp_path, prior=True)
+    _mutate(path, lambda r: r["data"].append({"type": "transformation_prior", "transform": "nope", "stiffness": [1] * 6}))
+    c = GenericCameraCalibration()
+    with pytest.raises(capi.VisgeomError) as e:
+        c.addResiduals(path)
+    assert "has not been declared" in str(e.value)

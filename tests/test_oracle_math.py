@@ -201,3 +201,27 @@ def test_eval_dataset_equals_block_by_block():
         r1, J1 = vgo.eval_block(vgo.MODEL_EUCM, [1, 0], grid, obs[b].reshape(-1, 2), [intr, glob, poses[b]])
         assert np.array_equal(r1, res[b]) and np.array_equal(J1[0], ji[b])
         assert np.array_equal(J1[1], jm[0][b]) and np.array_equal(J1[2], jm[1][b])
+
+
+def test_transformation_prior_block():
+    """TransformationPrior (calib_cost_functions.h:79-103, .cpp:214-228): zero at the prior, A-weighted and rotated
+    relative transform elsewhere, constant Jacobian A = diag(stiffness) with the rotation block times interOmegaRot."""
+    st = np.array([10.0, 20.0, 30.0, 4.0, 5.0, 6.0])
+    xp = np.array([0.2, -0.1, 0.05, 0.3, -0.4, 0.1])
+    r0, J = vgo.transformation_prior(st, xp, xp)
+    assert np.max(np.abs(r0)) < 1e-15
+    M = vgo.inter_omega_rot(xp[3:])
+    A = np.zeros((6, 6))
+    A[:3, :3] = np.diag(st[:3])
+    A[3:, 3:] = np.diag(st[3:]) @ M
+    assert np.max(np.abs(J - A)) < 1e-15
+    x = xp + np.array([0.01, -0.02, 0.005, 0.002, 0.001, -0.003])
+    r, _ = vgo.transformation_prior(st, xp, x)
+    # independent: e = prior^-1 o xi through matrices
+    Rp, Rx = _rodrigues(torch.tensor(xp[3:])).numpy(), _rodrigues(torch.tensor(x[3:])).numpy()
+    et = Rp.T @ (x[:3] - xp[:3])
+    Re = Rp.T @ Rx
+    ang = np.arccos((np.trace(Re) - 1) / 2)
+    er = ang / (2 * np.sin(ang)) * np.array([Re[2, 1] - Re[1, 2], Re[0, 2] - Re[2, 0], Re[1, 0] - Re[0, 1]])
+    ref = A @ np.concatenate([Rp @ et, Rp @ er])
+    assert np.max(np.abs(r - ref)) < 1e-12

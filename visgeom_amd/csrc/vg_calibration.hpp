@@ -7,7 +7,8 @@
 // Differences from the reference, all stated in DESIGN.md section 8:
 //   * "images" datasets need pre-extracted corners ("corners_file", same layout as ir_data's "data_file"): the
 //     corner detector (OpenCV) is out of scope.  "ir_data" is read exactly as the reference reads it.
-//   * odometry / odometry_intrinsic / transformation_prior entries are rejected (other cost functions).
+//   * odometry / odometry_intrinsic entries are rejected (OdometryPrior couples consecutive poses and breaks the
+//     arrow structure the solver relies on); transformation_prior is accepted on global transforms.
 //   * the per-image and global-transform initial refinements use plain least squares (the reference wraps them
 //     in SoftLOneLoss(25) / SoftLOneLoss(1)); the main solve has no loss function in the reference either (:539-564).
 #pragma once
@@ -25,81 +26,16 @@
 
 #include "vg_internal.hpp"
 #include "vg_json.hpp"
+#include "vg_transf_host.hpp"
 
 namespace vgcal {
 
-using Array6d = std::array<double, 6>;  // include/std.h:43
-
-// ------------------------------------------------------------------ host-side Transformation<double> pieces
-inline vg::Quat quat_of(const double *rot)
-{
-    const vg::RotTrig g = vg::rot_trig(rot, false, true);
-    return vg::quat_from_rotvec(rot, g);
-}
-
-// Transformation::compose  transformation.h:80-88
-inline Array6d compose(const Array6d &a, const Array6d &b)
-{
-    const vg::Quat q1 = quat_of(a.data() + 3), q2 = quat_of(b.data() + 3);
-    double rt[3];
-    vg::quat_rotate(q1, b.data(), rt);
-    Array6d r;
-    for (int i = 0; i < 3; i++) r[i] = rt[i] + a[i];
-    vg::quat_to_rotvec(vg::quat_mul(q1, q2), r.data() + 3);
-    return r;
-}
-
-// Transformation::inverseCompose  transformation.h:90-99   (a^-1 o b)
-inline Array6d inverse_compose(const Array6d &a, const Array6d &b)
-{
-    const vg::Quat q1 = quat_of(a.data() + 3), q2 = quat_of(b.data() + 3);
-    const vg::Quat q1inv = {-q1.x, -q1.y, -q1.z, q1.w};
-    const double d[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
-    Array6d r;
-    vg::quat_rotate(q1inv, d, r.data());
-    vg::quat_to_rotvec(vg::quat_mul(q1inv, q2), r.data() + 3);
-    return r;
-}
-
-// Transformation::composeInverse  transformation.h:101-110   (a o b^-1)
-inline Array6d compose_inverse(const Array6d &a, const Array6d &b)
-{
-    const vg::Quat q1 = quat_of(a.data() + 3), q2 = quat_of(b.data() + 3);
-    const vg::Quat q2inv = {-q2.x, -q2.y, -q2.z, q2.w};
-    const vg::Quat qres = vg::quat_mul(q1, q2inv);
-    double rt[3];
-    vg::quat_rotate(qres, b.data(), rt);
-    Array6d r;
-    for (int i = 0; i < 3; i++) r[i] = a[i] - rt[i];
-    vg::quat_to_rotvec(qres, r.data() + 3);
-    return r;
-}
-
-// Transformation::inverse  transformation.h:112-119
-inline Array6d inverse(const Array6d &a)
-{
-    const double neg[3] = {-a[3], -a[4], -a[5]};
-    const vg::RotTrig g = vg::rot_trig(a.data() + 3, true, false);
-    double R[9];
-    vg::rotation_matrix(a.data() + 3, -1., g, R);  // rotMatInv
-    Array6d r;
-    for (int i = 0; i < 3; i++) r[i] = -(R[3 * i] * a[0] + R[3 * i + 1] * a[1] + R[3 * i + 2] * a[2]);
-    r[3] = neg[0]; r[4] = neg[1]; r[5] = neg[2];
-    return r;
-}
-
-// rotationVector(R) = Quaternion(R).toRotationVector()   geometry_core.h:120-124, quaternion.h:52-59
-// (assumes 1 + trace(R) > 0, like the reference: SURVEY D10)
-inline void rotvec_from_matrix(const double *R, double *rot)
-{
-    vg::Quat q;
-    q.w = std::sqrt(1.0 + (R[0] + R[4] + R[8])) / 2.0;
-    const double w4 = 4.0 * q.w;
-    q.x = (R[7] - R[5]) / w4;
-    q.y = (R[2] - R[6]) / w4;
-    q.z = (R[3] - R[1]) / w4;
-    vg::quat_to_rotvec(q, rot);
-}
+using vgth::Array6d;
+using vgth::compose;
+using vgth::compose_inverse;
+using vgth::inverse;
+using vgth::inverse_compose;
+using vgth::rotvec_from_matrix;
 
 // transformFromData  include/json.h:36-67 : 3 [x,y,theta] / 6 [t,rotvec] / 7 [t,quat xyzw] / 12 row-major [R|t]
 inline bool transform_from_values(const std::vector<double> &v, Array6d &out, std::string &err)
@@ -210,6 +146,7 @@ struct vg_calibration {
     std::map<std::string, int> cameraModelMap;
     std::map<std::string, bool> cameraConstantMap;
     std::vector<vgcal::ImageData> dataVec;
+    std::vector<std::pair<std::string, std::array<double, 6>>> transformationPriors;  // (transform, stiffness)
     std::string log;  // what the reference prints to stdout while parsing / solving
 
     vgcal::Array6d &getTransformData(const std::string &name, int idx)  // unified_calibration.h:161-165
@@ -597,8 +534,21 @@ inline void parse_data(vg_calibration *c, const vgjson::Value &root, const std::
             read_corners(data, file, data.cameraName);
             init_transforms(c, data, di.at("init").as_string());
             // addGridResidualBlocks (:514-630) happens when the GPU problem is assembled, in compute()
+        } else if (type == "transformation_prior") {  // :808-829
+            const std::string name = di.at("transform").as_string();
+            if (c->transformInfoMap.find(name) == c->transformInfoMap.end())
+                throw Error{VG_ERR_INVALID_ARGUMENT, name + " has not been declared"};
+            if (!c->transformInfoMap[name].prior) throw Error{VG_ERR_INVALID_ARGUMENT, name + " must have a prior value"};
+            if (!c->transformInfoMap[name].global)
+                throw Error{VG_ERR_INVALID_ARGUMENT, "transformation_prior on a sequence transform is not supported"};
+            const std::vector<double> st = di.at("stiffness").as_vector();
+            if (st.size() != 6) throw Error{VG_ERR_INVALID_ARGUMENT, "stiffness needs 6 values"};
+            std::array<double, 6> a;
+            std::copy(st.begin(), st.end(), a.begin());
+            c->transformationPriors.emplace_back(name, a);
         } else {
-            throw Error{VG_ERR_INVALID_ARGUMENT, "data type \"" + type + "\" is not supported (grid reprojection residuals only)"};
+            throw Error{VG_ERR_INVALID_ARGUMENT, "data type \"" + type + "\" is not supported (grid reprojection residuals and "
+                                                 "transformation priors only)"};
         }
     }
 }
@@ -685,6 +635,8 @@ int vg_calibration_compute(vg_calibration *c, const vg_solve_options *options, v
                                          corners.data(), nullptr)) != VG_OK)
             return bail(rc);
     }
+    for (auto &pr : c->transformationPriors)
+        if ((rc = vg_problem_add_transformation_prior(p, tfId[pr.first], pr.second.data())) != VG_OK) return bail(rc);
     if ((rc = vg_problem_finalize(p)) != VG_OK) return bail(rc);
     vg_solve_summary local;
     if ((rc = vg_problem_solve(p, options, summary ? summary : &local)) != VG_OK) return bail(rc);

@@ -9,6 +9,7 @@
 
 #include "vg_internal.hpp"
 #include "vg_gram.hpp"
+#include "vg_transf_host.hpp"
 
 namespace {
 
@@ -274,6 +275,28 @@ int vg_problem_add_dataset(vg_problem *p, int camera_id, int chain_len, const in
     d.h_obs.assign(corners, corners + (size_t)n_images * 2 * n_points);
     p->dss.push_back(std::move(d));
     if (dataset_id) *dataset_id = (int)p->dss.size() - 1;
+    return VG_OK;
+}
+
+int vg_problem_add_transformation_prior(vg_problem *p, int transform_id, const double *stiffness)
+{
+    if (!p || !stiffness) return fail(VG_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (p->finalized) return fail(VG_ERR_STATE, "problem already finalized");
+    if (transform_id < 0 || transform_id >= (int)p->tfs.size()) return fail(VG_ERR_INVALID_ARGUMENT, "transform id out of range");
+    const Transform &t = p->tfs[transform_id];
+    if (!t.global) return fail(VG_ERR_INVALID_ARGUMENT, "transformation priors are supported on global transforms only");
+    vgi::Prior pr;
+    pr.tf = transform_id;
+    for (int k = 0; k < 6; k++) pr.xi[k] = t.init[k];
+    const vg::RotTrig g = vg::rot_trig(pr.xi + 3, true, true);
+    vg::rotation_matrix(pr.xi + 3, 1., g, pr.R);   // _R(_xiPrior.rotMat())
+    double M[9];
+    vg::inter_omega_rot(pr.xi + 3, g, M);          // interOmegaRot(_xiPrior.rot())
+    for (int k = 0; k < 36; k++) pr.A[k] = 0.;
+    for (int k = 0; k < 3; k++) pr.A[6 * k + k] = stiffness[k];
+    for (int r = 0; r < 3; r++)                    // bottomRightCorner = diag(stiffness[3..5]) * M
+        for (int c = 0; c < 3; c++) pr.A[6 * (3 + r) + 3 + c] = stiffness[3 + r] * M[3 * r + c];
+    p->priors.push_back(pr);
     return VG_OK;
 }
 

@@ -55,6 +55,14 @@ struct Dataset {
     vg::ChainDesc chain;
 };
 
+// TransformationPrior block (include/calibration/calib_cost_functions.h:79-103, .cpp:214-228) on a global transform
+struct Prior {
+    int tf = -1;
+    double A[36];  // row-major; diag(stiffness) with the rotation part multiplied by interOmegaRot(prior rot)
+    double R[9];   // rotMat of the prior
+    double xi[6];  // the prior value
+};
+
 }  // namespace vgi
 
 struct vg_problem {
@@ -64,6 +72,7 @@ struct vg_problem {
     std::vector<vgi::Camera> cams;
     std::vector<vgi::Transform> tfs;
     std::vector<vgi::Dataset> dss;
+    std::vector<vgi::Prior> priors;
     int64_t n_params = 0;
     double *d_params = nullptr;
     vg::PrepDataset *d_prep = nullptr;  // one descriptor per non-empty dataset (vg_chain_prep_multi_kernel)

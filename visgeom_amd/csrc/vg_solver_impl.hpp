@@ -10,6 +10,7 @@
 
 #include "vg_internal.hpp"
 #include "vg_solver.hpp"
+#include "vg_transf_host.hpp"
 
 using vgi::fail;
 
@@ -330,6 +331,39 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
                    : fail(VG_ERR_STATE, "allreduce callback failed");
     };
 
+    // TransformationPrior blocks live on the host: r = A [R e_t; R e_r], e = prior^-1 o xi, Jacobian = A
+    // (calib_cost_functions.cpp:214-228).  Added AFTER the all-reduce, identically on every rank.
+    auto add_priors = [&](const std::vector<double> &xg_vals, std::vector<double> &Uo, std::vector<double> &go, double &c2) {
+        for (const vgi::Prior &pr : p->priors) {
+            const int g0 = tf_goff[pr.tf];
+            vgth::Array6d prior, xi;
+            for (int k = 0; k < 6; k++) { prior[k] = pr.xi[k]; xi[k] = xg_vals[g0 + k]; }
+            const vgth::Array6d e = vgth::inverse_compose(prior, xi);
+            double er[6], r[6];
+            for (int k = 0; k < 3; k++) {
+                er[k] = pr.R[3 * k] * e[0] + pr.R[3 * k + 1] * e[1] + pr.R[3 * k + 2] * e[2];
+                er[3 + k] = pr.R[3 * k] * e[3] + pr.R[3 * k + 1] * e[4] + pr.R[3 * k + 2] * e[5];
+            }
+            for (int k = 0; k < 6; k++) {
+                r[k] = 0.;
+                for (int c2i = 0; c2i < 6; c2i++) r[k] += pr.A[6 * k + c2i] * er[c2i];
+            }
+            for (int a2 = 0; a2 < 6; a2++) {
+                for (int b2 = 0; b2 < 6; b2++) {
+                    double h = 0.;
+                    for (int k = 0; k < 6; k++) h += pr.A[6 * k + a2] * pr.A[6 * k + b2];
+                    Uo[(size_t)(g0 + a2) * G + g0 + b2] += h;
+                }
+                double gsum = 0.;
+                for (int k = 0; k < 6; k++) gsum += pr.A[6 * k + a2] * r[k];
+                go[g0 + a2] += gsum;
+            }
+            for (int k = 0; k < 6; k++) c2 += r[k] * r[k];
+        }
+    };
+    // values of the global columns at the starting point
+    for (int a2 = 0; a2 < G; a2++) VG_HIP(hipMemcpy(&h_xg[a2], p->d_params + gcol_param[a2], sizeof(double), hipMemcpyDeviceToHost));
+
     DevBuf<double> *cur = gramA, *cand = gramB;
     vg::SolveDatasetDev *ds_cur = d_dsA.p, *ds_cand = d_dsB.p;
     double cost2 = 0., cost2_c = 0.;
@@ -342,6 +376,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
         std::copy(pack.begin(), pack.begin() + (size_t)G * G, U.begin());
         std::copy(pack.begin() + (size_t)G * G, pack.begin() + (size_t)G * G + G, gg.begin());
         cost2 = pack.back();
+        add_priors(h_xg, U, gg, cost2);
     }
     double radius = opt.initial_trust_region_radius, decrease_factor = 2.;
     int iter = 0, n_success = 0, term = VG_TERM_NO_CONVERGENCE;
@@ -482,6 +517,14 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
                 // pose part of the gradient max-norm is replaced by its (summable) 2-norm, an upper bound:
                 // the gradient test can only fire later than Ceres' max-norm test, never earlier.
                 if (opt.allreduce) gmax_p = std::sqrt(gp2);
+                if (!p->priors.empty()) {  // global values of the candidate: clamp(x + dg), as vg_apply_step_kernel does
+                    std::vector<double> xg_c(G);
+                    for (int a2 = 0; a2 < G; a2++) {
+                        const double v = h_xg[a2] + dg[a2], l2 = lo[(size_t)gcol_param[a2]], h2 = hi[(size_t)gcol_param[a2]];
+                        xg_c[a2] = v < l2 ? l2 : (v > h2 ? h2 : v);
+                    }
+                    add_priors(xg_c, Uc, ggc, cost2_c);
+                }
             }
             double gdg = 0., ddg = 0., dg2 = 0., gmax_g = 0.;
             for (int a2 = 0; a2 < G; a2++) {

@@ -150,6 +150,13 @@ class CalibrationProblem:
                               "K": self.cameras[camera]["K"], "L": len(chain)})
         return did.value
 
+    def add_transformation_prior(self, transform, stiffness):
+        """TransformationPrior block (calib_cost_functions.h:79-103) pulling a global transform towards its current value"""
+        v = _c(stiffness)
+        if v.size != 6:
+            raise ValueError("stiffness needs 6 values")
+        capi.check(self._lib.vg_problem_add_transformation_prior(self._h, transform, _ptr(v)))
+
     def finalize(self):
         capi.check(self._lib.vg_problem_finalize(self._h))
         self.num_parameters = self._lib.vg_problem_num_parameters(self._h)
