@@ -193,6 +193,30 @@ def main():
                 "avg_launch_ms": emit_ms, "event_pair_per_launch_ms": float(np.mean(per_launch_ms)),
                 "event_pair_median_ms": float(np.median(per_launch_ms))}
 
+    # ---- PCIe-inclusive rate of the same step when the caller wants the rows in HOST memory (the Ceres
+    # EvaluationCallback route): kernels + D2H of residuals and all Jacobian blocks into
+    # pinned buffers.  Reported for DESIGN.md; it is never `value`.
+    pcie = None
+    try:
+        h_res = torch.empty(res.shape, dtype=torch.float64).pin_memory()
+        h_ji = torch.empty(ji.shape, dtype=torch.float64).pin_memory()
+        h_jm = [torch.empty(t.shape, dtype=torch.float64).pin_memory() for t in jm]
+        reps = max(3, a.steps // 20)
+        p.prepare()
+        p.evaluate_dataset_to_host(ds, h_res, h_ji, h_jm)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            p.prepare()
+            p.evaluate_dataset_to_host(ds, h_res, h_ji, h_jm)
+        el = time.perf_counter() - t0
+        assert torch.equal(h_res, res.cpu())
+        pcie = {"evals_per_s": n_obs * reps / el, "ms_per_step": el / reps * 1e3,
+                "host_GBps": (16 + 16 * (K + 6)) * n_obs * reps / el / 1e9}
+        del h_res, h_ji, h_jm
+    except Exception as e:
+        pcie = {"error": repr(e)}
+
     # ---- measured streaming rates on this box, same 16 B/lane pattern (context for the fraction) ----
     from visgeom_amd import capi
     import ctypes
@@ -314,11 +338,12 @@ def main():
         "config": {"workload": "%s mono, %d images x %d corners (8x12 board) per GPU, chain [xiCamBoard DIRECT], "
                                "residual + all Jacobian blocks (K=%d intrinsics + 6 pose) emitted to HBM in Ceres "
                                "block layout; step = chain-prep kernel + emit kernel" % (a.model.upper(), n_img, N, K),
-                   "images_per_gpu": n_img, "corners_per_image": N, "model": a.model, "chain": ["DIRECT"],
+                   "images_per_gpu": n_img, "corners_per_image": N, "camera_model": a.model, "chain": ["DIRECT"],
                    "seed": int(d["seed"]), "sharding": "images sharded over ranks, no data-path collective"},
         "roofline": roofline,
         "jtj": jtj,
         "solve": solve,
+        "pcie_inclusive": pcie,
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(d, a.model, a.cpu_seconds)

@@ -155,6 +155,12 @@ int vg_problem_prepare(vg_problem *p);
 int vg_dataset_evaluate(vg_problem *p, int dataset_id, double *residuals, double *jac_intr,
                         double *const *jac_member);
 int vg_problem_synchronize(vg_problem *p);
+/* The same evaluation delivered to HOST memory (what a Ceres EvaluationCallback needs):
+ * runs kernel 2 into library-owned device buffers, copies the Ceres-layout arrays to the given host pointers
+ * (pinned memory recommended; any of the Jacobian pointers may be NULL) and synchronises.  Block b of the dataset
+ * is then at  residuals + b*2N,  jac_intr + b*2N*K,  jac_member[l] + b*2N*6. */
+int vg_dataset_evaluate_to_host(vg_problem *p, int dataset_id, double *residuals, double *jac_intr,
+                                double *const *jac_member);
 
 /* number of failed projections (1e15 residual pairs) seen by the last vg_dataset_evaluate of that
  * dataset; synchronises the stream.  Not in the reference. */

@@ -355,3 +355,25 @@ def test_full_size_10k_images_properties_and_oracle(vg, S):
     jd = Ji @ dp[:6] + np.einsum("brc,bc->br", Jp, dp[6:].reshape(n, 6))
     assert np.max(np.abs(fd - jd)) <= 1e-5 * np.max(np.abs(jd))
     p.close()
+
+
+def test_evaluate_to_host_delivers_the_same_rows(vg, S):
+    """the EvaluationCallback route: rows copied to (pinned) host memory are the device rows, NULL blocks skipped"""
+    import torch
+
+    d = S.make_mono("ucm", 50, 2)
+    p = vg.CalibrationProblem(0)
+    cam = p.add_camera("ucm", d["init_intrinsics"])
+    glob = p.add_transform(True, [0.01, 0.02, -0.01, 0.01, -0.02, 0.03])
+    seq = p.add_transform(False, d["init_poses"])
+    ds = p.add_dataset(cam, [(glob, 1), (seq, 0)], d["board"], d["corners"])
+    p.finalize()
+    res, ji, jm = p.alloc_outputs(ds)
+    p.prepare()
+    p.evaluate_dataset(ds, res, ji, jm)
+    h_res = torch.empty(res.shape, dtype=torch.float64).pin_memory()
+    h_ji = np.empty(tuple(ji.shape))                      # pageable numpy memory works too
+    h_jm = [None, torch.empty(jm[1].shape, dtype=torch.float64).pin_memory()]
+    p.evaluate_dataset_to_host(ds, h_res, h_ji, h_jm)
+    assert torch.equal(h_res, res.cpu()) and np.array_equal(h_ji, ji.cpu().numpy()) and torch.equal(h_jm[1], jm[1].cpu())
+    p.close()

@@ -87,6 +87,7 @@ SIGNATURES = {
     "vg_problem_prepare": (ctypes.c_int, [_vp]),
     "vg_dataset_evaluate": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vpp]),
     "vg_problem_synchronize": (ctypes.c_int, [_vp]),
+    "vg_dataset_evaluate_to_host": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vpp]),
     "vg_dataset_failed_count": (ctypes.c_int, [_vp, ctypes.c_int, _i64p]),
     "vg_dataset_gram_width": (ctypes.c_int, [_vp, ctypes.c_int]),
     "vg_dataset_gram_fused": (ctypes.c_int, [_vp, ctypes.c_int, _vp]),

@@ -51,6 +51,13 @@ void free_dataset(Dataset &d)
     if (d.d_failed) (void)hipFree(d.d_failed);
     if (d.d_partials) (void)hipFree(d.d_partials);
     d.d_partials = nullptr;
+    if (d.d_out_res) (void)hipFree(d.d_out_res);
+    if (d.d_out_ji) (void)hipFree(d.d_out_ji);
+    d.d_out_res = d.d_out_ji = nullptr;
+    for (int l = 0; l < vg::kMaxChain; l++) {
+        if (d.d_out_jm[l]) (void)hipFree(d.d_out_jm[l]);
+        d.d_out_jm[l] = nullptr;
+    }
     d.d_board = d.d_obs = d.d_frames = nullptr;
     d.d_seq = nullptr;
     d.d_failed = nullptr;
@@ -481,6 +488,34 @@ int vg_dataset_evaluate(vg_problem *p, int dataset_id, double *residuals, double
         }
         if (rc != VG_OK) return rc;
     }
+    return VG_OK;
+}
+
+int vg_dataset_evaluate_to_host(vg_problem *p, int dataset_id, double *residuals, double *jac_intr, double *const *jac_member)
+{
+    int rc = valid_dataset(p, dataset_id);
+    if (rc != VG_OK) return rc;
+    if (!p->finalized) return fail(VG_ERR_STATE, "problem not finalized");
+    Dataset &d = p->dss[dataset_id];
+    if (!d.n_blocks) return VG_OK;
+    if (!residuals) return fail(VG_ERR_INVALID_ARGUMENT, "residuals is NULL");
+    VG_HIP(hipSetDevice(p->device));
+    const size_t rows = (size_t)d.n_blocks * 2 * d.N;
+    const int K = p->cams[d.camera].K;
+    if (!d.d_out_res) VG_HIP(hipMalloc(&d.d_out_res, sizeof(double) * rows));
+    if (jac_intr && !d.d_out_ji) VG_HIP(hipMalloc(&d.d_out_ji, sizeof(double) * rows * K));
+    double *jm[vg::kMaxChain] = {nullptr};
+    for (int l = 0; l < d.L; l++)
+        if (jac_member && jac_member[l]) {
+            if (!d.d_out_jm[l]) VG_HIP(hipMalloc(&d.d_out_jm[l], sizeof(double) * rows * 6));
+            jm[l] = d.d_out_jm[l];
+        }
+    if ((rc = vg_dataset_evaluate(p, dataset_id, d.d_out_res, jac_intr ? d.d_out_ji : nullptr, jm)) != VG_OK) return rc;
+    VG_HIP(hipMemcpyAsync(residuals, d.d_out_res, sizeof(double) * rows, hipMemcpyDeviceToHost, p->stream));
+    if (jac_intr) VG_HIP(hipMemcpyAsync(jac_intr, d.d_out_ji, sizeof(double) * rows * K, hipMemcpyDeviceToHost, p->stream));
+    for (int l = 0; l < d.L; l++)
+        if (jm[l]) VG_HIP(hipMemcpyAsync(jac_member[l], jm[l], sizeof(double) * rows * 6, hipMemcpyDeviceToHost, p->stream));
+    VG_HIP(hipStreamSynchronize(p->stream));
     return VG_OK;
 }
 

@@ -49,6 +49,8 @@ struct Dataset {
     double *d_board = nullptr, *d_obs = nullptr, *d_frames = nullptr;
     int32_t *d_seq = nullptr;
     unsigned long long *d_failed = nullptr;
+    double *d_out_res = nullptr, *d_out_ji = nullptr;  // device staging of vg_dataset_evaluate_to_host
+    double *d_out_jm[vg::kMaxChain] = {nullptr};
     double *d_partials = nullptr;  // [ceil(n_blocks / kSlab)][W*W] workspace of vg_dataset_gram_sum
     unsigned long long epoch = 0;  // evaluation counter, tags d_failed
     int frame_stride = 0;

@@ -273,6 +273,21 @@ class CalibrationProblem:
         out["termination"] = capi.TERMINATION.get(summ.termination, str(summ.termination))
         return out
 
+    def evaluate_dataset_to_host(self, d, res, jac_intr=None, jac_member=None):
+        """kernel 2 + D2H of the Ceres-layout arrays into host tensors / arrays (pinned torch tensors recommended);
+        what an EvaluationCallback hands to the per-block Evaluate copies."""
+        L = self.datasets[d]["L"]
+
+        def ptr(t):
+            return t.data_ptr() if hasattr(t, "data_ptr") else t.ctypes.data
+
+        jm = (ctypes.c_void_p * max(L, 1))()
+        for l in range(L):
+            t = jac_member[l] if jac_member else None
+            jm[l] = ptr(t) if t is not None else None
+        capi.check(self._lib.vg_dataset_evaluate_to_host(self._h, d, ctypes.c_void_p(ptr(res)),
+                                                         ctypes.c_void_p(ptr(jac_intr)) if jac_intr is not None else None, jm))
+
     def synchronize(self):
         capi.check(self._lib.vg_problem_synchronize(self._h))
 
