@@ -105,6 +105,10 @@ def main():
             raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (a.gpus, a.gpus))
         a.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    # VG_BENCH_BACKEND=gloo lets the multi-rank control flow be rehearsed with several ranks on ONE GPU
+    # (RCCL refuses two ranks per device); the driver's runs use the default, nccl = RCCL over xGMI.
+    backend = os.environ.get("VG_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -112,7 +116,20 @@ def main():
 
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+
+    def all_reduce_(t, op=None):
+        # RCCL reduces device tensors in place; the gloo rehearsal path goes through host memory
+        kw = {} if op is None else {"op": op}
+        if backend == "nccl":
+            dist.all_reduce(t, **kw)
+        else:
+            h = t.cpu()
+            dist.all_reduce(h, **kw)
+            t.copy_(h)
 
     from visgeom_amd import CalibrationProblem, synthetic
 
@@ -149,7 +166,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        all_reduce_(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert p.failed_count(ds) == 0
     value = world * n_obs * a.steps / elapsed
@@ -254,7 +271,7 @@ def main():
     def finish():
         p.gram_sum(ds, gram, gsum)
         if dist is not None:
-            dist.all_reduce(gsum)
+            all_reduce_(gsum)
 
     def it_fused():
         p.prepare()
@@ -282,7 +299,7 @@ def main():
         el = time.perf_counter() - t0
         if dist is not None:
             t = torch.tensor([el], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            all_reduce_(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         return el / n * 1e3
 
