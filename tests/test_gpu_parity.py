@@ -377,3 +377,26 @@ def test_evaluate_to_host_delivers_the_same_rows(vg, S):
     p.evaluate_dataset_to_host(ds, h_res, h_ji, h_jm)
     assert torch.equal(h_res, res.cpu()) and np.array_equal(h_ji, ji.cpu().numpy()) and torch.equal(h_jm[1], jm[1].cpu())
     p.close()
+
+
+def test_chunked_launches_for_huge_datasets(vg, S, monkeypatch):
+    """datasets beyond 2^30 observations are evaluated in several launches of whole images; the chunking is
+    exercised here by lowering the per-launch limit (VG_MAX_OBS_PER_LAUNCH) instead of allocating 240 GB"""
+    import torch
+
+    d = S.make_mono("eucm", 37, 2)
+    p = vg.CalibrationProblem(0)
+    cam = p.add_camera("eucm", d["init_intrinsics"])
+    seq = p.add_transform(False, d["init_poses"])
+    ds = p.add_dataset(cam, [(seq, 0)], d["board"], d["corners"])
+    p.finalize()
+    ref = p.alloc_outputs(ds)
+    out = p.alloc_outputs(ds)
+    p.prepare()
+    p.evaluate_dataset(ds, *ref)
+    p.synchronize()
+    monkeypatch.setenv("VG_MAX_OBS_PER_LAUNCH", str(5 * 96 + 17))   # 5 images per launch -> 8 launches
+    p.evaluate_dataset(ds, *out)
+    p.synchronize()
+    assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1]) and torch.equal(out[2][0], ref[2][0])
+    p.close()

@@ -463,7 +463,9 @@ int vg_dataset_evaluate(vg_problem *p, int dataset_id, double *residuals, double
         if (jac_member && jac_member[l]) want_jac = true;
 
     // 32-bit observation indices inside a launch: chunk very large datasets by whole images
-    const int64_t max_blocks_per_launch = ((int64_t)1 << 30) / d.N > 0 ? ((int64_t)1 << 30) / d.N : 1;
+    int64_t max_obs = (int64_t)1 << 30;
+    if (const char *e = getenv("VG_MAX_OBS_PER_LAUNCH")) max_obs = atoll(e) > 0 ? atoll(e) : max_obs;  // test hook for the chunked path
+    const int64_t max_blocks_per_launch = max_obs / d.N > 0 ? max_obs / d.N : 1;
     for (int64_t b0 = 0; b0 < d.n_blocks; b0 += max_blocks_per_launch) {
         const int64_t nb = d.n_blocks - b0 < max_blocks_per_launch ? d.n_blocks - b0 : max_blocks_per_launch;
         vg::EmitArgs a;
