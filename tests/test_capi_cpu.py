@@ -135,3 +135,21 @@ def test_solve_option_defaults_mirror_the_reference(lib):
     # Solver::Options of GenericCameraCalibration::compute, unified_calibration.cpp:42-52
     assert (o.max_num_iterations, o.function_tolerance, o.gradient_tolerance, o.parameter_tolerance) == (1000, 1e-15, 1e-15, 1e-15)
     assert o.initial_trust_region_radius == 1e4 and o.use_bounds == 1 and not o.allreduce
+
+
+def test_header_is_plain_c99(tmp_path):
+    """the boundary is a C ABI: the header must compile as C99 (no C++-isms), and a C program must link against
+    the shared library"""
+    from visgeom_amd import _build
+
+    src = tmp_path / "use.c"
+    src.write_text('#include "visgeom_amd.h"\n#include <stdio.h>\n'
+                   "int main(void) { vg_solve_options o; vg_solve_options_init(&o);\n"
+                   '  printf("%d %d %d\\n", vg_abi_version(), vg_num_intrinsics(VG_MODEL_MEI), o.max_num_iterations);\n'
+                   "  return 0; }\n")
+    exe = tmp_path / "use"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           str(src), "-o", str(exe), "-L", _build.LIB_DIR, "-lvisgeom_amd",
+                           "-Wl,-rpath," + _build.LIB_DIR, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.check_output([str(exe)], text=True).split()
+    assert out == ["1", "10", "1000"]
