@@ -124,6 +124,20 @@ int vg_problem_add_dataset(vg_problem *p, int camera_id, int chain_len, const in
  * only (the reference also allows element 0 of a sequence).  Seen by vg_problem_solve, not by the per-dataset
  * evaluation entries. */
 int vg_problem_add_transformation_prior(vg_problem *p, int transform_id, const double *stiffness);
+/* OdometryPrior (include/calibration/calib_cost_functions.h:64-77, .cpp:119-212; parseData :743-807): six residuals
+ * between elements `index` and `index + 1` of a SEQUENCE transform, built from the two odometry poses xi1, xi2 and
+ * the relative error model (err_v, err_w, lambda).  These blocks couple consecutive poses: the solver eliminates such
+ * a sequence as a block-tridiagonal system on the host (fine for the few-hundred-pose odometry sets the reference
+ * targets; not available together with a multi-rank all-reduce). */
+int vg_problem_add_odometry_prior(vg_problem *p, int transform_id, int64_t index, double err_v, double err_w,
+                                  double lambda, const double *xi1, const double *xi2);
+/* Host-only evaluation of one OdometryPrior block, exported so the block can be checked without a solve:
+ * constructor arguments (err_v, err_w, lambda, odometry poses xi1_odom / xi2_odom) + the two current poses ->
+ * residual[6], J1[36], J2[36] (row-major; either Jacobian may be NULL). */
+int vg_odometry_prior_evaluate(double err_v, double err_w, double lambda, const double *xi1_odom, const double *xi2_odom,
+                               const double *xi1, const double *xi2, double *residual, double *J1, double *J2);
+/* SetParameterBlockConstant on ONE element of a sequence ("anchor": true, :803-806). */
+int vg_problem_set_pose_constant(vg_problem *p, int transform_id, int64_t index);
 /* freezes the layout, uploads everything, allocates per-block frames. */
 int vg_problem_finalize(vg_problem *p);
 

@@ -803,6 +803,122 @@ void vgo_transformation_prior(const double stiffness[6], const double xi_prior[6
     if (jac) memcpy(jac, A, sizeof A);
 }
 
+/* ------------------------------------------------------------------------------------------
+ * OdometryPrior (calibration version): ctor src/calibration/calib_cost_functions.cpp:119-167,
+ * Evaluate :171-212, declaration include/calibration/calib_cost_functions.h:64-77
+ * ---------------------------------------------------------------------------------------- */
+static void mat3_inverse(const double M[9], double I[9]) /* Eigen's 3x3 inverse: adjugate / determinant */
+{
+    const double c00 = M[4] * M[8] - M[5] * M[7], c01 = M[5] * M[6] - M[3] * M[8], c02 = M[3] * M[7] - M[4] * M[6];
+    const double det = M[0] * c00 + M[1] * c01 + M[2] * c02;
+    const double id = 1. / det;
+    I[0] = c00 * id; I[1] = (M[2] * M[7] - M[1] * M[8]) * id; I[2] = (M[1] * M[5] - M[2] * M[4]) * id;
+    I[3] = c01 * id; I[4] = (M[0] * M[8] - M[2] * M[6]) * id; I[5] = (M[2] * M[3] - M[0] * M[5]) * id;
+    I[6] = c02 * id; I[7] = (M[1] * M[6] - M[0] * M[7]) * id; I[8] = (M[0] * M[4] - M[1] * M[3]) * id;
+}
+
+void vgo_odometry_prior_init(double errV, double errW, double lambda, const double xi1[6], const double xi2[6],
+                             double zetaPrior[6], double A[36])
+{
+    inverse_compose(xi1, xi2, zetaPrior); /* _zetaPrior(xi1.inverseCompose(xi2)) */
+    const double MIN_SIGMA_V = 0.01, MIN_SIGMA_W = 0.01, MIN_DELTA = 0.01, MIN_L = 0.01;
+    const double nr = norm3(zetaPrior + 3), nt = norm3(zetaPrior);
+    const double delta = nr > MIN_DELTA ? nr : MIN_DELTA;
+    const double l = nt > MIN_L ? nt : MIN_L;
+    const double delta2 = delta / 2., l2 = l / 2.;
+    const double s = sin(delta2), c = cos(delta2);
+    const double dfdu[6] = {c, l2 * s, -s, l2 * c, 0, 1}; /* 3x2 row-major */
+    double Cu0 = errV * errV * l * l, Cu1 = errW * errW * delta * delta;
+    if (Cu0 < MIN_SIGMA_V * MIN_SIGMA_V) Cu0 = MIN_SIGMA_V * MIN_SIGMA_V;
+    if (Cu1 < MIN_SIGMA_W * MIN_SIGMA_W) Cu1 = MIN_SIGMA_W * MIN_SIGMA_W;
+    double Cx[9], CxInv[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+            Cx[3 * i + j] = dfdu[2 * i] * Cu0 * dfdu[2 * j] + dfdu[2 * i + 1] * Cu1 * dfdu[2 * j + 1] + (i == j ? lambda * lambda : 0.);
+    mat3_inverse(Cx, CxInv);
+    /* Eigen::LLT<Matrix3d>(CxInv).matrixU(): CxInv = L L^T, U = L^T */
+    double L[9] = {0};
+    for (int r = 0; r < 3; r++)
+        for (int cc = 0; cc <= r; cc++) {
+            double v = CxInv[3 * r + cc];
+            for (int k = 0; k < cc; k++) v -= L[3 * r + k] * L[3 * cc + k];
+            L[3 * r + cc] = (r == cc) ? sqrt(v) : v / L[3 * cc + cc];
+        }
+    double U[9];
+    for (int r = 0; r < 3; r++)
+        for (int cc = 0; cc < 3; cc++) U[3 * r + cc] = L[3 * cc + r];
+    for (int i = 0; i < 36; i++) A[i] = 0.;
+    A[0] = U[0]; A[1] = U[1]; A[6] = U[3]; A[7] = U[4]; /* _A.topLeftCorner<2,2>() = U.topLeftCorner<2,2>() */
+    A[5] = U[2]; A[11] = U[5];                          /* _A.topRightCorner<2,1>() = U.topRightCorner<2,1>(): column 5 of the 6x6 */
+    A[14] = 1. / lambda;                                /* _A(2,2) */
+    A[21] = 1. / lambda; A[28] = 1. / lambda; A[35] = U[8]; /* bottomRightCorner<3,3>() = diag(1/lambda, 1/lambda, U(2,2)) */
+}
+
+/* 6x6 row-major blocks: out = [[Ra, 0],[0, Rb]] */
+static void blockdiag6(const double Ra[9], const double Rb[9], double out[36])
+{
+    for (int i = 0; i < 36; i++) out[i] = 0.;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            out[6 * i + j] = Ra[3 * i + j];
+            out[6 * (3 + i) + 3 + j] = Rb[3 * i + j];
+        }
+}
+
+static void mat6_mul(const double A[36], const double B[36], double C[36])
+{
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j < 6; j++) {
+            double s = 0.;
+            for (int k = 0; k < 6; k++) s += A[6 * i + k] * B[6 * k + j];
+            C[6 * i + j] = s;
+        }
+}
+
+void vgo_odometry_prior_eval(const double zetaPrior[6], const double A[36], const double xi1[6], const double xi2[6],
+                             double residual[6], double J1[36], double J2[36])
+{
+    double zeta[6], err[6];
+    inverse_compose(xi1, xi2, zeta);
+    inverse_compose(zetaPrior, zeta, err);
+    for (int i = 0; i < 6; i++) {
+        double s = 0.;
+        for (int k = 0; k < 6; k++) s += A[6 * i + k] * err[k];
+        residual[i] = s;
+    }
+    if (J1) {
+        double n1[3] = {-xi1[3], -xi1[4], -xi1[5]}, R10[9], M[9], RM[9], J1m[36];
+        vgo_rotation_matrix(n1, R10);      /* xi1.rotMatInv() */
+        vgo_inter_omega_rot(xi1 + 3, M);
+        mat3_mul(R10, M, RM);              /* R10 * interOmegaRot(xi1.rot()) */
+        blockdiag6(R10, RM, J1m);
+        /* TT = zeta.screwTransfInv(): [[R, -R hat(t)],[0, R]], R = zeta.rotMatInv()   transformation.h:234-243 */
+        double nz[3] = {-zeta[3], -zeta[4], -zeta[5]}, R[9], H[9], RH[9], TT[36];
+        vgo_rotation_matrix(nz, R);
+        hat_(zeta, H);
+        mat3_mul(R, H, RH);
+        for (int i = 0; i < 36; i++) TT[i] = 0.;
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) {
+                TT[6 * i + j] = R[3 * i + j];
+                TT[6 * i + 3 + j] = -RH[3 * i + j];
+                TT[6 * (3 + i) + 3 + j] = R[3 * i + j];
+            }
+        double T1[36], T2[36];
+        mat6_mul(A, TT, T1);
+        mat6_mul(T1, J1m, T2);
+        for (int i = 0; i < 36; i++) J1[i] = -T2[i]; /* jac = -_A * TT * J1 */
+    }
+    if (J2) {
+        double n2[3] = {-xi2[3], -xi2[4], -xi2[5]}, R20[9], M[9], RM[9], J2m[36];
+        vgo_rotation_matrix(n2, R20);
+        vgo_inter_omega_rot(xi2 + 3, M);
+        mat3_mul(R20, M, RM);
+        blockdiag6(R20, RM, J2m);
+        mat6_mul(A, J2m, J2); /* jac = _A * J2 */
+    }
+}
+
 int vgo_max_threads(void)
 {
 #ifdef _OPENMP

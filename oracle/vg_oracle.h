@@ -101,6 +101,13 @@ long vgo_dataset_gram(int K, int L, int N, long n_blocks, const double *residual
 void vgo_transformation_prior(const double stiffness[6], const double xi_prior[6], const double xi[6],
                               double residual[6], double jac[36]);
 
+/* OdometryPrior (calibration version): constructor (calib_cost_functions.cpp:119-167) -> zetaPrior[6], A[36]
+ * (row-major), and Evaluate (:171-212) -> residual[6], J1 / J2 [36] row-major (either may be NULL). */
+void vgo_odometry_prior_init(double errV, double errW, double lambda, const double xi1[6], const double xi2[6],
+                             double zetaPrior[6], double A[36]);
+void vgo_odometry_prior_eval(const double zetaPrior[6], const double A[36], const double xi1[6], const double xi2[6],
+                             double residual[6], double J1[36], double J2[36]);
+
 int vgo_max_threads(void);
 
 #ifdef __cplusplus

@@ -75,6 +75,10 @@ def lib():
                                        ctypes.c_int]
         L.vgo_transformation_prior.restype = None
         L.vgo_transformation_prior.argtypes = [_dp, _dp, _dp, _dp, _dp]
+        L.vgo_odometry_prior_init.restype = None
+        L.vgo_odometry_prior_init.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_double, _dp, _dp, _dp, _dp]
+        L.vgo_odometry_prior_eval.restype = None
+        L.vgo_odometry_prior_eval.argtypes = [_dp, _dp, _dp, _dp, _dp, _dp, _dp]
         _lib = L
     return _lib
 
@@ -181,6 +185,22 @@ def transformation_prior(stiffness, xi_prior, xi):
     r, J = np.empty(6), np.empty((6, 6))
     lib().vgo_transformation_prior(_ptr(st), _ptr(xp), _ptr(x), _ptr(r), _ptr(J))
     return r, J
+
+
+class OdometryPrior:
+    """OdometryPrior of the calibration library (calib_cost_functions.h:64-77)"""
+
+    def __init__(self, errV, errW, lam, xi1, xi2):
+        self.zeta = np.empty(6)
+        self.A = np.empty((6, 6))
+        a, b = _c(xi1), _c(xi2)
+        lib().vgo_odometry_prior_init(errV, errW, lam, _ptr(a), _ptr(b), _ptr(self.zeta), _ptr(self.A))
+
+    def evaluate(self, xi1, xi2):
+        a, b = _c(xi1), _c(xi2)
+        r, J1, J2 = np.empty(6), np.empty((6, 6)), np.empty((6, 6))
+        lib().vgo_odometry_prior_eval(_ptr(self.zeta), _ptr(self.A), _ptr(a), _ptr(b), _ptr(r), _ptr(J1), _ptr(J2))
+        return r, J1, J2
 
 
 def compose(a, b, inverse=False):

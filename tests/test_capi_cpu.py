@@ -153,3 +153,32 @@ def test_header_is_plain_c99(tmp_path):
                            "-Wl,-rpath," + _build.LIB_DIR, "-Wl,-rpath,/opt/rocm/lib"])
     out = subprocess.check_output([str(exe)], text=True).split()
     assert out == ["1", "10", "1000"]
+
+
+def test_odometry_prior_host_block_matches_oracle(lib):
+    """vg_odometry_prior_evaluate is host arithmetic (no GPU needed): same residual and Jacobians as the C
+    restatement of OdometryPrior (calib_cost_functions.cpp:119-212), incl. the floors of the constructor."""
+    import numpy as np
+
+    from oracle import vgo
+
+    rng = np.random.default_rng(11)
+    dp = ctypes.POINTER(ctypes.c_double)
+    P = lambda a: a.ctypes.data_as(dp)
+    cases = [(0.05, 0.02, 0.3, 0.3), (0.0, 0.0, 1.0, 0.0), (0.5, 0.5, 0.01, 1.5)]   # (err_v, err_w, lambda, motion scale)
+    for errV, errW, lam, scale in cases:
+        o1 = rng.standard_normal(6) * 0.5
+        o2 = vgo.compose(o1, rng.standard_normal(6) * scale)
+        x1 = o1 + 0.05 * rng.standard_normal(6)
+        x2 = o2 + 0.05 * rng.standard_normal(6)
+        r, J1, J2 = np.empty(6), np.empty((6, 6)), np.empty((6, 6))
+        assert lib.vg_odometry_prior_evaluate(errV, errW, lam, P(o1), P(o2), P(x1), P(x2), P(r), P(J1), P(J2)) == 0
+        ro, J1o, J2o = vgo.OdometryPrior(errV, errW, lam, o1, o2).evaluate(x1, x2)
+        sc = max(1.0, np.max(np.abs(J1o)))
+        assert np.max(np.abs(r - ro)) <= 1e-12 * max(1.0, np.max(np.abs(ro)))
+        assert np.max(np.abs(J1 - J1o)) <= 1e-12 * sc and np.max(np.abs(J2 - J2o)) <= 1e-12 * sc
+        # Jacobians optional
+        r2 = np.empty(6)
+        assert lib.vg_odometry_prior_evaluate(errV, errW, lam, P(o1), P(o2), P(x1), P(x2), P(r2), None, None) == 0
+        assert np.array_equal(r, r2)
+    assert lib.vg_odometry_prior_evaluate(0.1, 0.1, 0.0, P(o1), P(o2), P(x1), P(x2), P(r), None, None) != 0

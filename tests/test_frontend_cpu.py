@@ -78,7 +78,7 @@ def test_parse_errors_mirror_the_reference(tmp_path, what, msg):
                                          "value": r["transformations"][0]["value"]})
             r["data"][0]["transform_chain"].append({"name": "other", "direct": True})
         elif what == "unknown_type":
-            r["data"][0]["type"] = "odometry"
+            r["data"][0]["type"] = "odometry_intrinsic"
         elif what == "images_without_corners":
             r["data"][0].update(type="images", object={"cols": 12, "rows": 8, "size": 0.1})
         elif what == "bad_literal":
@@ -144,3 +144,47 @@ def test_transformation_prior_entries(tmp_path):
     with pytest.raises(capi.VisgeomError) as e:
         c.addResiduals(path)
     assert "has not been declared" in str(e.value)
+
+
+def test_odometry_entry_initialises_the_sequence(tmp_path):
+    """data type "odometry" (unified_calibration.cpp:743-807): "init": true fills the sequence from the odometry
+    values; parsing needs no GPU"""
+    d = S.make_handeye(6)
+    path = S.write_handeye_json(str(tmp_path), d)
+    c = GenericCameraCalibration()
+    assert c.addResiduals(path)
+    assert np.array_equal(c.transform("xiOdomBase"), d["odometry"])
+    assert np.array_equal(c.transform("xiBaseCam").ravel(), d["init_xi_base_cam"])
+    assert c.num_datasets() == 1
+    c.close()
+
+
+@pytest.mark.parametrize("what,msg", [
+    ("undeclared", "has not been declared"),
+    ("global", "is global. Odometry must be a sequence"),
+    ("twice", "has already been initialized"),
+    ("missing", "No such node"),
+    ("bad_literal", "invalid trasformation format"),
+])
+def test_odometry_parse_errors_mirror_the_reference(tmp_path, what, msg):
+    d = S.make_handeye(6)
+    path = S.write_handeye_json(str(tmp_path), d)
+
+    def fn(r):
+        odo = r["data"][0]
+        if what == "undeclared":
+            odo["transform"] = "nope"
+        elif what == "global":
+            odo["transform"] = "xiBaseCam"
+        elif what == "twice":
+            r["data"].append(dict(odo))
+        elif what == "missing":
+            del odo["anchor"]
+        elif what == "bad_literal":
+            odo["value"][2] = [1, 2]
+    _mutate(path, fn)
+    c = GenericCameraCalibration()
+    with pytest.raises(capi.VisgeomError) as e:
+        c.addResiduals(path)
+    assert msg in str(e.value)
+    c.close()

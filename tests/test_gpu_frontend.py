@@ -136,3 +136,31 @@ def test_stereo_example_structure(gpu, tmp_path):
         sig, outl = c.writeImageResidual(i, tmp_path / ("image_error_%d.txt" % i), n_images=[40, 40, 25, 25][i])
         assert np.all(sig < 1e-6) and outl == 0
     c.close()
+
+
+def test_handeye_with_odometry_entry(gpu, tmp_path):
+    """the "odometry" data type end to end (unified_calibration.cpp:743-807): sequence initialised from odometry,
+    anchored at element 0, one OdometryPrior per consecutive pair, grid data through the 3-member chain
+    [xiBaseCam inverse, xiOdomBase inverse, xiOdomBoard direct]; through the class mirror and the calib CLI."""
+    from visgeom_amd import _build, synthetic as S
+    from visgeom_amd.calibration import GenericCameraCalibration
+
+    n = 16
+    d = S.make_handeye(n, sigma=0.1)
+    path = S.write_handeye_json(str(tmp_path), d)
+    c = GenericCameraCalibration()
+    c.addResiduals(path)
+    report = c.compute(max_num_iterations=200)
+    print("handeye", c.summary["termination"], c.summary["num_iterations"], "%.4e -> %.4e" % (c.summary["initial_cost"], c.summary["final_cost"]))
+    assert "Sequence : xiOdomBase" in report
+    assert c.summary["num_global_columns"] == 18 and c.summary["num_pose_blocks"] == n
+    assert np.array_equal(c.transform("xiOdomBase")[0], d["odometry"][0])          # anchor
+    assert np.max(np.abs(c.transform("xiBaseCam").ravel() - d["gt_xi_base_cam"])) < 5e-3
+    assert np.max(np.abs(c.transform("xiOdomBase") - d["gt_base"])) < 1e-2
+    assert rel(c.intrinsics("cam"), d["gt_intrinsics"]) < 5e-3
+    # residual cost: 0.1 px noise on 2 * 96 * n residuals -> 0.5 * sigma^2 * (rows - dof), odometry blocks add little
+    assert 0.3 < c.summary["final_cost"] / (0.5 * 0.01 * 2 * 96 * n) < 1.5
+    c.close()
+    r = subprocess.run([_build.CLI, path], capture_output=True, text=True, cwd=str(tmp_path), timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "Sequence : xiOdomBase" in r.stdout and "xiBaseCam" in r.stdout

@@ -248,3 +248,88 @@ def test_transformation_prior_matches_scipy_on_the_oracle(vg):
     # the prior really pulls: without it the transform sits elsewhere
     assert np.max(np.abs(ref.x[12:18] - s["gt_xi12"])) > 1e-4
     p.close()
+
+
+def _handeye_reference(d, n, errV, errW, lam, x0):
+    """scipy over the oracle: grid rows of the chain [xiBaseCam I, xiOdomBase_i I, xiOdomBoard D] + one
+    vgo.OdometryPrior per consecutive pair; element 0 of the sequence is held constant (anchor)."""
+    from scipy.optimize import least_squares
+
+    N = d["board"].shape[0]
+    blocks = [vgo.OdometryPrior(errV, errW, lam, d["odometry"][i], d["odometry"][i + 1]) for i in range(n - 1)]
+    free = np.ones(x0.size, dtype=bool)
+    free[18:24] = False
+
+    def full(z):
+        x = x0.copy()
+        x[free] = z
+        return x
+
+    def fun(z):
+        x = full(z)
+        r, _, _ = vgo.eval_dataset(0, [1, 1, 0], d["board"], d["corners"], x, 0, [6, 18, 12], [0, 6, 0], np.arange(n), want_jac=False)
+        ro = [b.evaluate(x[18 + 6 * i:24 + 6 * i], x[24 + 6 * i:30 + 6 * i])[0] for i, b in enumerate(blocks)]
+        return np.concatenate([r.ravel()] + ro)
+
+    def jac(z):
+        x = full(z)
+        _, ji, jm = vgo.eval_dataset(0, [1, 1, 0], d["board"], d["corners"], x, 0, [6, 18, 12], [0, 6, 0], np.arange(n), want_jac=True)
+        J = np.zeros((2 * N * n + 6 * (n - 1), x.size))
+        for b in range(n):
+            rows = slice(b * 2 * N, (b + 1) * 2 * N)
+            J[rows, 0:6] = ji[b]
+            J[rows, 6:12] = jm[0][b]
+            J[rows, 18 + 6 * b:24 + 6 * b] = jm[1][b]
+            J[rows, 12:18] = jm[2][b]
+        for i, blk in enumerate(blocks):
+            _, J1, J2 = blk.evaluate(x[18 + 6 * i:24 + 6 * i], x[24 + 6 * i:30 + 6 * i])
+            rows = slice(2 * N * n + 6 * i, 2 * N * n + 6 * i + 6)
+            J[rows, 18 + 6 * i:24 + 6 * i] = J1
+            J[rows, 24 + 6 * i:30 + 6 * i] = J2
+        return J[:, free]
+
+    ref = least_squares(fun, x0[free], jac=jac, method="trf", x_scale="jac", xtol=1e-15, ftol=1e-15, gtol=1e-15, max_nfev=500)
+    return ref, full, fun, jac, free
+
+
+@pytest.mark.parametrize("lam", [0.05, 1.0])
+def test_odometry_prior_matches_scipy_on_the_oracle(vg, lam):
+    """data type "odometry" (unified_calibration.cpp:743-807): OdometryPrior blocks couple consecutive elements of
+    the sequence, so the pose system is block tridiagonal instead of block diagonal; anchor = element 0 constant.
+    Hand-eye set: camera on a moving base, chain [xiBaseCam I, xiOdomBase_i I, xiOdomBoard D]."""
+    from visgeom_amd import synthetic as S
+
+    n = 12
+    d = S.make_handeye(n, sigma=0.1)
+    errV, errW = 0.05, 0.05
+    x0 = np.concatenate([d["init_intrinsics"], d["init_xi_base_cam"], d["init_xi_odom_board"], d["odometry"].ravel()])
+    ref, full, fun, jac, free = _handeye_reference(d, n, errV, errW, lam, x0)
+
+    p = vg.CalibrationProblem(0)
+    cam = p.add_camera("eucm", d["init_intrinsics"])
+    bc = p.add_transform(True, d["init_xi_base_cam"])
+    ob = p.add_transform(True, d["init_xi_odom_board"])
+    seq = p.add_transform(False, d["odometry"])
+    p.add_dataset(cam, [(bc, 1), (seq, 1), (ob, 0)], d["board"], d["corners"])
+    for i in range(n - 1):
+        p.add_odometry_prior(seq, i, errV, errW, lam, d["odometry"][i], d["odometry"][i + 1])
+    p.set_pose_constant(seq, 0)
+    p.finalize()
+    summ = p.solve(max_num_iterations=300, use_bounds=0)
+    x = p.get_parameters()
+    print("odometry lam=%g" % lam, summ["termination"], summ["num_iterations"],
+          "cost gpu %.10e scipy %.10e (initial %.4e)" % (summ["final_cost"], ref.cost, summ["initial_cost"]))
+    assert np.array_equal(x[18:24], x0[18:24])                      # the anchor did not move
+    assert abs(summ["initial_cost"] - 0.5 * np.sum(fun(x0[free]) ** 2)) <= 1e-10 * summ["initial_cost"]
+    assert abs(summ["final_cost"] - 0.5 * np.sum(fun(x[free]) ** 2)) <= 1e-10 * summ["final_cost"]
+    # the reference's odometry Jacobians are first-order approximations (tests/test_oracle_math.py), so like the
+    # TransformationPrior case the comparison is solver-to-solver: gradient (by the reference's J) reduced, same cost.
+    g = jac(x[free]).T @ fun(x[free])
+    g0 = jac(x0[free]).T @ fun(x0[free])
+    assert np.max(np.abs(g)) <= 1e-5 * np.max(np.abs(g0))
+    assert abs(summ["final_cost"] - ref.cost) <= 1e-5 * ref.cost
+    assert rel(x[:6], full(ref.x)[:6]) < 1e-4
+    assert np.max(np.abs(x[6:] - full(ref.x)[6:])) < 1e-3
+    # calibration sanity: the hand-eye transform is recovered
+    assert np.max(np.abs(x[6:12] - d["gt_xi_base_cam"])) < 5e-3
+    p.close()

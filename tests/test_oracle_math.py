@@ -225,3 +225,72 @@ def test_transformation_prior_block():
     er = ang / (2 * np.sin(ang)) * np.array([Re[2, 1] - Re[1, 2], Re[0, 2] - Re[2, 0], Re[1, 0] - Re[0, 1]])
     ref = A @ np.concatenate([Rp @ et, Rp @ er])
     assert np.max(np.abs(r - ref)) < 1e-12
+
+
+def _se3(xi):
+    T = np.eye(4)
+    T[:3, :3] = _rodrigues(torch.tensor(np.asarray(xi[3:], dtype=np.float64))).numpy()
+    T[:3, 3] = xi[:3]
+    return T
+
+
+def _log_rot(R):
+    ang = np.arccos(np.clip((np.trace(R) - 1) / 2, -1, 1))
+    if ang < 1e-12:
+        return np.zeros(3)
+    return ang / (2 * np.sin(ang)) * np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+
+
+def test_odometry_prior_block():
+    """OdometryPrior (calib_cost_functions.h:64-77, .cpp:119-212): r = A (zetaPrior^-1 o xi1^-1 o xi2).  Zero when the
+    pair reproduces the measured increment (whatever the absolute pose), independent matrix formulation elsewhere, the
+    structure of A (upper-triangular planar block in (x, y, yaw), 1/lambda on z, roll, pitch), and the known quality of
+    the reference's analytic Jacobians: right-multiplied increments are treated as additive, which is first-order
+    accurate only for small rotation vectors."""
+    rng = np.random.default_rng(5)
+    o1 = np.array([0.3, -0.2, 0.0, 0.0, 0.0, 0.4])
+    o2 = np.array([0.55, -0.05, 0.0, 0.0, 0.0, 0.65])
+    errV, errW, lam = 0.05, 0.02, 0.3
+    blk = vgo.OdometryPrior(errV, errW, lam, o1, o2)
+    # zeta = o1^-1 o o2
+    Z = np.linalg.inv(_se3(o1)) @ _se3(o2)
+    assert np.max(np.abs(blk.zeta[:3] - Z[:3, 3])) < 1e-14 and np.max(np.abs(blk.zeta[3:] - _log_rot(Z[:3, :3]))) < 1e-14
+    # A: Cholesky factor (upper) of the inverse planar covariance, spread over (x, y, yaw); 1/lambda elsewhere
+    delta, l = max(np.linalg.norm(blk.zeta[3:]), 0.01), max(np.linalg.norm(blk.zeta[:3]), 0.01)
+    s, c = np.sin(delta / 2), np.cos(delta / 2)
+    dfdu = np.array([[c, l / 2 * s], [-s, l / 2 * c], [0, 1]])
+    Cu = np.diag([max(errV**2 * l**2, 1e-4), max(errW**2 * delta**2, 1e-4)])
+    Cx = dfdu @ Cu @ dfdu.T + lam**2 * np.eye(3)
+    U = np.linalg.cholesky(np.linalg.inv(Cx)).T
+    A = np.zeros((6, 6))
+    A[:2, :2] = U[:2, :2]
+    A[:2, 5] = U[:2, 2]
+    A[2, 2] = A[3, 3] = A[4, 4] = 1 / lam
+    A[5, 5] = U[2, 2]
+    assert np.max(np.abs(blk.A - A)) < 1e-11 * np.max(np.abs(A))
+    # zero for ANY absolute pose that reproduces the increment
+    base = np.array([1.0, 2.0, -0.5, 0.2, -0.3, 0.9])
+    x1 = vgo.compose(base, o1)
+    x2 = vgo.compose(base, o2)
+    r0, _, _ = blk.evaluate(x1, x2)
+    assert np.max(np.abs(r0)) < 1e-12
+    # independent formulation away from the prior
+    x1 = o1 + 0.02 * rng.standard_normal(6)
+    x2 = o2 + 0.02 * rng.standard_normal(6)
+    r, J1, J2 = blk.evaluate(x1, x2)
+    E = np.linalg.inv(Z) @ np.linalg.inv(_se3(x1)) @ _se3(x2)
+    ref = A @ np.concatenate([E[:3, 3], _log_rot(E[:3, :3])])
+    assert np.max(np.abs(r - ref)) < 1e-12
+    # Jacobians against central differences: a few percent, not 1e-7 (documented reference behaviour)
+    def fd(which):
+        J = np.zeros((6, 6))
+        for k in range(6):
+            d = np.zeros(6)
+            d[k] = 1e-6
+            a = blk.evaluate(x1 + d, x2)[0] if which == 0 else blk.evaluate(x1, x2 + d)[0]
+            b = blk.evaluate(x1 - d, x2)[0] if which == 0 else blk.evaluate(x1, x2 - d)[0]
+            J[:, k] = (a - b) / 2e-6
+        return J
+    for J, F in ((J1, fd(0)), (J2, fd(1))):
+        assert np.max(np.abs(J - F)) < 0.05 * np.max(np.abs(F))
+        assert np.max(np.abs(J - F)) > 1e-6 * np.max(np.abs(F))   # ... and they really are inexact

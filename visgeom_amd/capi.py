@@ -72,6 +72,11 @@ SIGNATURES = {
     "vg_problem_add_dataset": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _ip, _ip, ctypes.c_int, _dp,
                                               ctypes.c_int64, _i32p, _dp, _ip]),
     "vg_problem_add_transformation_prior": (ctypes.c_int, [_vp, ctypes.c_int, _dp]),
+    "vg_problem_add_odometry_prior": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int64, ctypes.c_double, ctypes.c_double,
+                                                     ctypes.c_double, _dp, _dp]),
+    "vg_odometry_prior_evaluate": (ctypes.c_int, [ctypes.c_double, ctypes.c_double, ctypes.c_double, _dp, _dp, _dp, _dp, _dp,
+                                                  _dp, _dp]),
+    "vg_problem_set_pose_constant": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int64]),
     "vg_problem_finalize": (ctypes.c_int, [_vp]),
     "vg_problem_num_parameters": (ctypes.c_int64, [_vp]),
     "vg_problem_camera_offset": (ctypes.c_int64, [_vp, ctypes.c_int]),

@@ -7,8 +7,8 @@
 // Differences from the reference, all stated in DESIGN.md section 8:
 //   * "images" datasets need pre-extracted corners ("corners_file", same layout as ir_data's "data_file"): the
 //     corner detector (OpenCV) is out of scope.  "ir_data" is read exactly as the reference reads it.
-//   * odometry / odometry_intrinsic entries are rejected (OdometryPrior couples consecutive poses and breaks the
-//     arrow structure the solver relies on); transformation_prior is accepted on global transforms.
+//   * odometry_intrinsic entries are rejected (OdometryCost is declared with one parameter block but added with three,
+//     broken as shipped); transformation_prior is accepted on global transforms; odometry is accepted.
 //   * the per-image and global-transform initial refinements use plain least squares (the reference wraps them
 //     in SoftLOneLoss(25) / SoftLOneLoss(1)); the main solve has no loss function in the reference either (:539-564).
 #pragma once
@@ -147,6 +147,13 @@ struct vg_calibration {
     std::map<std::string, bool> cameraConstantMap;
     std::vector<vgcal::ImageData> dataVec;
     std::vector<std::pair<std::string, std::array<double, 6>>> transformationPriors;  // (transform, stiffness)
+    struct Odometry {
+        std::string transform;
+        double errV, errW, lambda;
+        std::vector<std::array<double, 6>> poses;
+        bool anchor;
+    };
+    std::vector<Odometry> odometry;
     std::string log;  // what the reference prints to stdout while parsing / solving
 
     vgcal::Array6d &getTransformData(const std::string &name, int idx)  // unified_calibration.h:161-165
@@ -534,6 +541,34 @@ inline void parse_data(vg_calibration *c, const vgjson::Value &root, const std::
             read_corners(data, file, data.cameraName);
             init_transforms(c, data, di.at("init").as_string());
             // addGridResidualBlocks (:514-630) happens when the GPU problem is assembled, in compute()
+        } else if (type == "odometry") {  // :743-807
+            vg_calibration::Odometry od;
+            od.transform = di.at("transform").as_string();
+            if (c->transformInfoMap.find(od.transform) == c->transformInfoMap.end())
+                throw Error{VG_ERR_INVALID_ARGUMENT, od.transform + " has not been declared"};
+            if (c->transformInfoMap[od.transform].global)
+                throw Error{VG_ERR_INVALID_ARGUMENT, od.transform + " is global. Odometry must be a sequence"};
+            od.errV = di.at("err_v").as_number();
+            od.errW = di.at("err_w").as_number();
+            od.lambda = di.at("lambda").as_number();
+            std::string err;
+            for (auto &item : di.at("value").arr) {
+                Array6d x;
+                if (!transform_from_values(item.as_vector(), x, err)) throw Error{VG_ERR_INVALID_ARGUMENT, err};
+                od.poses.push_back(x);
+            }
+            if (di.at("init").as_bool()) {  // use the odometry as initial values
+                c->log += od.transform + "\n";
+                if (!c->sequenceTransformMap[od.transform].empty())
+                    throw Error{VG_ERR_INVALID_ARGUMENT, od.transform + " has already been initialized"};
+                c->transformInfoMap[od.transform].initialized = true;
+                for (auto &xi : od.poses) {
+                    c->sequenceTransformMap[od.transform].push_back(xi);
+                    c->sequenceInitMap[od.transform].push_back(true);
+                }
+            }
+            od.anchor = di.at("anchor").as_bool();
+            c->odometry.push_back(od);
         } else if (type == "transformation_prior") {  // :808-829
             const std::string name = di.at("transform").as_string();
             if (c->transformInfoMap.find(name) == c->transformInfoMap.end())
@@ -547,8 +582,7 @@ inline void parse_data(vg_calibration *c, const vgjson::Value &root, const std::
             std::copy(st.begin(), st.end(), a.begin());
             c->transformationPriors.emplace_back(name, a);
         } else {
-            throw Error{VG_ERR_INVALID_ARGUMENT, "data type \"" + type + "\" is not supported (grid reprojection residuals and "
-                                                 "transformation priors only)"};
+            throw Error{VG_ERR_INVALID_ARGUMENT, "data type \"" + type + "\" is not supported"};
         }
     }
 }
@@ -634,6 +668,13 @@ int vg_calibration_compute(vg_calibration *c, const vg_solve_options *options, v
                                          (int)data.board.size(), board.data(), (int64_t)idx.size(), idx.data(),
                                          corners.data(), nullptr)) != VG_OK)
             return bail(rc);
+    }
+    for (auto &od : c->odometry) {  // one OdometryPrior per consecutive pair (:790-801), optional anchor (:803-806)
+        for (size_t i = 0; i + 1 < od.poses.size(); i++)
+            if ((rc = vg_problem_add_odometry_prior(p, tfId[od.transform], (int64_t)i, od.errV, od.errW, od.lambda, od.poses[i].data(),
+                                                    od.poses[i + 1].data())) != VG_OK)
+                return bail(rc);
+        if (od.anchor && (rc = vg_problem_set_pose_constant(p, tfId[od.transform], 0)) != VG_OK) return bail(rc);
     }
     for (auto &pr : c->transformationPriors)
         if ((rc = vg_problem_add_transformation_prior(p, tfId[pr.first], pr.second.data())) != VG_OK) return bail(rc);

@@ -307,6 +307,41 @@ int vg_problem_add_transformation_prior(vg_problem *p, int transform_id, const d
     return VG_OK;
 }
 
+int vg_problem_add_odometry_prior(vg_problem *p, int transform_id, int64_t index, double err_v, double err_w, double lambda,
+                                  const double *xi1, const double *xi2)
+{
+    if (!p || !xi1 || !xi2) return fail(VG_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (p->finalized) return fail(VG_ERR_STATE, "problem already finalized");
+    if (transform_id < 0 || transform_id >= (int)p->tfs.size()) return fail(VG_ERR_INVALID_ARGUMENT, "transform id out of range");
+    const Transform &t = p->tfs[transform_id];
+    if (t.global) return fail(VG_ERR_INVALID_ARGUMENT, "Odometry must be a sequence");  // :749-752
+    if (index < 0 || index + 1 >= t.count) return fail(VG_ERR_INVALID_ARGUMENT, "odometry index outside the sequence");
+    if (!(lambda > 0.)) return fail(VG_ERR_INVALID_ARGUMENT, "lambda must be positive");
+    p->odoms.push_back(vgodo::make_block(transform_id, index, err_v, err_w, lambda, xi1, xi2));
+    return VG_OK;
+}
+
+int vg_odometry_prior_evaluate(double err_v, double err_w, double lambda, const double *xi1_odom, const double *xi2_odom,
+                               const double *xi1, const double *xi2, double *residual, double *J1, double *J2)
+{
+    if (!xi1_odom || !xi2_odom || !xi1 || !xi2 || !residual) return fail(VG_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!(lambda > 0.)) return fail(VG_ERR_INVALID_ARGUMENT, "lambda must be positive");
+    const vgodo::Block b = vgodo::make_block(0, 0, err_v, err_w, lambda, xi1_odom, xi2_odom);
+    vgodo::evaluate(b, xi1, xi2, residual, J1, J2);
+    return VG_OK;
+}
+
+int vg_problem_set_pose_constant(vg_problem *p, int transform_id, int64_t index)
+{
+    if (!p) return fail(VG_ERR_INVALID_ARGUMENT, "problem is NULL");
+    if (p->finalized) return fail(VG_ERR_STATE, "problem already finalized");
+    if (transform_id < 0 || transform_id >= (int)p->tfs.size()) return fail(VG_ERR_INVALID_ARGUMENT, "transform id out of range");
+    const Transform &t = p->tfs[transform_id];
+    if (t.global || index < 0 || index >= t.count) return fail(VG_ERR_INVALID_ARGUMENT, "not an element of a sequence transform");
+    p->const_poses.emplace_back(transform_id, index);
+    return VG_OK;
+}
+
 int vg_problem_finalize(vg_problem *p)
 {
     if (!p) return fail(VG_ERR_INVALID_ARGUMENT, "problem is NULL");

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "vg_kernels.hpp"
+#include "vg_odometry.hpp"
 
 namespace vgi {
 
@@ -75,6 +76,8 @@ struct vg_problem {
     std::vector<vgi::Transform> tfs;
     std::vector<vgi::Dataset> dss;
     std::vector<vgi::Prior> priors;
+    std::vector<vgodo::Block> odoms;                       // OdometryPrior blocks (consecutive elements of a sequence)
+    std::vector<std::pair<int, int64_t>> const_poses;     // (sequence transform, index) held constant ("anchor")
     int64_t n_params = 0;
     double *d_params = nullptr;
     vg::PrepDataset *d_prep = nullptr;  // one descriptor per non-empty dataset (vg_chain_prep_multi_kernel)

@@ -91,7 +91,22 @@ __global__ __launch_bounds__(64) void vg_pose_factor_kernel(SchurArgs a)
             gp[r] += Gb[(o + r) * D.W + D.W - 1];
         }
     }
-    bool active = !a.pose_frozen[i] && r1 > r0;
+    // pose_frozen: 0 = eliminated here, 1 = constant, 2 = belongs to a sequence coupled by OdometryPrior blocks:
+    // its raw V_i / g_i go to the record and the host eliminates the whole sequence as a block-tridiagonal system
+    const unsigned char mode = a.pose_frozen[i];
+    if (mode == 2) {
+        double *rec = a.rec + (size_t)i * kPoseRec;
+#pragma unroll
+        for (int k = 0; k < 21; k++) rec[k] = V[k];
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            rec[21 + k] = gp[k];
+            rec[27 + k] = V[tri(k, k)];
+        }
+        rec[33] = 0.;
+        return;
+    }
+    bool active = mode == 0 && r1 > r0;
 #pragma unroll
     for (int r = 0; r < 6; r++) {
         vd[r] = V[tri(r, r)];
@@ -161,6 +176,11 @@ __global__ __launch_bounds__(256) void vg_schur_rows_kernel(SchurArgs a)
     }
     fwd6(L, w, y);
     double *out = a.rows + (size_t)i * 6 * C + gcol;
+    if (a.pose_frozen[i] == 2) {  // host-eliminated sequence: hand over the raw column of W_i^T (last column: g_i)
+#pragma unroll
+        for (int k = 0; k < 6; k++) out[k * C] = w[k];
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < 6; k++) out[k * C] = active ? y[k] : 0.;
 }

@@ -1,6 +1,7 @@
 // vg_solver_impl.hpp -- Levenberg-Marquardt driver with per-pose Schur elimination (see vg_solver.hpp).
 // Host orchestration + the small dense algebra; all O(images) work runs in HIP kernels.  Included at the end
 // of vg_capi.hip: the library is ONE translation unit, so the non-template kernels exist once.
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -100,6 +101,198 @@ int launch_dense_gram(hipStream_t st, const double *X, unsigned n_rows, int C, u
     return VG_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// A sequence transform whose consecutive elements are coupled by OdometryPrior blocks: its pose system is block
+// tridiagonal (6x6 blocks) instead of block diagonal.  The GPU hands over the raw V_i, g_i, W_i^T of every element;
+// the host adds the odometry terms, factors  H = L L^T  (block bidiagonal L), forms the rows  Y = L^-1 [W^T | g]  that
+// take the place of the per-pose rows in the Schur complement, and later back-substitutes.  O(n * 6^2 * G) per
+// iteration on one core: meant for the few-hundred-pose odometry sets the reference targets.
+// ------------------------------------------------------------------------------------------
+struct CoupledSeq {
+    int tf = -1;
+    int64_t pb = 0, n = 0, param_off = 0;
+    std::vector<vgodo::Block> blocks;       // sorted by element index
+    std::vector<unsigned char> frozen;      // per element
+    std::vector<double> x, xc;              // current / candidate values [n][6]
+    std::vector<double> Cf, Bs;             // per element: Cholesky factor C_i (lower, 6x6 row-major), B_i = L_{i+1,i}
+    std::vector<double> Y, g, Dd;           // rows [6n][C], full gradient [6n], clamped undamped diagonal [6n]
+
+    double cost2(const std::vector<double> &xv) const
+    {
+        double c = 0.;
+        for (const auto &b : blocks) {
+            double r[6];
+            vgodo::evaluate(b, &xv[(size_t)b.i * 6], &xv[(size_t)(b.i + 1) * 6], r, nullptr, nullptr);
+            for (int k = 0; k < 6; k++) c += r[k] * r[k];
+        }
+        return c;
+    }
+
+    static bool chol6(const double *A, double *L)
+    {
+        for (int k = 0; k < 36; k++) L[k] = 0.;
+        for (int r = 0; r < 6; r++)
+            for (int c = 0; c <= r; c++) {
+                double s = A[6 * r + c];
+                for (int k = 0; k < c; k++) s -= L[6 * r + k] * L[6 * c + k];
+                if (r == c) {
+                    if (!(s > 0.) || !std::isfinite(s)) return false;
+                    L[6 * r + r] = std::sqrt(s);
+                } else {
+                    L[6 * r + c] = s / L[6 * c + c];
+                }
+            }
+        return true;
+    }
+
+    // rec: [n][kPoseRec] raw V (packed lower) | g | diag ;  raw: [6n][C] raw W^T | g columns.  Returns false when a
+    // diagonal block is not positive definite.
+    bool eliminate(const double *rec, const double *raw, int G, double mu, double dmin, double dmax)
+    {
+        const int C = G + 1;
+        std::vector<double> H((size_t)n * 36, 0.), E((size_t)n * 36, 0.);  // diagonal blocks, E_i = H_{i,i+1}
+        g.assign((size_t)n * 6, 0.);
+        for (int64_t i = 0; i < n; i++) {
+            const double *r = rec + (size_t)i * vg::kPoseRec;
+            for (int a2 = 0; a2 < 6; a2++)
+                for (int b2 = 0; b2 <= a2; b2++) H[(size_t)i * 36 + 6 * a2 + b2] = H[(size_t)i * 36 + 6 * b2 + a2] = r[a2 * (a2 + 1) / 2 + b2];
+            for (int k = 0; k < 6; k++) g[(size_t)i * 6 + k] = r[21 + k];
+        }
+        for (const auto &b : blocks) {
+            double r[6], J1[36], J2[36];
+            vgodo::evaluate(b, &x[(size_t)b.i * 6], &x[(size_t)(b.i + 1) * 6], r, J1, J2);
+            double *H1 = &H[(size_t)b.i * 36], *H2 = &H[(size_t)(b.i + 1) * 36], *Ei = &E[(size_t)b.i * 36];
+            for (int a2 = 0; a2 < 6; a2++) {
+                for (int b2 = 0; b2 < 6; b2++) {
+                    double s11 = 0., s22 = 0., s12 = 0.;
+                    for (int k = 0; k < 6; k++) {
+                        s11 += J1[6 * k + a2] * J1[6 * k + b2];
+                        s22 += J2[6 * k + a2] * J2[6 * k + b2];
+                        s12 += J1[6 * k + a2] * J2[6 * k + b2];
+                    }
+                    H1[6 * a2 + b2] += s11;
+                    H2[6 * a2 + b2] += s22;
+                    Ei[6 * a2 + b2] += s12;
+                }
+                double g1 = 0., g2 = 0.;
+                for (int k = 0; k < 6; k++) { g1 += J1[6 * k + a2] * r[k]; g2 += J2[6 * k + a2] * r[k]; }
+                g[(size_t)b.i * 6 + a2] += g1;
+                g[(size_t)(b.i + 1) * 6 + a2] += g2;
+            }
+        }
+        Dd.assign((size_t)n * 6, 0.);
+        std::vector<double> R((size_t)n * 6 * C);  // right-hand sides [W^T | g] with the odometry gradient in the last column
+        for (int64_t i = 0; i < n; i++) {
+            for (int k = 0; k < 6; k++) {
+                for (int c = 0; c < G; c++) R[((size_t)i * 6 + k) * C + c] = raw[((size_t)i * 6 + k) * C + c];
+                R[((size_t)i * 6 + k) * C + G] = g[(size_t)i * 6 + k];
+            }
+            if (frozen[(size_t)i]) {  // constant element: unit block, no coupling, zero right-hand side
+                for (int k = 0; k < 36; k++) H[(size_t)i * 36 + k] = 0.;
+                for (int k = 0; k < 6; k++) H[(size_t)i * 36 + 7 * k] = 1.;
+                for (int k = 0; k < 36; k++) E[(size_t)i * 36 + k] = 0.;
+                if (i > 0) for (int k = 0; k < 36; k++) E[(size_t)(i - 1) * 36 + k] = 0.;
+                for (int k = 0; k < 6 * C; k++) R[(size_t)i * 6 * C + k] = 0.;
+                for (int k = 0; k < 6; k++) g[(size_t)i * 6 + k] = 0.;
+            } else {
+                for (int k = 0; k < 6; k++) {
+                    const double d = H[(size_t)i * 36 + 7 * k];
+                    const double dc = d < dmin ? dmin : (d > dmax ? dmax : d);
+                    Dd[(size_t)i * 6 + k] = dc;
+                    H[(size_t)i * 36 + 7 * k] += mu * dc;
+                }
+            }
+        }
+        Cf.assign((size_t)n * 36, 0.);
+        Bs.assign((size_t)n * 36, 0.);
+        Y.assign((size_t)n * 6 * C, 0.);
+        for (int64_t i = 0; i < n; i++) {
+            double D[36];
+            for (int k = 0; k < 36; k++) D[k] = H[(size_t)i * 36 + k];
+            if (i > 0) {  // D -= B_{i-1} B_{i-1}^T
+                const double *B = &Bs[(size_t)(i - 1) * 36];
+                for (int a2 = 0; a2 < 6; a2++)
+                    for (int b2 = 0; b2 < 6; b2++) {
+                        double s2 = 0.;
+                        for (int k = 0; k < 6; k++) s2 += B[6 * a2 + k] * B[6 * b2 + k];
+                        D[6 * a2 + b2] -= s2;
+                    }
+            }
+            double *Ci = &Cf[(size_t)i * 36];
+            if (!chol6(D, Ci)) return false;
+            // Y_i = C_i^-1 (R_i - B_{i-1} Y_{i-1})
+            for (int c = 0; c < C; c++) {
+                double v[6];
+                for (int k = 0; k < 6; k++) {
+                    double s2 = R[((size_t)i * 6 + k) * C + c];
+                    if (i > 0)
+                        for (int q = 0; q < 6; q++) s2 -= Bs[(size_t)(i - 1) * 36 + 6 * k + q] * Y[((size_t)(i - 1) * 6 + q) * C + c];
+                    v[k] = s2;
+                }
+                for (int k = 0; k < 6; k++) {
+                    double s2 = v[k];
+                    for (int q = 0; q < k; q++) s2 -= Ci[6 * k + q] * Y[((size_t)i * 6 + q) * C + c];
+                    Y[((size_t)i * 6 + k) * C + c] = s2 / Ci[6 * k + k];
+                }
+            }
+            if (i + 1 < n) {  // B_i = E_i^T C_i^-T  <=>  B_i C_i^T = E_i^T : row by row forward substitution
+                double *B = &Bs[(size_t)i * 36];
+                const double *Ei = &E[(size_t)i * 36];
+                for (int a2 = 0; a2 < 6; a2++)
+                    for (int k = 0; k < 6; k++) {
+                        double s2 = Ei[6 * k + a2];  // (E^T)[a2][k]
+                        for (int q = 0; q < k; q++) s2 -= B[6 * a2 + q] * Ci[6 * k + q];
+                        B[6 * a2 + k] = s2 / Ci[6 * k + k];
+                    }
+            }
+        }
+        return true;
+    }
+
+    // dp = -L^-T (y + Y dg); returns the scalar terms gp.dp | sum D dp^2 | |dp|^2 | |g|^2 | max|g|
+    void backsub(const double *dg, int G, std::vector<double> &dp, double *scal5) const
+    {
+        const int C = G + 1;
+        dp.assign((size_t)n * 6, 0.);
+        std::vector<double> v((size_t)n * 6);
+        for (int64_t i = 0; i < n; i++)
+            for (int k = 0; k < 6; k++) {
+                double s2 = Y[((size_t)i * 6 + k) * C + G];
+                for (int c = 0; c < G; c++) s2 += Y[((size_t)i * 6 + k) * C + c] * dg[c];
+                v[(size_t)i * 6 + k] = s2;
+            }
+        std::vector<double> xs((size_t)n * 6, 0.);
+        for (int64_t i = n - 1; i >= 0; i--) {  // L^T x = v :  C_i^T x_i = v_i - B_i^T x_{i+1}
+            double w[6];
+            for (int k = 0; k < 6; k++) {
+                double s2 = v[(size_t)i * 6 + k];
+                if (i + 1 < n)
+                    for (int q = 0; q < 6; q++) s2 -= Bs[(size_t)i * 36 + 6 * q + k] * xs[(size_t)(i + 1) * 6 + q];
+                w[k] = s2;
+            }
+            const double *Ci = &Cf[(size_t)i * 36];
+            for (int k = 5; k >= 0; k--) {
+                double s2 = w[k];
+                for (int q = k + 1; q < 6; q++) s2 -= Ci[6 * q + k] * xs[(size_t)i * 6 + q];
+                xs[(size_t)i * 6 + k] = s2 / Ci[6 * k + k];
+            }
+        }
+        for (int k = 0; k < 5; k++) scal5[k] = 0.;
+        for (int64_t i = 0; i < n; i++) {
+            if (frozen[(size_t)i]) continue;
+            for (int k = 0; k < 6; k++) {
+                const double d = -xs[(size_t)i * 6 + k], gk = g[(size_t)i * 6 + k];
+                dp[(size_t)i * 6 + k] = d;
+                scal5[0] += gk * d;
+                scal5[1] += Dd[(size_t)i * 6 + k] * d * d;
+                scal5[2] += d * d;
+                scal5[3] += gk * gk;
+                scal5[4] = std::fabs(gk) > scal5[4] ? std::fabs(gk) : scal5[4];
+            }
+        }
+    }
+};
+
 }  // namespace
 
 extern "C" {
@@ -181,6 +374,37 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             }
         }
     }
+
+    // sequences coupled by OdometryPrior blocks -> host elimination (pose mode 2); constant elements ("anchor")
+    std::vector<CoupledSeq> coupled;
+    for (const auto &b : p->odoms) {
+        CoupledSeq *cs = nullptr;
+        for (auto &c2 : coupled)
+            if (c2.tf == b.tf) cs = &c2;
+        if (!cs) {
+            coupled.emplace_back();
+            cs = &coupled.back();
+            cs->tf = b.tf;
+            cs->pb = tf_pbase[b.tf];
+            cs->n = p->tfs[b.tf].count;
+            cs->param_off = p->tfs[b.tf].offset;
+            cs->frozen.assign((size_t)cs->n, p->tfs[b.tf].constant ? 1 : 0);
+        }
+        cs->blocks.push_back(b);
+    }
+    for (const auto &cp : p->const_poses) {
+        pose_frozen[(size_t)(tf_pbase[cp.first] + cp.second)] = 1;
+        for (auto &c2 : coupled)
+            if (c2.tf == cp.first) c2.frozen[(size_t)cp.second] = 1;
+    }
+    for (auto &c2 : coupled) {
+        std::sort(c2.blocks.begin(), c2.blocks.end(), [](const vgodo::Block &a2, const vgodo::Block &b2) { return a2.i < b2.i; });
+        for (int64_t i = 0; i < c2.n; i++) pose_frozen[(size_t)(c2.pb + i)] = 2;
+        c2.x.resize((size_t)c2.n * 6);
+        c2.xc.resize((size_t)c2.n * 6);
+    }
+    if (!coupled.empty() && opt.allreduce)
+        return fail(VG_ERR_INVALID_ARGUMENT, "OdometryPrior blocks are not supported together with a multi-rank all-reduce");
 
     // per dataset: local -> global column map, pose column offset, pose references
     std::vector<std::vector<int>> lmap(n_ds);
@@ -378,6 +602,10 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
         cost2 = pack.back();
         add_priors(h_xg, U, gg, cost2);
     }
+    for (auto &c2 : coupled) {
+        VG_HIP(hipMemcpy(c2.x.data(), d_x.p + c2.param_off, sizeof(double) * c2.x.size(), hipMemcpyDeviceToHost));
+        cost2 += c2.cost2(c2.x);
+    }
     double radius = opt.initial_trust_region_radius, decrease_factor = 2.;
     int iter = 0, n_success = 0, term = VG_TERM_NO_CONVERGENCE;
     double grad_max = 0.;
@@ -405,12 +633,31 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
         sa.rows = d_rows.p;
         sa.bad = d_bad.p;
         std::fill(h_rgram.begin(), h_rgram.end(), 0.);
+        bool coupled_ok = true;
         if (n_poses) {
             VG_HIP(hipMemsetAsync(d_bad.p, 0, sizeof(int), st));
             hipLaunchKernelGGL(vg::vg_pose_factor_kernel, dim3((unsigned)((n_poses + 63) / 64)), dim3(64), 0, st, sa);
             VG_HIP(hipGetLastError());
             hipLaunchKernelGGL(vg::vg_schur_rows_kernel, dim3((unsigned)((n_poses * C + 255) / 256)), dim3(256), 0, st, sa);
             VG_HIP(hipGetLastError());
+            // sequences coupled by odometry: raw V / g / W^T come back, the host eliminates the block-tridiagonal
+            // system and puts its rows where the per-pose rows would be
+            for (auto &c2 : coupled) {
+                std::vector<double> hrec((size_t)c2.n * vg::kPoseRec), hraw((size_t)c2.n * 6 * C);
+                VG_HIP(hipMemcpyAsync(hrec.data(), d_rec.p + (size_t)c2.pb * vg::kPoseRec, sizeof(double) * hrec.size(),
+                                      hipMemcpyDeviceToHost, st));
+                VG_HIP(hipMemcpyAsync(hraw.data(), d_rows.p + (size_t)c2.pb * 6 * C, sizeof(double) * hraw.size(),
+                                      hipMemcpyDeviceToHost, st));
+                VG_HIP(hipStreamSynchronize(st));
+                if (!c2.eliminate(hrec.data(), hraw.data(), G, mu, opt.min_lm_diagonal, opt.max_lm_diagonal)) {
+                    coupled_ok = false;
+                    std::fill(c2.Y.begin(), c2.Y.end(), 0.);
+                    c2.Y.resize((size_t)c2.n * 6 * C, 0.);
+                }
+                VG_HIP(hipMemcpyAsync(d_rows.p + (size_t)c2.pb * 6 * C, c2.Y.data(), sizeof(double) * c2.Y.size(),
+                                      hipMemcpyHostToDevice, st));
+                VG_HIP(hipStreamSynchronize(st));  // c2.Y may be rewritten before an async copy from pageable memory ends
+            }
             VG_TRY(launch_dense_gram(st, d_rows.p, n_rows, C, rows_per_group, n_groups, d_rgroups.p));
             hipLaunchKernelGGL(vg::vg_gram_slab_sum_kernel, dim3(n_slabs), dim3(256), 0, st, (const double *)d_rgroups.p,
                                n_groups, C * C, d_rslabs.p);
@@ -439,7 +686,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
                 S[(size_t)a2 * G + a2] = 1.;
                 rhs[a2] = 0.;
             }
-        bool step_ok = G == 0 || chol_solve(G, S.data(), rhs.data(), dg.data());
+        bool step_ok = coupled_ok && (G == 0 || chol_solve(G, S.data(), rhs.data(), dg.data()));
         t_host += now_s() - t0;
 
         double model_change = 0., step2 = 0., cost_change = 0., rho = 0.;
@@ -471,6 +718,16 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
                                    d_scal_sum.p);
                 VG_HIP(hipGetLastError());
             }
+            double host_scal[5] = {0., 0., 0., 0., 0.};
+            for (auto &c2 : coupled) {
+                std::vector<double> dp;
+                double sc[5];
+                c2.backsub(dg.data(), G, dp, sc);
+                for (int k = 0; k < 4; k++) host_scal[k] += sc[k];
+                host_scal[4] = sc[4] > host_scal[4] ? sc[4] : host_scal[4];
+                VG_HIP(hipMemcpyAsync(d_delta.p + c2.param_off, dp.data(), sizeof(double) * dp.size(), hipMemcpyHostToDevice, st));
+                VG_HIP(hipStreamSynchronize(st));
+            }
             if (n_params) {
                 hipLaunchKernelGGL(vg::vg_apply_step_kernel, dim3((unsigned)((n_params + 255) / 256)), dim3(256), 0, st,
                                    (const double *)d_x.p, (const double *)d_delta.p, (const double *)d_lo.p,
@@ -491,8 +748,13 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             for (int a2 = 0; a2 < G; a2++) h_xg[a2] = ps[6 + a2];
             double xg2 = 0.;
             for (int a2 = 0; a2 < G; a2++) xg2 += h_xg[a2] * h_xg[a2];
-            double gdp = ps[0], ddp = ps[1], dp2 = ps[2], gp2 = ps[3], xp2 = ps[4], gmax_p = ps[5];
+            double gdp = ps[0] + host_scal[0], ddp = ps[1] + host_scal[1], dp2 = ps[2] + host_scal[2],
+                   gp2 = ps[3] + host_scal[3], xp2 = ps[4], gmax_p = ps[5] > host_scal[4] ? ps[5] : host_scal[4];
             VG_TRY(evaluate(d_xc.p, cand, Uc, ggc, cost2_c));
+            for (auto &c2 : coupled) {
+                VG_HIP(hipMemcpy(c2.xc.data(), d_xc.p + c2.param_off, sizeof(double) * c2.xc.size(), hipMemcpyDeviceToHost));
+                cost2_c += c2.cost2(c2.xc);
+            }
             {
                 std::vector<double> pack(Uc);
                 pack.insert(pack.end(), ggc.begin(), ggc.end());
@@ -569,6 +831,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             std::swap(cur, cand);
             std::swap(ds_cur, ds_cand);
             std::swap(d_x.p, d_xc.p);
+            for (auto &c2 : coupled) c2.x.swap(c2.xc);
             U.swap(Uc);
             gg.swap(ggc);
             const double prev = cost2;

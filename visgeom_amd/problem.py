@@ -157,6 +157,14 @@ class CalibrationProblem:
             raise ValueError("stiffness needs 6 values")
         capi.check(self._lib.vg_problem_add_transformation_prior(self._h, transform, _ptr(v)))
 
+    def add_odometry_prior(self, transform, index, err_v, err_w, lam, xi1, xi2):
+        """OdometryPrior block (calib_cost_functions.h:64-77) between elements index and index + 1 of a sequence"""
+        a, b = _c(xi1), _c(xi2)
+        capi.check(self._lib.vg_problem_add_odometry_prior(self._h, transform, index, err_v, err_w, lam, _ptr(a), _ptr(b)))
+
+    def set_pose_constant(self, transform, index):
+        capi.check(self._lib.vg_problem_set_pose_constant(self._h, transform, index))
+
     def finalize(self):
         capi.check(self._lib.vg_problem_finalize(self._h))
         self.num_parameters = self._lib.vg_problem_num_parameters(self._h)

@@ -256,6 +256,45 @@ def make_rig(n_frames, config_index=5, sigma=0.1):
             "gt_poses": poses, "init_poses": poses + _perturb(seed, n_frames, 6), "seed": seed}
 
 
+def _se3(xi):
+    T = np.eye(4)
+    T[:3, :3] = rodrigues(np.asarray(xi[3:], dtype=np.float64))
+    T[:3, 3] = xi[:3]
+    return T
+
+
+def _xi_of(T):
+    return np.concatenate([T[:3, 3], rotvec_from_matrix(T[:3, :3])])
+
+
+def make_handeye(n_frames, config_index=6, sigma=0.1, odo_sigma=0.002):
+    """Hand-eye set for the odometry path (data type "odometry", unified_calibration.cpp:743-807): an EUCM camera
+    mounted on a moving base at xiBaseCam, a fixed board at xiOdomBoard, one base pose xiOdomBase_i per frame, and
+    odometry measurements of those poses.  Camera chain [xiBaseCam INVERSE, xiOdomBase INVERSE, xiOdomBoard DIRECT]:
+    X_cam = T_BC^-1 T_OB_i^-1 T_OBoard X_board.  xiOdomBase_0 is the odometry origin (identity)."""
+    seed = BASE_SEED + config_index
+    board = board_points()
+    gt = GT_EUCM_CAM1.copy()
+    cam_board = make_poses(seed, n_frames, [("eucm", gt, np.eye(3), np.zeros(3))], board)   # board -> camera, per frame
+    xi_bc = np.array([0.10, -0.05, 0.20, 0.03, -0.02, 0.05])
+    T_bc = _se3(xi_bc)
+    T_oboard = T_bc @ _se3(cam_board[0])
+    base = np.stack([_xi_of(T_oboard @ np.linalg.inv(_se3(cb)) @ np.linalg.inv(T_bc)) for cb in cam_board])
+    base[0] = 0.0
+    X = np.einsum("nij,kj->nki", rodrigues(cam_board[:, 3:]), board) + cam_board[:, None, :3]
+    uv, ok = project("eucm", gt, X)
+    assert ok.all()
+    odo = base + odo_sigma * np.stack(normal_pair(seed, np.repeat(np.arange(n_frames, dtype=np.uint64), 3),
+                                                  np.tile(np.arange(3, dtype=np.uint64), n_frames) + np.uint64(PERTURB_OFFSET + 4096)),
+                                      -1).reshape(n_frames, 6)
+    odo[0] = 0.0
+    return {"board": board, "corners": uv + _noise(seed, n_frames, board.shape[0], sigma), "gt_intrinsics": gt,
+            "init_intrinsics": INIT["eucm"].copy(), "gt_xi_base_cam": xi_bc, "gt_xi_odom_board": _xi_of(T_oboard),
+            "init_xi_base_cam": xi_bc + _perturb(seed, 1, 6, salt=9)[0],
+            "init_xi_odom_board": _xi_of(T_oboard) + _perturb(seed, 1, 6, salt=10)[0],
+            "gt_base": base, "odometry": odo, "seed": seed}
+
+
 def write_calibration_json(directory, d, model, name="calib", camera="cam", sequence="xiCamBoard", prior=False,
                            init=True, flags=(), as_images=False, skip=()):
     """Config 1: write <name>.json (+ <name>_corners.json) in the reference's calibration schema (README.md:36-223,
@@ -286,6 +325,39 @@ def write_calibration_json(directory, d, model, name="calib", camera="cam", sequ
     root = {"transformations": [tf],
             "cameras": [{"name": camera, "type": model, "constant": False, "value": d["init_intrinsics"].tolist()}],
             "data": [data]}
+    path = os.path.join(directory, name + ".json")
+    with open(path, "w") as f:
+        json.dump(root, f, indent=1)
+    return path
+
+
+def write_handeye_json(directory, d, name="handeye", err_v=0.05, err_w=0.05, lam=0.05, anchor=True, odometry_first=True):
+    """A calibration file using the "odometry" data type (README.md odometry section, parse at
+    unified_calibration.cpp:743-807) for a set made by make_handeye: the sequence xiOdomBase is initialised from
+    the odometry values ("init": true) and anchored at element 0; the camera data has nothing left to initialise."""
+    import json
+    import os
+
+    board = d["board"]
+    n = d["corners"].shape[0]
+    corners_file = name + "_corners.json"
+    with open(os.path.join(directory, corners_file), "w") as f:
+        json.dump([[{"camera": "cam", "points": d["corners"][i].tolist()}] for i in range(n)], f)
+    odo = {"type": "odometry", "transform": "xiOdomBase", "err_v": err_v, "err_w": err_w, "lambda": lam,
+           "init": True, "anchor": bool(anchor), "value": d["odometry"].tolist()}
+    grid = {"type": "ir_data", "camera": "cam", "parameters": [], "init": "none",
+            "transform_chain": [{"name": "xiBaseCam", "direct": False}, {"name": "xiOdomBase", "direct": False},
+                                {"name": "xiOdomBoard", "direct": True}],
+            "image_width": IMAGE_W, "image_height": IMAGE_H, "data_file": corners_file,
+            "object": {"points": board.tolist(), "corner_ul": 0, "corner_ur": BOARD_COLS - 1,
+                       "corner_bl": BOARD_COLS * (BOARD_ROWS - 1), "corner_br": BOARD_COLS * BOARD_ROWS - 1}}
+    root = {"transformations": [{"name": "xiBaseCam", "global": True, "prior": True, "constant": False,
+                                 "value": d["init_xi_base_cam"].tolist()},
+                                {"name": "xiOdomBoard", "global": True, "prior": True, "constant": False,
+                                 "value": d["init_xi_odom_board"].tolist()},
+                                {"name": "xiOdomBase", "global": False, "prior": False, "constant": False}],
+            "cameras": [{"name": "cam", "type": "eucm", "constant": False, "value": d["init_intrinsics"].tolist()}],
+            "data": [odo, grid] if odometry_first else [grid, odo]}
     path = os.path.join(directory, name + ".json")
     with open(path, "w") as f:
         json.dump(root, f, indent=1)
