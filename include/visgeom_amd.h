@@ -120,9 +120,9 @@ int vg_problem_add_dataset(vg_problem *p, int camera_id, int chain_len, const in
                            const int32_t *image_index, const double *corners, int *dataset_id);
 /* TransformationPrior (include/calibration/calib_cost_functions.h:79-103, .cpp:214-228; parseData :808-829): six
  * residuals A * [R e_t; R e_r], e = prior^-1 o xi, pulling a transform towards the value it has NOW (the reference
- * requires the transform to have a prior value and uses it).  stiffness: the 6 diagonal weights.  Global transforms
- * only (the reference also allows element 0 of a sequence).  Seen by vg_problem_solve, not by the per-dataset
- * evaluation entries. */
+ * requires the transform to have a prior value and uses it).  stiffness: the 6 diagonal weights.  On a sequence
+ * transform the block acts on element 0, as in the reference (getTransformData(name), :826).  Seen by
+ * vg_problem_solve, not by the per-dataset evaluation entries. */
 int vg_problem_add_transformation_prior(vg_problem *p, int transform_id, const double *stiffness);
 /* OdometryPrior (include/calibration/calib_cost_functions.h:64-77, .cpp:119-212; parseData :743-807): six residuals
  * between elements `index` and `index + 1` of a SEQUENCE transform, built from the two odometry poses xi1, xi2 and

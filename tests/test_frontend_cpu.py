@@ -116,7 +116,7 @@ def test_cli_is_built_and_prints_usage():
 
 
 def test_transformation_prior_entries(tmp_path):
-    """parseData :808-829: the transform must exist and have a prior value; here it must also be global"""
+    """parseData :808-829: the transform must exist and have a prior value; global, or a sequence (element 0)"""
     d, path = _write(tmp_path, prior=True)
 
     def add(r, name="xiRig", with_prior=True, is_global=True):
@@ -130,14 +130,24 @@ def test_transformation_prior_entries(tmp_path):
     c = GenericCameraCalibration()
     c.addResiduals(path)
     c.close()
-    for kw, msg in (({"with_prior": False}, "must have a prior value"), ({"is_global": False}, "sequence transform is not supported")):
-        d, path = _write(tmp_path, prior=True)
-        _mutate(path, lambda r: add(r, **kw))
-        c = GenericCameraCalibration()
-        with pytest.raises(capi.VisgeomError) as e:
-            c.addResiduals(path)
-        assert msg in str(e.value)
-        c.close()
+    d, path = _write(tmp_path, prior=True)
+    _mutate(path, lambda r: add(r, with_prior=False))
+    c = GenericCameraCalibration()
+    with pytest.raises(capi.VisgeomError) as e:
+        c.addResiduals(path)
+    assert "must have a prior value" in str(e.value)
+    c.close()
+    # a sequence with a prior value is accepted: the block goes on its element 0 (getTransformData default index)
+    d, path = _write(tmp_path, prior=True)
+    _mutate(path, lambda r: add(r, is_global=False))
+    c = GenericCameraCalibration()
+    assert c.addResiduals(path)
+    c.close()
+    d, path = _write(tmp_path, prior=True)
+    _mutate(path, lambda r: r["data"].append({"type": "transformation_prior", "transform": "xiCamBoard", "stiffness": [1] * 6}))
+    c = GenericCameraCalibration()
+    assert c.addResiduals(path)
+    c.close()
     d, path = _write(tmp_path, prior=True)
     _mutate(path, lambda r: r["data"].append({"type": "transformation_prior", "transform": "nope", "stiffness": [1] * 6}))
     c = GenericCameraCalibration()

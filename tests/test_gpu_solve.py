@@ -333,3 +333,75 @@ def test_odometry_prior_matches_scipy_on_the_oracle(vg, lam):
     # calibration sanity: the hand-eye transform is recovered
     assert np.max(np.abs(x[6:12] - d["gt_xi_base_cam"])) < 5e-3
     p.close()
+
+
+@pytest.mark.parametrize("with_odometry", [False, True])
+def test_transformation_prior_on_a_sequence_acts_on_element_zero(vg, with_odometry):
+    """parseData :808-829 hands getTransformData(name) = element 0 of a sequence to TransformationPrior.  Mono EUCM
+    set, a stiff and deliberately wrong prior on pose 0; optionally odometry blocks on the same sequence (then both
+    kinds of block meet in the same block-tridiagonal elimination)."""
+    from scipy.optimize import least_squares
+
+    from visgeom_amd import synthetic as S
+
+    n, N = 8, 96
+    d = S.make_mono("eucm", n, 2, sigma=0.1)
+    # The reference's prior Jacobian is diag(stiffness) * M(prior rot) where the exact one is diag * R * M: off by the
+    # prior's rotation.  With a board pose of 2-3 rad it is unusable (every solver stalls somewhere else), so pose 0
+    # is replaced by a nearly fronto-parallel one (|rot| = 0.04), the regime the block can work in.
+    gt0 = np.array([-0.55, -0.35, 1.0, 0.03, -0.02, 0.015])
+    uv, ok = S.project("eucm", d["gt_intrinsics"], (S.rodrigues(gt0[3:]) @ d["board"].T).T + gt0[:3])
+    assert ok.all() and uv.min() > 20 and uv[:, 0].max() < S.IMAGE_W - 20 and uv[:, 1].max() < S.IMAGE_H - 20
+    d["corners"][0] = uv + 0.1 * np.random.default_rng(8).standard_normal(uv.shape)
+    d["gt_poses"][0] = gt0
+    d["init_poses"][0] = gt0 + np.array([0.008, -0.006, 0.009, -0.007, 0.005, 0.006])
+    x0 = np.concatenate([d["init_intrinsics"], d["init_poses"].ravel()])
+    prior = d["init_poses"][0].copy()
+    stiff = np.array([400.0, 400.0, 400.0, 600.0, 600.0, 600.0])
+    odo = d["gt_poses"] + 0.003 * np.random.default_rng(3).standard_normal((n, 6))
+    blocks = [vgo.OdometryPrior(0.05, 0.05, 0.2, odo[i], odo[i + 1]) for i in range(n - 1)] if with_odometry else []
+
+    def fun(x):
+        r, _, _ = vgo.eval_dataset(0, [0], d["board"], d["corners"], x, 0, [6], [6], np.arange(n), want_jac=False)
+        rp, _ = vgo.transformation_prior(stiff, prior, x[6:12])
+        ro = [b.evaluate(x[6 + 6 * i:12 + 6 * i], x[12 + 6 * i:18 + 6 * i])[0] for i, b in enumerate(blocks)]
+        return np.concatenate([r.ravel(), rp] + ro)
+
+    def jac(x):
+        _, ji, jm = vgo.eval_dataset(0, [0], d["board"], d["corners"], x, 0, [6], [6], np.arange(n), want_jac=True)
+        J = np.zeros((2 * N * n + 6 + 6 * len(blocks), x.size))
+        for b in range(n):
+            rows = slice(b * 2 * N, (b + 1) * 2 * N)
+            J[rows, 0:6] = ji[b]
+            J[rows, 6 + 6 * b:12 + 6 * b] = jm[0][b]
+        J[2 * N * n:2 * N * n + 6, 6:12] = vgo.transformation_prior(stiff, prior, x[6:12])[1]
+        for i, blk in enumerate(blocks):
+            _, J1, J2 = blk.evaluate(x[6 + 6 * i:12 + 6 * i], x[12 + 6 * i:18 + 6 * i])
+            rows = slice(2 * N * n + 6 + 6 * i, 2 * N * n + 12 + 6 * i)
+            J[rows, 6 + 6 * i:12 + 6 * i] = J1
+            J[rows, 12 + 6 * i:18 + 6 * i] = J2
+        return J
+
+    ref = least_squares(fun, x0, jac=jac, method="trf", x_scale="jac", xtol=1e-15, ftol=1e-15, gtol=1e-15, max_nfev=500)
+    p = vg.CalibrationProblem(0)
+    cam = p.add_camera("eucm", d["init_intrinsics"])
+    seq = p.add_transform(False, d["init_poses"])
+    p.add_dataset(cam, [(seq, 0)], d["board"], d["corners"])
+    p.add_transformation_prior(seq, stiff)
+    for i in range(len(blocks)):
+        p.add_odometry_prior(seq, i, 0.05, 0.05, 0.2, odo[i], odo[i + 1])
+    p.finalize()
+    summ = p.solve(max_num_iterations=300, use_bounds=0)
+    x = p.get_parameters()
+    print("sequence prior odo=%s" % with_odometry, summ["termination"], summ["num_iterations"],
+          "cost gpu %.10e scipy %.10e" % (summ["final_cost"], ref.cost))
+    assert abs(summ["initial_cost"] - 0.5 * np.sum(fun(x0) ** 2)) <= 1e-10 * summ["initial_cost"]
+    assert abs(summ["final_cost"] - 0.5 * np.sum(fun(x) ** 2)) <= 1e-10 * summ["final_cost"]
+    g, g0 = jac(x).T @ fun(x), jac(x0).T @ fun(x0)
+    assert np.max(np.abs(g)) <= 1e-5 * np.max(np.abs(g0))
+    assert abs(summ["final_cost"] - ref.cost) <= 1e-5 * ref.cost
+    assert np.max(np.abs(x[6:] - ref.x[6:])) < 1e-3 and rel(x[:6], ref.x[:6]) < 1e-4
+    # the prior pulls pose 0 away from where the images alone put it
+    free = least_squares(lambda z: fun(z)[:2 * N * n], x0, method="trf", x_scale="jac", max_nfev=200)
+    assert np.max(np.abs(x[6:12] - free.x[6:12])) > 1e-4
+    p.close()

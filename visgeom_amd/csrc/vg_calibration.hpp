@@ -574,8 +574,8 @@ inline void parse_data(vg_calibration *c, const vgjson::Value &root, const std::
             if (c->transformInfoMap.find(name) == c->transformInfoMap.end())
                 throw Error{VG_ERR_INVALID_ARGUMENT, name + " has not been declared"};
             if (!c->transformInfoMap[name].prior) throw Error{VG_ERR_INVALID_ARGUMENT, name + " must have a prior value"};
-            if (!c->transformInfoMap[name].global)
-                throw Error{VG_ERR_INVALID_ARGUMENT, "transformation_prior on a sequence transform is not supported"};
+            if (!c->transformInfoMap[name].global && c->sequenceTransformMap[name].empty())
+                throw Error{VG_ERR_INVALID_ARGUMENT, name + " is an empty sequence"};  // the reference would index element 0 (:826)
             const std::vector<double> st = di.at("stiffness").as_vector();
             if (st.size() != 6) throw Error{VG_ERR_INVALID_ARGUMENT, "stiffness needs 6 values"};
             std::array<double, 6> a;

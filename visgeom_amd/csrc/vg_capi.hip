@@ -291,7 +291,8 @@ int vg_problem_add_transformation_prior(vg_problem *p, int transform_id, const d
     if (p->finalized) return fail(VG_ERR_STATE, "problem already finalized");
     if (transform_id < 0 || transform_id >= (int)p->tfs.size()) return fail(VG_ERR_INVALID_ARGUMENT, "transform id out of range");
     const Transform &t = p->tfs[transform_id];
-    if (!t.global) return fail(VG_ERR_INVALID_ARGUMENT, "transformation priors are supported on global transforms only");
+    // a sequence transform gets the block on its element 0: getTransformData(name) defaults to index 0 (:826)
+    if (!t.global && t.count < 1) return fail(VG_ERR_INVALID_ARGUMENT, "the sequence transform is empty");
     vgi::Prior pr;
     pr.tf = transform_id;
     for (int k = 0; k < 6; k++) pr.xi[k] = t.init[k];

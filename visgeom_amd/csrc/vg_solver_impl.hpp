@@ -108,10 +108,28 @@ int launch_dense_gram(hipStream_t st, const double *X, unsigned n_rows, int C, u
 // take the place of the per-pose rows in the Schur complement, and later back-substitutes.  O(n * 6^2 * G) per
 // iteration on one core: meant for the few-hundred-pose odometry sets the reference targets.
 // ------------------------------------------------------------------------------------------
+// TransformationPrior::Evaluate, calib_cost_functions.cpp:214-228: r = A * blockdiag(R, R) * (prior^-1 o xi); J = A
+inline void prior_residual(const vgi::Prior &pr, const double *xi6, double *r)
+{
+    vgth::Array6d prior, xi;
+    for (int k = 0; k < 6; k++) { prior[k] = pr.xi[k]; xi[k] = xi6[k]; }
+    const vgth::Array6d e = vgth::inverse_compose(prior, xi);
+    double er[6];
+    for (int k = 0; k < 3; k++) {
+        er[k] = pr.R[3 * k] * e[0] + pr.R[3 * k + 1] * e[1] + pr.R[3 * k + 2] * e[2];
+        er[3 + k] = pr.R[3 * k] * e[3] + pr.R[3 * k + 1] * e[4] + pr.R[3 * k + 2] * e[5];
+    }
+    for (int k = 0; k < 6; k++) {
+        r[k] = 0.;
+        for (int c = 0; c < 6; c++) r[k] += pr.A[6 * k + c] * er[c];
+    }
+}
+
 struct CoupledSeq {
     int tf = -1;
-    int64_t pb = 0, n = 0, param_off = 0;
+    int64_t pb = 0, n = 0, param_off = 0;   // first pose block, number of elements, first parameter of the range
     std::vector<vgodo::Block> blocks;       // sorted by element index
+    std::vector<std::pair<int64_t, vgi::Prior>> unary;  // TransformationPrior blocks on single elements of the range
     std::vector<unsigned char> frozen;      // per element
     std::vector<double> x, xc;              // current / candidate values [n][6]
     std::vector<double> Cf, Bs;             // per element: Cholesky factor C_i (lower, 6x6 row-major), B_i = L_{i+1,i}
@@ -123,6 +141,11 @@ struct CoupledSeq {
         for (const auto &b : blocks) {
             double r[6];
             vgodo::evaluate(b, &xv[(size_t)b.i * 6], &xv[(size_t)(b.i + 1) * 6], r, nullptr, nullptr);
+            for (int k = 0; k < 6; k++) c += r[k] * r[k];
+        }
+        for (const auto &u : unary) {
+            double r[6];
+            prior_residual(u.second, &xv[(size_t)u.first * 6], r);
             for (int k = 0; k < 6; k++) c += r[k] * r[k];
         }
         return c;
@@ -178,6 +201,21 @@ struct CoupledSeq {
                 for (int k = 0; k < 6; k++) { g1 += J1[6 * k + a2] * r[k]; g2 += J2[6 * k + a2] * r[k]; }
                 g[(size_t)b.i * 6 + a2] += g1;
                 g[(size_t)(b.i + 1) * 6 + a2] += g2;
+            }
+        }
+        for (const auto &u : unary) {  // constant Jacobian A
+            double r[6];
+            prior_residual(u.second, &x[(size_t)u.first * 6], r);
+            const double *A = u.second.A;
+            for (int a2 = 0; a2 < 6; a2++) {
+                for (int b2 = 0; b2 < 6; b2++) {
+                    double s2 = 0.;
+                    for (int k = 0; k < 6; k++) s2 += A[6 * k + a2] * A[6 * k + b2];
+                    H[(size_t)u.first * 36 + 6 * a2 + b2] += s2;
+                }
+                double g1 = 0.;
+                for (int k = 0; k < 6; k++) g1 += A[6 * k + a2] * r[k];
+                g[(size_t)u.first * 6 + a2] += g1;
             }
         }
         Dd.assign((size_t)n * 6, 0.);
@@ -392,10 +430,26 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
         }
         cs->blocks.push_back(b);
     }
+    for (const auto &pr : p->priors) {  // TransformationPrior on a sequence = on its element 0
+        if (p->tfs[pr.tf].global) continue;
+        CoupledSeq *cs = nullptr;
+        for (auto &c2 : coupled)
+            if (c2.tf == pr.tf) cs = &c2;
+        if (!cs) {  // no odometry on this sequence: only element 0 leaves the per-pose GPU path
+            coupled.emplace_back();
+            cs = &coupled.back();
+            cs->tf = pr.tf;
+            cs->pb = tf_pbase[pr.tf];
+            cs->n = 1;
+            cs->param_off = p->tfs[pr.tf].offset;
+            cs->frozen.assign(1, p->tfs[pr.tf].constant ? 1 : 0);
+        }
+        cs->unary.emplace_back((int64_t)0, pr);
+    }
     for (const auto &cp : p->const_poses) {
         pose_frozen[(size_t)(tf_pbase[cp.first] + cp.second)] = 1;
         for (auto &c2 : coupled)
-            if (c2.tf == cp.first) c2.frozen[(size_t)cp.second] = 1;
+            if (c2.tf == cp.first && cp.second < c2.n) c2.frozen[(size_t)cp.second] = 1;
     }
     for (auto &c2 : coupled) {
         std::sort(c2.blocks.begin(), c2.blocks.end(), [](const vgodo::Block &a2, const vgodo::Block &b2) { return a2.i < b2.i; });
@@ -404,7 +458,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
         c2.xc.resize((size_t)c2.n * 6);
     }
     if (!coupled.empty() && opt.allreduce)
-        return fail(VG_ERR_INVALID_ARGUMENT, "OdometryPrior blocks are not supported together with a multi-rank all-reduce");
+        return fail(VG_ERR_INVALID_ARGUMENT, "OdometryPrior blocks and priors on sequence elements are not supported together with a multi-rank all-reduce");
 
     // per dataset: local -> global column map, pose column offset, pose references
     std::vector<std::vector<int>> lmap(n_ds);
@@ -559,19 +613,10 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
     // (calib_cost_functions.cpp:214-228).  Added AFTER the all-reduce, identically on every rank.
     auto add_priors = [&](const std::vector<double> &xg_vals, std::vector<double> &Uo, std::vector<double> &go, double &c2) {
         for (const vgi::Prior &pr : p->priors) {
+            if (!p->tfs[pr.tf].global) continue;  // element 0 of a sequence: handled with the poses (CoupledSeq::unary)
             const int g0 = tf_goff[pr.tf];
-            vgth::Array6d prior, xi;
-            for (int k = 0; k < 6; k++) { prior[k] = pr.xi[k]; xi[k] = xg_vals[g0 + k]; }
-            const vgth::Array6d e = vgth::inverse_compose(prior, xi);
-            double er[6], r[6];
-            for (int k = 0; k < 3; k++) {
-                er[k] = pr.R[3 * k] * e[0] + pr.R[3 * k + 1] * e[1] + pr.R[3 * k + 2] * e[2];
-                er[3 + k] = pr.R[3 * k] * e[3] + pr.R[3 * k + 1] * e[4] + pr.R[3 * k + 2] * e[5];
-            }
-            for (int k = 0; k < 6; k++) {
-                r[k] = 0.;
-                for (int c2i = 0; c2i < 6; c2i++) r[k] += pr.A[6 * k + c2i] * er[c2i];
-            }
+            double r[6];
+            prior_residual(pr, &xg_vals[g0], r);
             for (int a2 = 0; a2 < 6; a2++) {
                 for (int b2 = 0; b2 < 6; b2++) {
                     double h = 0.;
