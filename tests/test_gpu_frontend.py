@@ -164,3 +164,47 @@ def test_handeye_with_odometry_entry(gpu, tmp_path):
     r = subprocess.run([_build.CLI, path], capture_output=True, text=True, cwd=str(tmp_path), timeout=300)
     assert r.returncode == 0, r.stderr
     assert "Sequence : xiOdomBase" in r.stdout and "xiBaseCam" in r.stdout
+
+
+def test_images_dataset_skips_frames_missing_in_the_initialising_dataset(gpu, tmp_path):
+    """extractGridProjections :1006-1023: camera 2 re-uses the stereo sequence camera 1 initialised; a frame without
+    a pattern in camera 1's dataset is skipped in camera 2's as well (its pose was never initialised)."""
+    import json
+
+    from visgeom_amd import synthetic as S
+    from visgeom_amd.calibration import GenericCameraCalibration
+
+    n, miss = 14, 5
+    st = S.make_stereo(n, sigma=0.0)
+    obj = {"type": "checkboard", "cols": 12, "rows": 8, "size": 0.1}
+
+    def corners(name, cam, arr, skip=()):
+        json.dump([[] if i in skip else [{"camera": cam, "points": a.tolist()}] for i, a in enumerate(arr)], open(tmp_path / name, "w"))
+        return name
+
+    def entry(cam, init, chain, file):
+        return {"type": "images", "camera": cam, "init": init, "parameters": [], "object": obj,
+                "transform_chain": [{"name": nm, "direct": dr} for nm, dr in chain], "corners_file": file,
+                "images": {"prefix": "/nowhere/", "names": []}}
+
+    root = {"transformations": [{"name": "xiCamBoardStereo", "global": False, "constant": False, "prior": False},
+                                {"name": "xiCam12", "global": True, "constant": False, "prior": True,
+                                 "value": (st["gt_xi12"] + 0.004).tolist()}],
+            "cameras": [{"name": "camera1", "type": "eucm", "constant": False, "value": S.INIT["eucm"].tolist()},
+                        {"name": "camera2", "type": "eucm", "constant": False, "value": S.INIT["eucm"].tolist()}],
+            "data": [entry("camera1", "xiCamBoardStereo", [("xiCamBoardStereo", True)], corners("s1.json", "camera1", st["corners1"], skip=(miss,))),
+                     entry("camera2", "none", [("xiCam12", False), ("xiCamBoardStereo", True)], corners("s2.json", "camera2", st["corners2"]))]}
+    path = tmp_path / "stereo_skip.json"
+    json.dump(root, open(path, "w"))
+    c = GenericCameraCalibration()
+    c.addResiduals(path)
+    assert "image %d : ERROR, the pattern has not been found on the corresponding image" % miss in c.log()
+    c.compute(max_num_iterations=200)
+    assert c.summary["num_pose_blocks"] == n                      # the placeholder pose is still a parameter block
+    sig, _ = c.writeImageResidual(1, tmp_path / "image_error_1.txt", n_images=n)
+    assert sig[miss] == 0 and np.loadtxt(tmp_path / "image_error_1.txt").shape[0] == (n - 1) * 96
+    keep = [i for i in range(n) if i != miss]
+    assert np.max(np.abs(c.transform("xiCamBoardStereo")[keep] - st["gt_poses"][keep])) < 1e-6
+    assert np.array_equal(c.transform("xiCamBoardStereo")[miss], [0, 0, 1, 0, 0, 0])
+    assert np.max(np.abs(c.transform("xiCam12").ravel() - st["gt_xi12"])) < 1e-6
+    c.close()

@@ -539,6 +539,24 @@ inline void parse_data(vg_calibration *c, const vgjson::Value &root, const std::
                 if (idx < 0 || idx >= nb) throw Error{VG_ERR_INVALID_ARGUMENT, "board corner index out of range"};
             if (!file.empty() && file[0] != '/') file = base_dir + file;
             read_corners(data, file, data.cameraName);
+            if (type == "images") {
+                // extractGridProjections :996-1023: when the chain's sequence has already been initialised through another
+                // dataset, an image whose counterpart there had no pattern is skipped here as well
+                std::string sequenceName;
+                for (auto &name : data.transNameVec)
+                    if (!c->transformInfoMap[name].global) {
+                        sequenceName = name;
+                        break;
+                    }
+                const std::vector<bool> &initVec = c->sequenceInitMap[sequenceName];
+                if (c->transformInfoMap[sequenceName].initialized)
+                    for (size_t i = 0; i < data.detectedCornersVec.size(); i++)
+                        if ((i >= initVec.size() || !initVec[i]) && !data.detectedCornersVec[i].empty()) {
+                            c->log += "image " + std::to_string(i) +
+                                      " : ERROR, the pattern has not been found on the corresponding image\n";
+                            data.detectedCornersVec[i].clear();
+                        }
+            }
             init_transforms(c, data, di.at("init").as_string());
             // addGridResidualBlocks (:514-630) happens when the GPU problem is assembled, in compute()
         } else if (type == "odometry") {  // :743-807
