@@ -223,6 +223,10 @@ typedef struct vg_solve_options {
     double max_lm_diagonal;             /* 1e32 */
     int use_bounds;                     /* 1 */
     int verbose;                        /* minimizer_progress_to_stdout, :51 */
+    double soft_l1_scale;               /* 0: no loss function (the global problem, :539-564 pass NULL).  a > 0:
+                                           ceres::SoftLOneLoss(a) on every grid residual block, rho(s) =
+                                           2 a^2 (sqrt(1 + s / a^2) - 1) of the block's squared norm s -- what the two
+                                           initial refinements use (a = 25 :1143, a = 1 :379-401) */
     vg_allreduce_fn allreduce;          /* multi-GPU: images sharded over ranks, global parameters replicated */
     void *allreduce_user;
 } vg_solve_options;

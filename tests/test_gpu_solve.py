@@ -405,3 +405,56 @@ def test_transformation_prior_on_a_sequence_acts_on_element_zero(vg, with_odomet
     free = least_squares(lambda z: fun(z)[:2 * N * n], x0, method="trf", x_scale="jac", max_nfev=200)
     assert np.max(np.abs(x[6:12] - free.x[6:12])) > 1e-4
     p.close()
+
+
+def test_soft_l1_loss_per_residual_block(vg):
+    """vg_solve_options.soft_l1_scale = a: ceres::SoftLOneLoss(a) on every grid block (what the reference's initial
+    refinements use, unified_calibration.cpp:379-401 a = 1, :1143 a = 25).  Intrinsics free, poses constant, one image
+    with corners shifted by 25 px: the robust optimum must equal scipy's minimum of sum_b rho(|r_b|^2) over the
+    oracle's residuals, and sit closer to the generating intrinsics than the plain least-squares one."""
+    from scipy.optimize import least_squares
+
+    from visgeom_amd import synthetic as S
+
+    n, N, a = 12, 96, 1.0
+    d = S.make_mono("eucm", n, 2, sigma=0.1)
+    corners = d["corners"].copy()
+    corners[4] += np.array([25.0, -15.0])
+    x0 = np.concatenate([d["init_intrinsics"], d["gt_poses"].ravel()])
+
+    def blocks(k):
+        x = x0.copy()
+        x[:6] = k
+        r, _, _ = vgo.eval_dataset(0, [0], d["board"], corners, x, 0, [6], [6], np.arange(n), want_jac=False)
+        return r.reshape(n, -1)
+
+    def robust(k):
+        r = blocks(k)
+        s = np.sum(r * r, axis=1)
+        rho = 2 * a * a * (np.sqrt(1 + s / (a * a)) - 1)
+        return (r * np.sqrt(rho / s)[:, None]).ravel()
+
+    ref = least_squares(robust, x0[:6], jac="3-point", x_scale="jac", xtol=1e-15, ftol=1e-15, gtol=1e-15, max_nfev=2000)
+    plain = least_squares(lambda k: blocks(k).ravel(), x0[:6], jac="3-point", x_scale="jac", xtol=1e-15, ftol=1e-15, gtol=1e-15)
+
+    def solve(scale):
+        p = vg.CalibrationProblem(0)
+        cam = p.add_camera("eucm", d["init_intrinsics"])
+        seq = p.add_transform(False, d["gt_poses"], constant=True)
+        p.add_dataset(cam, [(seq, 0)], d["board"], corners)
+        p.finalize()
+        summ = p.solve(max_num_iterations=300, use_bounds=0, soft_l1_scale=scale)
+        k = p.get_parameters()[:6]
+        p.close()
+        return summ, k
+
+    s_rob, k_rob = solve(a)
+    s_pl, k_pl = solve(0.0)
+    print("soft-l1", s_rob["termination"], s_rob["num_iterations"], "cost %.8e scipy %.8e" % (s_rob["final_cost"], ref.cost),
+          "| plain cost %.6e" % s_pl["final_cost"])
+    assert abs(s_rob["final_cost"] - ref.cost) <= 1e-9 * ref.cost
+    assert rel(k_rob, ref.x) < 1e-6
+    assert abs(s_pl["final_cost"] - plain.cost) <= 1e-9 * plain.cost and rel(k_pl, plain.x) < 1e-6
+    e_rob, e_pl = rel(k_rob, d["gt_intrinsics"]), rel(k_pl, d["gt_intrinsics"])
+    print("error vs generating intrinsics: robust %.2e plain %.2e" % (e_rob, e_pl))
+    assert e_rob < 0.5 * e_pl

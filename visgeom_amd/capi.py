@@ -34,7 +34,7 @@ class SolveOptions(ctypes.Structure):
                 ("initial_trust_region_radius", ctypes.c_double), ("max_trust_region_radius", ctypes.c_double),
                 ("min_trust_region_radius", ctypes.c_double), ("min_relative_decrease", ctypes.c_double),
                 ("min_lm_diagonal", ctypes.c_double), ("max_lm_diagonal", ctypes.c_double),
-                ("use_bounds", ctypes.c_int), ("verbose", ctypes.c_int),
+                ("use_bounds", ctypes.c_int), ("verbose", ctypes.c_int), ("soft_l1_scale", ctypes.c_double),
                 ("allreduce", ALLREDUCE_FN), ("allreduce_user", ctypes.c_void_p)]
 
 

@@ -175,7 +175,8 @@ struct Error {
 inline void refine_on_gpu(vg_calibration *c, const ImageData &data, const std::vector<int> &images,
                           const std::vector<std::string> &chain_names, const std::vector<int> &chain_status,
                           const std::vector<std::vector<Array6d> *> &chain_values,  // per member: pointer to values
-                          const std::vector<bool> &chain_is_seq, const std::vector<bool> &chain_const, int max_iter)
+                          const std::vector<bool> &chain_is_seq, const std::vector<bool> &chain_const, int max_iter,
+                          double soft_l1_scale)
 {
     vg_problem *p = nullptr;
     auto chk = [&](int rc) {
@@ -215,6 +216,7 @@ inline void refine_on_gpu(vg_calibration *c, const ImageData &data, const std::v
     o.function_tolerance = 1e-6;
     o.gradient_tolerance = 1e-10;
     o.parameter_tolerance = 1e-8;
+    o.soft_l1_scale = soft_l1_scale;  // new SoftLOneLoss(a) of the reference's sub-problems
     vg_solve_summary s;
     chk(vg_problem_solve(p, &o, &s));
     std::vector<double> x((size_t)vg_problem_num_parameters(p));
@@ -312,7 +314,7 @@ inline std::vector<Array6d> estimate_initial_grids(vg_calibration *c, const Imag
     std::vector<Array6d> cam_pose(data.detectedCornersVec.size(), Array6d{0, 0, 1, 0, 0, 0});
     for (int img : images) cam_pose[(size_t)img] = estimate_initial_grid_geometric(c, data, img);
     if (!data.doNotSolve && !images.empty())
-        refine_on_gpu(c, data, images, {"__camera_frame__"}, {VG_TRANSFORM_DIRECT}, {&cam_pose}, {true}, {false}, 500);
+        refine_on_gpu(c, data, images, {"__camera_frame__"}, {VG_TRANSFORM_DIRECT}, {&cam_pose}, {true}, {false}, 500, 25.);  // SoftLOneLoss(25) :1143
     return cam_pose;
 }
 
@@ -375,7 +377,7 @@ inline void init_transforms(vg_calibration *c, ImageData &data, const std::strin
                     vals.push_back(&glob_store[l]);
                 }
             }
-            refine_on_gpu(c, data, images, data.transNameVec, data.transStatusVec, vals, is_seq, is_const, 500);
+            refine_on_gpu(c, data, images, data.transNameVec, data.transStatusVec, vals, is_seq, is_const, 500, 1.);  // SoftLOneLoss(1) :379-401
             for (size_t l = 0; l < data.transNameVec.size(); l++)
                 if (data.transNameVec[l] == initName) c->globalTransformMap[initName] = glob_store[l][0];
         }

@@ -185,6 +185,20 @@ __global__ __launch_bounds__(256) void vg_schur_rows_kernel(SchurArgs a)
     for (int k = 0; k < 6; k++) out[k * C] = active ? y[k] : 0.;
 }
 
+// ceres::SoftLOneLoss(a) on one residual block = one image: rho(s) = 2 a^2 (sqrt(1 + s / a^2) - 1), s = r^T r.
+// rho'' < 0, so Ceres' Corrector only scales residuals and Jacobian rows by sqrt(rho'): the block's Gram matrix
+// becomes rho' * G, and its last entry (r^T r, twice the cost term) becomes rho(s).  One wave per block; the wave
+// reads s before any of its lanes writes.
+__global__ __launch_bounds__(64) void vg_gram_soft_l1_kernel(double *__restrict__ gram, int entries, double a2)
+{
+    double *G = gram + (size_t)blockIdx.x * entries;
+    const double s = G[entries - 1];
+    const double q = sqrt(1. + s / a2);
+    const double w = 1. / q, rho = 2. * a2 * (q - 1.);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int e = threadIdx.x; e < entries; e += kWave) G[e] = e == entries - 1 ? rho : w * G[e];
+}
+
 struct BacksubArgs {
     SchurArgs s;
     const double *dg;              // [G] global step

@@ -350,6 +350,7 @@ void vg_solve_options_init(vg_solve_options *o)
     o->max_lm_diagonal = 1e32;
     o->use_bounds = 1;
     o->verbose = 0;
+    o->soft_l1_scale = 0.;
     o->allreduce = nullptr;
     o->allreduce_user = nullptr;
 }
@@ -576,6 +577,14 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
         if ((r = vgi::prepare_at(p, x_dev)) != VG_OK) return r;
         for (int d = 0; d < n_ds; d++) {
             if ((r = vgi::gram_fused_at(p, d, x_dev, set[d].p)) != VG_OK) return r;
+            if (opt.soft_l1_scale > 0. && p->dss[d].n_blocks) {
+                // robustified blocks: J'^T J' = rho' J^T J, J'^T r' = rho' J^T r, cost term rho(s)   (Ceres' Corrector
+                // with rho'' < 0, always the case for SoftLOne) -- re-weight the Gram blocks in place, nothing
+                // downstream changes
+                hipLaunchKernelGGL(vg::vg_gram_soft_l1_kernel, dim3((unsigned)p->dss[d].n_blocks), dim3(64), 0, st, set[d].p,
+                                   Wd[d] * Wd[d], opt.soft_l1_scale * opt.soft_l1_scale);
+                VG_HIP(hipGetLastError());
+            }
             if ((r = vgi::gram_sum_into(p, d, set[d].p, d_sums.p + (size_t)d * Wmax * Wmax)) != VG_OK) return r;
         }
         VG_HIP(hipMemcpyAsync(pin_sums.p, d_sums.p, sizeof(double) * h_sums.size(), hipMemcpyDeviceToHost, st));
