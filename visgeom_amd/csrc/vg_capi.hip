@@ -395,7 +395,10 @@ int vg_problem_finalize(vg_problem *p)
         if (!d.n_blocks) continue;
         vg::PrepDataset pd;
         pd.chain = d.chain;
-        pd.seq_index = d.d_seq;
+        // image b uses element b of its sequence (the common case): no index array -> one dependent load less
+        bool identity = true;
+        for (size_t i = 0; i < d.h_seq.size() && identity; i++) identity = d.h_seq[i] == (int32_t)i;
+        pd.seq_index = identity ? nullptr : d.d_seq;
         pd.frames = d.d_frames;
         pd.first = first;
         pd.count = d.n_blocks;
