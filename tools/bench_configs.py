@@ -1,0 +1,125 @@
+#!/usr/bin/env python3
+"""One-GPU measurements of BASELINE.json's configs 2-5 (config 1 is the plumbing case of tests/test_gpu_frontend.py):
+emit pass (residual + all Jacobian blocks to HBM), fused normal-equation build, full LM solve.  Prints a markdown
+table + one JSON line per config; tools only, bench.py stays the driver's contract (config named by `metric`).
+
+usage: python tools/bench_configs.py [reps]
+"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from visgeom_amd import CalibrationProblem, synthetic  # noqa: E402
+
+REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+KOF = {"eucm": 6, "ucm": 5, "mei": 10}
+
+
+def timed(fn, reps=REPS):
+    for _ in range(max(3, reps // 10)):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e-3   # seconds
+
+
+def build(cfg):
+    p = CalibrationProblem(0)
+    if cfg == 2 or cfg == 4:
+        model, n = ("eucm", 1000) if cfg == 2 else ("mei", 10000)
+        d = synthetic.make_mono(model, n, cfg)
+        cam = p.add_camera(model, d["init_intrinsics"])
+        seq = p.add_transform(False, d["init_poses"])
+        dss = [(p.add_dataset(cam, [(seq, 0)], d["board"], d["corners"]), model, 1, n)]
+        gt = [d["gt_intrinsics"]]
+        name = "config %d: %s mono, %d images" % (cfg, model.upper(), n)
+    elif cfg == 3:
+        s = synthetic.make_stereo(2000)
+        c1 = p.add_camera("eucm", s["init_intrinsics1"])
+        c2 = p.add_camera("eucm", s["init_intrinsics2"])
+        x12 = p.add_transform(True, s["init_xi12"])
+        seq = p.add_transform(False, s["init_poses"])
+        dss = [(p.add_dataset(c1, [(seq, 0)], s["board"], s["corners1"]), "eucm", 1, 2000),
+               (p.add_dataset(c2, [(x12, 1), (seq, 0)], s["board"], s["corners2"]), "eucm", 2, 2000)]
+        gt = [s["gt_intrinsics1"], s["gt_intrinsics2"]]
+        name = "config 3: stereo 2 x EUCM + xiCam12, 2000 pairs"
+    else:
+        r = synthetic.make_rig(5000)
+        cams = [p.add_camera(m, r["init_intrinsics"][k]) for k, m in enumerate(r["models"])]
+        x1k = [p.add_transform(True, r["init_xi1k"][k]) for k in range(3)]
+        seq = p.add_transform(False, r["init_poses"])
+        dss = [(p.add_dataset(cams[0], [(seq, 0)], r["board"], r["corners"][0]), r["models"][0], 1, 5000)]
+        for k in range(3):
+            dss.append((p.add_dataset(cams[k + 1], [(x1k[k], 1), (seq, 0)], r["board"], r["corners"][k + 1]), r["models"][k + 1], 2, 5000))
+        gt = r["gt_intrinsics"]
+        name = "config 5: rig [UCM, EUCM, EUCM, Mei], 5000 frames"
+    p.finalize()
+    return p, dss, gt, name
+
+
+def main():
+    rows = []
+    for cfg in (2, 3, 4, 5):
+        p, dss, gt, name = build(cfg)
+        outs = [p.alloc_outputs(ds) for ds, _, _, _ in dss]
+        grams = [p.alloc_gram(ds) for ds, _, _, _ in dss]
+        n_obs = sum(n * 96 for _, _, _, n in dss)
+        bytes_emit = sum(n * 96 * (32 + 16 * (KOF[m] + 6 * L)) for _, m, L, n in dss)
+
+        def emit():
+            p.prepare()
+            for (ds, _, _, _), (res, ji, jm) in zip(dss, outs):
+                p.evaluate_dataset(ds, res, ji, jm)
+
+        def emit_only():
+            for (ds, _, _, _), (res, ji, jm) in zip(dss, outs):
+                p.evaluate_dataset(ds, res, ji, jm)
+
+        def jtj():
+            p.prepare()
+            for (ds, _, _, _), (gram, gsum) in zip(dss, grams):
+                p.gram_fused(ds, gram)
+                p.gram_sum(ds, gram, gsum)
+
+        t_emit, t_emit_only, t_jtj = timed(emit), timed(emit_only), timed(jtj)
+        x0 = p.get_parameters()
+        best = None
+        for _ in range(3):
+            p.set_parameters(x0)
+            torch.cuda.synchronize()
+            s = p.solve(max_num_iterations=200)
+            if best is None or s["total_seconds"] < best["total_seconds"]:
+                best = s
+        x = p.get_parameters()
+        err, off = 0.0, 0
+        for g in gt:
+            err = max(err, float(np.max(np.abs(x[off:off + g.size] - g) / np.maximum(np.abs(g), 1.0))))
+            off += g.size
+        row = {"config": name, "observations": n_obs, "emit_ms": t_emit * 1e3, "evals_per_s": n_obs / t_emit,
+               "emit_kernels_GBps": bytes_emit / t_emit_only / 1e9, "emit_bytes": bytes_emit, "jtj_fused_ms": t_jtj * 1e3,
+               "solve_ms": best["total_seconds"] * 1e3, "solve_iterations": best["num_iterations"],
+               "termination": best["termination"], "global_columns": best["num_global_columns"],
+               "max_rel_intrinsics_error_vs_generating": err}
+        rows.append(row)
+        print(json.dumps(row))
+        p.close()
+    print()
+    print("| config | observations | step (prep + emit) ms | evals/s | emit kernels GB/s (algorithmic) | JtJ fused ms/iter | LM solve ms (iterations) | G | intrinsics vs generating |")
+    print("|---|---|---|---|---|---|---|---|---|")
+    for r in rows:
+        print("| %s | %d | %.4f | %.3e | %.0f | %.4f | %.2f (%d) | %d | %.1e |" % (
+            r["config"], r["observations"], r["emit_ms"], r["evals_per_s"], r["emit_kernels_GBps"], r["jtj_fused_ms"],
+            r["solve_ms"], r["solve_iterations"], r["global_columns"], r["max_rel_intrinsics_error_vs_generating"]))
+
+
+if __name__ == "__main__":
+    main()

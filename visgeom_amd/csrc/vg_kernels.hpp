@@ -120,11 +120,54 @@ __device__ __forceinline__ void wave_store_rows(double *__restrict__ stage, cons
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Same tile for every model: rows wider than a pose block (Mei, K = 10) are staged in two half-waves of 32
+// observations each, so the LDS footprint -- and with it the number of resident waves that keep stores in flight --
+// does not depend on K (with a 10 KiB tile per wave only 3 workgroups fit a CU and Mei streamed at 5.2 TB/s).
+constexpr int kStageRowDoubles = 6;
+
 template <int MODEL>
 constexpr int emit_stage_doubles_per_wave()
 {
-    constexpr int K = CameraTraits<MODEL>::K;
-    return 2 * kWave * (K > 6 ? K : 6);
+    return 2 * kWave * kStageRowDoubles;
+}
+
+// wave_store_rows for S > kStageRowDoubles: lanes [32h, 32h + 32) stage their rows, the whole wave streams the
+// 32 * 16 * S contiguous bytes out, h = 0, 1.
+template <int S>
+__device__ __forceinline__ void wave_store_rows_halves(double *__restrict__ stage, const double *vals,
+                                                       double *__restrict__ out_tile, int n_valid_obs, int lane)
+{
+    static_assert(S <= 2 * kStageRowDoubles, "half a wave of rows must fit the tile");
+    using d2 = HIP_vector_type<double, 2>;
+    d2 *st = reinterpret_cast<d2 *>(stage);
+    constexpr int kHalf = kWave / 2;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        if ((lane >> 5) == h) {
+#pragma unroll
+            for (int i = 0; i < S; i++) {
+                d2 v;
+                v.x = vals[2 * i];
+                v.y = vals[2 * i + 1];
+                st[(lane & (kHalf - 1)) * S + i] = v;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        int nv = n_valid_obs - h * kHalf;
+        nv = nv < 0 ? 0 : (nv > kHalf ? kHalf : nv);
+        const int n16 = nv * S;
+        d2 *dst = reinterpret_cast<d2 *>(out_tile) + h * kHalf * S;
+#pragma unroll
+        for (int k = 0; k < (kHalf * S + kWave - 1) / kWave; k++) {
+            const int idx = k * kWave + lane;
+            if (idx < n16) dst[idx] = st[idx];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
 }
 
 // dynamic LDS: 4 wave tiles, then (FRAMES_LDS) the frames of the images this workgroup touches
@@ -208,7 +251,8 @@ __global__ __launch_bounds__(kEmitThreads) void vg_emit_kernel(EmitArgs a)
                 rows[i] = e.Ju[i];
                 rows[K + i] = e.Jv[i];
             }
-            wave_store_rows<K>(stage, rows, a.jac_intr + (size_t)ow * (2 * K), n_valid, lane);
+            if (K > kStageRowDoubles) wave_store_rows_halves<K>(stage, rows, a.jac_intr + (size_t)ow * (2 * K), n_valid, lane);
+            else wave_store_rows<(K > kStageRowDoubles ? 1 : K)>(stage, rows, a.jac_intr + (size_t)ow * (2 * K), n_valid, lane);
         }
         // pose blocks, u-row at +12i, v-row at +12i+6       calib_cost_functions.cpp:93-101
         for (int l = 0; l < a.L; l++) {
