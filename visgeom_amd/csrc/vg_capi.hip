@@ -128,7 +128,8 @@ void fill_gram_args(const vg_problem *p, const Dataset &d, vg::GramArgs &a, doub
 template <int MODEL>
 int launch_gram_fused(hipStream_t stream, const vg::GramArgs &a)
 {
-    const int T = (a.W + 15) / 16;
+    const bool rcol = a.W == 17;  // 16 Jacobian columns + residual (Mei mono): residual row / column on the lanes
+    const int T = rcol ? 1 : (a.W + 15) / 16;
     // one LDS tile per wave (= per pair of images); as many waves per workgroup (<= 4) as fit in 80 KiB, so
     // that two workgroups share a CU (160 KiB LDS) and one can contract while the other evaluates
     const size_t tile = (size_t)vg::gram_wave_lds_doubles(a.W, a.frame_stride_d) * sizeof(double);
@@ -138,7 +139,8 @@ int launch_gram_fused(hipStream_t stream, const vg::GramArgs &a)
     const unsigned int grid = (n_pairs + waves - 1) / waves;
     const size_t lds = (size_t)waves * tile;
     const dim3 blk(waves * vg::kWave);
-    if (T == 1) hipLaunchKernelGGL((vg::vg_gram_fused_kernel<MODEL, 1>), dim3(grid), blk, lds, stream, a);
+    if (rcol) hipLaunchKernelGGL((vg::vg_gram_fused_kernel<MODEL, 1, false, true>), dim3(grid), blk, lds, stream, a);
+    else if (T == 1) hipLaunchKernelGGL((vg::vg_gram_fused_kernel<MODEL, 1>), dim3(grid), blk, lds, stream, a);
     else if (T == 2 && a.W - 16 <= vg::kCornerMax)
         hipLaunchKernelGGL((vg::vg_gram_fused_kernel<MODEL, 2, true>), dim3(grid), blk, lds, stream, a);
     else if (T == 2) hipLaunchKernelGGL((vg::vg_gram_fused_kernel<MODEL, 2>), dim3(grid), blk, lds, stream, a);

@@ -108,10 +108,15 @@ __host__ __device__ constexpr int gram_wave_lds_doubles(int W, int frame_stride_
 // accumulated by the lanes instead (<= 10 products per row) and reduced once per image with shuffles.
 constexpr int kCornerMax = 4;
 
-template <int MODEL, int T, bool CORNER = false>
+//
+// RCOL (only with T == 1, W == 17 -- Mei mono: K + 6 = 16 Jacobian columns + the residual column): the Jacobian
+// columns fill the 16 x 16 MFMA tile exactly, so the whole 17th row/column (J^T r and r^T r) is accumulated by the
+// lanes -- 17 products per row -- instead of costing a second MFMA per 4 rows that would be 15/16 padding.
+template <int MODEL, int T, bool CORNER = false, bool RCOL = false>
 __global__ __launch_bounds__(kGramMaxWavesPerBlock *kWave) void vg_gram_fused_kernel(GramArgs a)
 {
     static_assert(!CORNER || T == 2, "the VALU corner only exists for two column tiles");
+    static_assert(!RCOL || (T == 1 && !CORNER), "the VALU residual column goes with one full column tile");
     constexpr int K = CameraTraits<MODEL>::K;
     using d2 = HIP_vector_type<double, 2>;
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -142,6 +147,9 @@ __global__ __launch_bounds__(kGramMaxWavesPerBlock *kWave) void vg_gram_fused_ke
 #pragma unroll
     for (int q = 0; q < kCornerMax * (kCornerMax + 1) / 2; q++) cacc[q] = 0.;
     const int Wc = CORNER ? W - 16 : 0;  // 1 .. kCornerMax
+    double racc[RCOL ? 17 : 1];
+#pragma unroll
+    for (int q = 0; q < (RCOL ? 17 : 1); q++) racc[q] = 0.;
     const int c16 = lane & 15, k4 = lane >> 4;
 
     for (unsigned int c0 = 0; c0 < a.N; c0 += kGramHalf) {
@@ -197,6 +205,13 @@ __global__ __launch_bounds__(kGramMaxWavesPerBlock *kWave) void vg_gram_fused_ke
 #pragma unroll
                 for (int c = r; c < kCornerMax; c++, q++) cacc[q] += cu[r] * cu[c] + cv[r] * cv[c];
         }
+        if (RCOL) {
+            // this lane's own two rows (just written, zeroed when the lane has no corner): column 16 against all 17
+            const double su = ru[16], sv = rv[16];
+#pragma unroll
+            for (int q = 0; q < 16; q++) racc[q] += ru[q] * su + rv[q] * sv;
+            racc[16] += su * su + sv * sv;
+        }
         wave_lds_fence();
 
         // always 16 groups of 4 rows per image: rows of lanes without a corner are zero, so a ragged last
@@ -225,6 +240,22 @@ __global__ __launch_bounds__(kGramMaxWavesPerBlock *kWave) void vg_gram_fused_ke
     }
     store_gram<T, CORNER>(accA, a.gram + (size_t)bA * W * W, W, lane);
     if (bA + 1 < a.n_blocks) store_gram<T, CORNER>(accB, a.gram + (size_t)(bA + 1) * W * W, W, lane);
+    if (RCOL) {
+        // sum over the 32 lanes of each image (fixed butterfly inside the half-wave), lane 0 of the half stores
+#pragma unroll
+        for (int q = 0; q < 17; q++)
+#pragma unroll
+            for (int off = 16; off >= 1; off >>= 1) racc[q] += __shfl_xor(racc[q], off, kWave);
+        if (sl == 0 && bvalid) {
+            double *g = a.gram + (size_t)b * W * W;
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                g[q * W + 16] = racc[q];
+                g[16 * W + q] = racc[q];
+            }
+            g[16 * W + 16] = racc[16];
+        }
+    }
     if (CORNER) {
         // sum over the 32 lanes of each image (fixed butterfly inside the half-wave), lane 0 of the half stores
 #pragma unroll
