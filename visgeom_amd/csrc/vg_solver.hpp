@@ -212,48 +212,69 @@ struct BacksubArgs {
 };
 
 // dp_i = -V_i'^-1 (g_i + W_i^T dg) = -L^-T (L^-1 g_i + (L^-1 W_i^T) dg): everything needed is already in the
-// six rows of the pose (last column = L^-1 g_i), no second gather from the Gram blocks.  The per-pose terms of the
-// model decrease / norms are reduced per wave (fixed butterfly), one partial per 64 poses.
-__global__ __launch_bounds__(64) void vg_backsub_kernel(BacksubArgs b)
+// six rows of the pose (last column = L^-1 g_i), no second gather from the Gram blocks.
+// 16 lanes per pose: the six G-long dot products are read coalesced (16 consecutive doubles per row and step) and
+// reduced inside the 16-lane group; the group's first lane finishes the 6 x 6 triangular solve.  One lane per pose
+// (a serial loop over 6 G uncoalesced loads) took 31 us for 5 000 poses x 45 columns.  The per-pose terms of the model
+// decrease / norms are reduced per workgroup in a fixed order, one partial per kBsPosesPerBlock poses.
+constexpr int kBsGroup = 16;
+constexpr int kBsThreads = 256;
+constexpr int kBsPosesPerGroup = 2;
+constexpr int kBsPosesPerBlock = (kBsThreads / kBsGroup) * kBsPosesPerGroup;
+
+__global__ __launch_bounds__(kBsThreads) void vg_backsub_kernel(BacksubArgs b)
 {
     const SchurArgs &a = b.s;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < a.G) {
-        b.delta[b.gcol_param[i]] = b.dg[i];
-        b.xg[i] = b.x[b.gcol_param[i]];
+    const int t = blockIdx.x * kBsThreads + threadIdx.x;
+    if (t < a.G) {
+        b.delta[b.gcol_param[t]] = b.dg[t];
+        b.xg[t] = b.x[b.gcol_param[t]];
     }
+    if ((int)(blockIdx.x * kBsPosesPerBlock) >= a.n_poses) return;  // workgroups that only carry global columns
+    const int gl = threadIdx.x & (kBsGroup - 1), grp = threadIdx.x >> 4;
+    const int C = a.G + 1;
     double s0 = 0., s1 = 0., s2 = 0., s3 = 0., s4 = 0., s5 = 0.;
-    if (i < a.n_poses) {
-        const double *rec = a.rec + (size_t)i * kPoseRec;
-        double L[21], y[6], x[6];
 #pragma unroll
-        for (int k = 0; k < 21; k++) L[k] = rec[k];
-        const bool active = rec[33] != 0.;
-        const int C = a.G + 1;
-        const double *rows = a.rows + (size_t)i * 6 * C;
+    for (int q = 0; q < kBsPosesPerGroup; q++) {
+        const int i = blockIdx.x * kBsPosesPerBlock + q * (kBsThreads / kBsGroup) + grp;
+        const bool pv = i < a.n_poses;  // uniform inside the 16-lane group
+        const double *rows = a.rows + (size_t)(pv ? i : 0) * 6 * C;
+        double y[6];
 #pragma unroll
         for (int k = 0; k < 6; k++) {
-            double s = rows[k * C + a.G];
-            for (int g = 0; g < a.G; g++) s += rows[k * C + g] * b.dg[g];
+            double s = 0.;
+            for (int g = gl; g < a.G; g += kBsGroup) s += rows[k * C + g] * b.dg[g];
             y[k] = s;
         }
-        bwd6(L, y, x);
-        double *dp = b.delta + b.pose_param[i];
-        const double *xp = b.x + b.pose_param[i];
 #pragma unroll
-        for (int c = 0; c < 6; c++) {
-            const double v = active ? -x[c] : 0.;
-            dp[c] = v;
-            const double g = rec[21 + c];
-            s0 += g * v;
-            s1 += clampd(rec[27 + c], a.dmin, a.dmax) * v * v;
-            if (active) s2 = fmax(s2, fabs(g));
-            if (active) s4 += g * g;
-            s3 += v * v;
-            s5 += xp[c] * xp[c];
+        for (int k = 0; k < 6; k++)
+#pragma unroll
+            for (int off = kBsGroup / 2; off >= 1; off >>= 1) y[k] += __shfl_xor(y[k], off, kWave);
+        if (gl == 0 && pv) {
+            const double *rec = a.rec + (size_t)i * kPoseRec;
+            double L[21], x[6];
+#pragma unroll
+            for (int k = 0; k < 21; k++) L[k] = rec[k];
+            const bool active = rec[33] != 0.;
+#pragma unroll
+            for (int k = 0; k < 6; k++) y[k] += rows[k * C + a.G];
+            bwd6(L, y, x);
+            double *dp = b.delta + b.pose_param[i];
+            const double *xp = b.x + b.pose_param[i];
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                const double v = active ? -x[c] : 0.;
+                dp[c] = v;
+                const double g = rec[21 + c];
+                s0 += g * v;
+                s1 += clampd(rec[27 + c], a.dmin, a.dmax) * v * v;
+                if (active) s2 = fmax(s2, fabs(g));
+                if (active) s4 += g * g;
+                s3 += v * v;
+                s5 += xp[c] * xp[c];
+            }
         }
     }
-    if ((int)(blockIdx.x * blockDim.x) >= a.n_poses) return;  // workgroups that only carry global columns
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
         s0 += __shfl_xor(s0, off, kWave);
@@ -263,14 +284,25 @@ __global__ __launch_bounds__(64) void vg_backsub_kernel(BacksubArgs b)
         s5 += __shfl_xor(s5, off, kWave);
         s2 = fmax(s2, __shfl_xor(s2, off, kWave));
     }
+    __shared__ double red[kBsThreads / kWave][6];
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+        red[wave][0] = s0; red[wave][1] = s1; red[wave][2] = s3; red[wave][3] = s4; red[wave][4] = s5; red[wave][5] = s2;
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
         double *sc = b.scal + (size_t)blockIdx.x * 5;
-        sc[0] = s0;
-        sc[1] = s1;
-        sc[2] = s3;
-        sc[3] = s4;
-        sc[4] = s5;
-        atomicMax(b.gmax_bits, (unsigned long long)__double_as_longlong(s2));  // order preserving for s2 >= 0
+        double m = 0.;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            double v = 0.;
+#pragma unroll
+            for (int w = 0; w < kBsThreads / kWave; w++) v += red[w][k];  // fixed order
+            sc[k] = v;
+        }
+#pragma unroll
+        for (int w = 0; w < kBsThreads / kWave; w++) m = fmax(m, red[w][5]);
+        atomicMax(b.gmax_bits, (unsigned long long)__double_as_longlong(m));  // order preserving for m >= 0
     }
 }
 

@@ -551,7 +551,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
     VG_TRY(d_rslabs.alloc((size_t)n_slabs * C * C));
     VG_TRY(d_rgram.alloc((size_t)C * C));
     VG_TRY(d_dg.alloc((size_t)(G ? G : 1)));
-    const unsigned int n_bs_groups = (unsigned int)((n_poses + 63) / 64);
+    const unsigned int n_bs_groups = (unsigned int)((n_poses + vg::kBsPosesPerBlock - 1) / vg::kBsPosesPerBlock);
     DevBuf<double> d_scal_sum, d_xg;
     DevBuf<unsigned long long> d_gmax;
     VG_TRY(d_scal.alloc((size_t)n_bs_groups * 5));
@@ -762,9 +762,9 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             ba.gmax_bits = d_gmax.p;
             ba.x = d_x.p;
             ba.xg = d_xg.p;
-            const int64_t nthr = n_poses > G ? n_poses : G;
-            if (nthr) {
-                hipLaunchKernelGGL(vg::vg_backsub_kernel, dim3((unsigned)((nthr + 63) / 64)), dim3(64), 0, st, ba);
+            if (n_poses || G) {  // G <= kBsThreads: one workgroup is enough for the global columns alone
+                const unsigned int bs_grid = n_bs_groups ? n_bs_groups : 1u;
+                hipLaunchKernelGGL(vg::vg_backsub_kernel, dim3(bs_grid), dim3(vg::kBsThreads), 0, st, ba);
                 VG_HIP(hipGetLastError());
             }
             if (n_bs_groups) {  // fixed-order sum of the per-workgroup partials
