@@ -387,8 +387,20 @@ __global__ __launch_bounds__(256) void vg_gram_final_sum_kernel(const double *__
     const int lane = threadIdx.x & (kWave - 1);
     const int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // one wave per entry
     if (e >= entries) return;
-    double s = 0.;
-    for (unsigned int i = lane; i < n_items; i += kWave) s += in[(size_t)i * entries + e];
+    // four independent partial sums per lane (item i goes to accumulator (i / 64) % 4): the loads of a group of four
+    // are in flight together -- with thousands of partials a single dependent chain made this kernel latency bound
+    double s0 = 0., s1 = 0., s2 = 0., s3 = 0.;
+    unsigned int i = lane;
+    for (; i + 3 * kWave < n_items; i += 4 * kWave) {
+        const double v0 = in[(size_t)i * entries + e], v1 = in[(size_t)(i + kWave) * entries + e];
+        const double v2 = in[(size_t)(i + 2 * kWave) * entries + e], v3 = in[(size_t)(i + 3 * kWave) * entries + e];
+        s0 += v0;
+        s1 += v1;
+        s2 += v2;
+        s3 += v3;
+    }
+    for (; i < n_items; i += kWave) s0 += in[(size_t)i * entries + e];
+    double s = (s0 + s1) + (s2 + s3);
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, kWave);  // fixed butterfly order
     if (lane == 0) out[e] = s;

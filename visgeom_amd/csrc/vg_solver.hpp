@@ -238,12 +238,40 @@ __global__ __launch_bounds__(kBsThreads) void vg_backsub_kernel(BacksubArgs b)
     for (int q = 0; q < kBsPosesPerGroup; q++) {
         const int i = blockIdx.x * kBsPosesPerBlock + q * (kBsThreads / kBsGroup) + grp;
         const bool pv = i < a.n_poses;  // uniform inside the 16-lane group
-        const double *rows = a.rows + (size_t)(pv ? i : 0) * 6 * C;
-        double y[6];
+        const int ii = pv ? i : 0;
+        const double *rows = a.rows + (size_t)ii * 6 * C;
+        // everything the group's first lane needs later is loaded by all 16 lanes up front (same addresses: one
+        // transaction per group), so the loads overlap the dot products instead of forming a second and third
+        // round trip behind the branch
+        const double *rec = a.rec + (size_t)ii * kPoseRec;
+        const long long pp = b.pose_param[ii];
+        double L[21], gk[6], dk[6], xk[6], y[6], yl[6];
+#pragma unroll
+        for (int k = 0; k < 21; k++) L[k] = rec[k];
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            gk[k] = rec[21 + k];
+            dk[k] = rec[27 + k];
+            xk[k] = b.x[pp + k];
+            yl[k] = rows[k * C + a.G];
+        }
+        const bool active = rec[33] != 0.;
+        // G <= 63: at most four columns per lane and row; all 24 loads are issued before the first use (a loop over
+        // a run-time G waits for every load in turn)
+        constexpr int kJ = 4;
+        double dgv[kJ], rv[6][kJ];
+#pragma unroll
+        for (int j = 0; j < kJ; j++) {
+            const int g = gl + kBsGroup * j;
+            dgv[j] = g < a.G ? b.dg[g] : 0.;
+#pragma unroll
+            for (int k = 0; k < 6; k++) rv[k][j] = g < a.G ? rows[k * C + g] : 0.;
+        }
 #pragma unroll
         for (int k = 0; k < 6; k++) {
             double s = 0.;
-            for (int g = gl; g < a.G; g += kBsGroup) s += rows[k * C + g] * b.dg[g];
+#pragma unroll
+            for (int j = 0; j < kJ; j++) s += rv[k][j] * dgv[j];
             y[k] = s;
         }
 #pragma unroll
@@ -251,27 +279,22 @@ __global__ __launch_bounds__(kBsThreads) void vg_backsub_kernel(BacksubArgs b)
 #pragma unroll
             for (int off = kBsGroup / 2; off >= 1; off >>= 1) y[k] += __shfl_xor(y[k], off, kWave);
         if (gl == 0 && pv) {
-            const double *rec = a.rec + (size_t)i * kPoseRec;
-            double L[21], x[6];
+            double x[6];
 #pragma unroll
-            for (int k = 0; k < 21; k++) L[k] = rec[k];
-            const bool active = rec[33] != 0.;
-#pragma unroll
-            for (int k = 0; k < 6; k++) y[k] += rows[k * C + a.G];
+            for (int k = 0; k < 6; k++) y[k] += yl[k];
             bwd6(L, y, x);
-            double *dp = b.delta + b.pose_param[i];
-            const double *xp = b.x + b.pose_param[i];
+            double *dp = b.delta + pp;
 #pragma unroll
             for (int c = 0; c < 6; c++) {
                 const double v = active ? -x[c] : 0.;
                 dp[c] = v;
-                const double g = rec[21 + c];
+                const double g = gk[c];
                 s0 += g * v;
-                s1 += clampd(rec[27 + c], a.dmin, a.dmax) * v * v;
+                s1 += clampd(dk[c], a.dmin, a.dmax) * v * v;
                 if (active) s2 = fmax(s2, fabs(g));
                 if (active) s4 += g * g;
                 s3 += v * v;
-                s5 += xp[c] * xp[c];
+                s5 += xk[c] * xk[c];
             }
         }
     }
