@@ -458,3 +458,95 @@ def test_soft_l1_loss_per_residual_block(vg):
     e_rob, e_pl = rel(k_rob, d["gt_intrinsics"]), rel(k_pl, d["gt_intrinsics"])
     print("error vs generating intrinsics: robust %.2e plain %.2e" % (e_rob, e_pl))
     assert e_rob < 0.5 * e_pl
+
+
+def test_active_bound_matches_scipy_bounded_least_squares(vg):
+    """box bounds of the camera models (ucm.h:199-215: xi in [0, 3]) are set on the intrinsic blocks
+    (unified_calibration.cpp:621-627).  Data generated with xi = 3.2: the constrained optimum sits ON the bound;
+    it must equal scipy's bounded trust-region solution over the oracle."""
+    from scipy.optimize import least_squares
+
+    from visgeom_amd import synthetic as S
+
+    n, N = 30, 96
+    gt = S.GT_UCM.copy()
+    gt[0] = 3.2
+    gt[1:3] *= (1 + 3.2) / (1 + S.GT_UCM[0])      # keep the image scale: f / (1 + xi) unchanged
+    d = S.make_mono("ucm", n, 2, sigma=0.1, gt=gt)
+    x0 = np.concatenate([d["init_intrinsics"], d["init_poses"].ravel()])
+
+    def parts(x, want):
+        return vgo.eval_dataset(vgo.MODEL_UCM, [0], d["board"], d["corners"], x, 0, [5], [6], np.arange(n), want_jac=want)
+
+    def fun(x):
+        return parts(x, False)[0].ravel()
+
+    def jac(x):
+        _, ji, jm = parts(x, True)
+        J = np.zeros((2 * N * n, x.size))
+        for b in range(n):
+            rows = slice(b * 2 * N, (b + 1) * 2 * N)
+            J[rows, 0:5] = ji[b]
+            J[rows, 5 + 6 * b:11 + 6 * b] = jm[0][b]
+        return J
+
+    lo = np.full(x0.size, -np.inf)
+    hi = np.full(x0.size, np.inf)
+    lo[:5] = [0, 1, 1, 1, 1]
+    hi[:5] = [3, 1e5, 1e5, 1e5, 1e5]
+    ref = least_squares(fun, x0, jac=jac, bounds=(lo, hi), method="trf", x_scale="jac", xtol=1e-15, ftol=1e-15, gtol=1e-15, max_nfev=500)
+    p, cam, seq, ds = mono_problem(vg, d, "ucm")
+    s = p.solve(max_num_iterations=300)      # use_bounds = 1 is the default
+    x = p.get_parameters()
+    print("bounded", s["termination"], s["num_iterations"], "cost gpu %.10e scipy %.10e xi %.6f" % (s["final_cost"], ref.cost, x[0]))
+    assert x[0] == 3.0                                           # exactly on the bound, never beyond
+    assert abs(ref.x[0] - 3.0) < 1e-6
+    assert abs(s["final_cost"] - ref.cost) <= 1e-7 * ref.cost
+    assert rel(x[1:5], ref.x[1:5]) < 1e-5
+    # without bounds the same data go past xi = 3
+    p2, _, _, _ = mono_problem(vg, d, "ucm")
+    p2.solve(max_num_iterations=300, use_bounds=0)
+    assert p2.get_parameters()[0] > 3.05
+    p.close()
+    p2.close()
+
+
+def test_degenerate_structures(vg):
+    """nothing free; a dataset without images next to a populated one; one image only"""
+    from visgeom_amd import synthetic as S
+
+    d = S.make_mono("eucm", 12, 2, sigma=0.1)
+    # (1) every block constant: the solve is a cost evaluation
+    p = vg.CalibrationProblem(0)
+    cam = p.add_camera("eucm", d["init_intrinsics"], constant=True)
+    seq = p.add_transform(False, d["init_poses"], constant=True)
+    p.add_dataset(cam, [(seq, 0)], d["board"], d["corners"])
+    p.finalize()
+    x0 = p.get_parameters()
+    s = p.solve(max_num_iterations=20)
+    r, _, _ = vgo.eval_dataset(0, [0], d["board"], d["corners"], x0, 0, [6], [6], np.arange(12), want_jac=False)
+    assert np.array_equal(p.get_parameters(), x0)
+    assert abs(s["final_cost"] - 0.5 * np.sum(r * r)) <= 1e-12 * s["final_cost"] and s["initial_cost"] == s["final_cost"]
+    p.close()
+    # (2) an empty dataset (all of its frames had no pattern) next to a populated one
+    p = vg.CalibrationProblem(0)
+    cam = p.add_camera("eucm", d["init_intrinsics"])
+    seq = p.add_transform(False, d["init_poses"])
+    seq2 = p.add_transform(False, d["init_poses"][:3])
+    p.add_dataset(cam, [(seq, 0)], d["board"], d["corners"])
+    p.add_dataset(cam, [(seq2, 0)], d["board"], np.zeros((0, 96, 2)), image_index=np.zeros(0, dtype=np.int32))
+    p.finalize()
+    s = p.solve(max_num_iterations=100)
+    x = p.get_parameters()
+    assert rel(x[:6], d["gt_intrinsics"]) < 2e-2 and s["final_cost"] < 1e-3 * s["initial_cost"]
+    assert np.array_equal(x[6 + 72:], d["init_poses"][:3].ravel())      # unreferenced poses do not move
+    p.close()
+    # (3) a single image: 6 + 6 unknowns against 192 residuals
+    p = vg.CalibrationProblem(0)
+    cam = p.add_camera("eucm", d["gt_intrinsics"], constant=True)
+    seq = p.add_transform(False, d["init_poses"][:1])
+    p.add_dataset(cam, [(seq, 0)], d["board"], d["corners"][:1])
+    p.finalize()
+    s = p.solve(max_num_iterations=100)
+    assert np.max(np.abs(p.get_parameters()[6:] - d["gt_poses"][0])) < 2e-3
+    p.close()

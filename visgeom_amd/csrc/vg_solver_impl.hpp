@@ -641,6 +641,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
     };
     // values of the global columns at the starting point
     for (int a2 = 0; a2 < G; a2++) VG_HIP(hipMemcpy(&h_xg[a2], p->d_params + gcol_param[a2], sizeof(double), hipMemcpyDeviceToHost));
+    std::vector<double> h_xcur(h_xg);  // global values at the CURRENT point (h_xg is refreshed only after the reduced solve)
 
     DevBuf<double> *cur = gramA, *cand = gramB;
     vg::SolveDatasetDev *ds_cur = d_dsA.p, *ds_cand = d_dsB.p;
@@ -734,13 +735,35 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             S[(size_t)a2 * G + a2] += mu * (dd < opt.min_lm_diagonal ? opt.min_lm_diagonal : (dd > opt.max_lm_diagonal ? opt.max_lm_diagonal : dd));
             rhs[a2] = -gg[a2] + h_rgram[(size_t)a2 * C + G];
         }
-        for (int a2 = 0; a2 < G; a2++)
-            if (gfrozen[a2]) {
-                for (int b2 = 0; b2 < G; b2++) S[(size_t)a2 * G + b2] = S[(size_t)b2 * G + a2] = 0.;
-                S[(size_t)a2 * G + a2] = 1.;
-                rhs[a2] = 0.;
-            }
-        bool step_ok = coupled_ok && (G == 0 || chol_solve(G, S.data(), rhs.data(), dg.data()));
+        // Constant blocks, and the active set of the box bounds: a parameter sitting ON a bound whose step points
+        // outwards is held for this iteration (its row / column leave the reduced system -- the Schur complement of
+        // the constrained problem is exactly that sub-matrix).  Without this the projected step keeps "spending" its
+        // decrease on a coordinate that cannot move, the gain ratio collapses and the radius shrinks to nothing.
+        std::vector<unsigned char> held(gfrozen.begin(), gfrozen.end());
+        std::vector<double> Sw, rw;
+        bool step_ok = coupled_ok;
+        for (int pass = 0; step_ok && pass <= G; pass++) {
+            Sw = S;
+            rw = rhs;
+            for (int a2 = 0; a2 < G; a2++)
+                if (held[a2]) {
+                    for (int b2 = 0; b2 < G; b2++) Sw[(size_t)a2 * G + b2] = Sw[(size_t)b2 * G + a2] = 0.;
+                    Sw[(size_t)a2 * G + a2] = 1.;
+                    rw[a2] = 0.;
+                }
+            step_ok = G == 0 || chol_solve(G, Sw.data(), rw.data(), dg.data());
+            bool changed = false;
+            if (step_ok && opt.use_bounds)
+                for (int a2 = 0; a2 < G; a2++) {
+                    if (held[a2]) continue;
+                    const double l2 = lo[(size_t)gcol_param[a2]], h2 = hi[(size_t)gcol_param[a2]];
+                    if ((h_xcur[a2] <= l2 && dg[a2] < 0.) || (h_xcur[a2] >= h2 && dg[a2] > 0.)) {
+                        held[a2] = 1;
+                        changed = true;
+                    }
+                }
+            if (!changed) break;
+        }
         t_host += now_s() - t0;
 
         double model_change = 0., step2 = 0., cost_change = 0., rho = 0.;
@@ -886,6 +909,10 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             std::swap(ds_cur, ds_cand);
             std::swap(d_x.p, d_xc.p);
             for (auto &c2 : coupled) c2.x.swap(c2.xc);
+            for (int a2 = 0; a2 < G; a2++) {  // what vg_apply_step_kernel wrote: clamp(x + dg)
+                const double v = h_xg[a2] + dg[a2], l2 = lo[(size_t)gcol_param[a2]], h2 = hi[(size_t)gcol_param[a2]];
+                h_xcur[a2] = v < l2 ? l2 : (v > h2 ? h2 : v);
+            }
             U.swap(Uc);
             gg.swap(ggc);
             const double prev = cost2;
