@@ -208,3 +208,42 @@ def test_images_dataset_skips_frames_missing_in_the_initialising_dataset(gpu, tm
     assert np.array_equal(c.transform("xiCamBoardStereo")[miss], [0, 0, 1, 0, 0, 0])
     assert np.max(np.abs(c.transform("xiCam12").ravel() - st["gt_xi12"])) < 1e-6
     c.close()
+
+
+def test_two_files_into_one_problem(gpu, tmp_path):
+    """generic_calibration.cpp:36-39 feeds every file on the command line to the same calibration object: the second
+    file declares only its own sequence and re-uses the camera of the first one (the maps are shared)."""
+    import json
+
+    from visgeom_amd import _build, synthetic as S
+    from visgeom_amd.calibration import GenericCameraCalibration
+
+    d1 = S.make_mono("eucm", 15, 0, sigma=0.0)
+    d2 = S.make_mono("eucm", 10, 8, sigma=0.0)
+    p1 = S.write_calibration_json(str(tmp_path), d1, "eucm", name="first", sequence="xiA", prior=False, init=True)
+    p2 = S.write_calibration_json(str(tmp_path), d2, "eucm", name="second", sequence="xiB", prior=False, init=True)
+    r = json.load(open(p2))
+    r["cameras"] = []                       # "cam" comes from the first file
+    json.dump(r, open(p2, "w"))
+    c = GenericCameraCalibration()
+    c.addResiduals(p1)
+    c.addResiduals(p2)
+    assert c.num_datasets() == 2
+    c.compute(max_num_iterations=200)
+    assert c.summary["num_pose_blocks"] == 25 and c.summary["num_global_columns"] == 6
+    assert rel(c.intrinsics("cam"), d1["gt_intrinsics"]) < 1e-6
+    assert np.max(np.abs(c.transform("xiA") - d1["gt_poses"])) < 1e-6
+    assert np.max(np.abs(c.transform("xiB") - d2["gt_poses"])) < 1e-6
+    c.close()
+    out = subprocess.run([_build.CLI, p1, p2], capture_output=True, text=True, cwd=str(tmp_path), timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert "Sequence : xiA" in out.stdout and "Sequence : xiB" in out.stdout
+    assert os.path.exists(tmp_path / "image_error_0.txt") and os.path.exists(tmp_path / "image_error_1.txt")
+    # a data entry that names an undeclared camera is a parse-time error, as in the reference
+    r["data"][0]["camera"] = "other"
+    json.dump(r, open(p2, "w"))
+    c = GenericCameraCalibration()
+    c.addResiduals(p1)
+    with pytest.raises(Exception):
+        c.addResiduals(p2)
+    c.close()
