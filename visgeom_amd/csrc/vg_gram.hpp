@@ -100,7 +100,7 @@ constexpr int kGramHalf = 32;
 
 __host__ __device__ constexpr int gram_wave_lds_doubles(int W, int frame_stride_d)
 {
-    return kGramRowsPerTile * W + 2 * frame_stride_d;
+    return kGramRowsPerTile * (W | 1) + 2 * frame_stride_d;  // odd LDS row stride, see the kernel
 }
 
 // CORNER (only with T == 2, W <= 20): the small (W-16) x (W-16) corner of the Gram matrix -- the 1 x 1 r^T r of Mei
@@ -126,7 +126,10 @@ __global__ __launch_bounds__(kGramMaxWavesPerBlock *kWave) void vg_gram_fused_ke
     if (bA >= a.n_blocks) return;  // whole wave leaves; no workgroup barrier below
     const int W = a.W, FS = a.frame_stride_d;
     double *tile = smem + (size_t)wave * gram_wave_lds_doubles(W, FS);
-    double *fr_lds = tile + kGramRowsPerTile * W;
+    // LDS row stride: odd number of doubles.  An even W (UCM: 12, 18, 24) puts the rows of lanes l and l + 16 in the
+    // same banks -- UCM mono ran at 41 us where the wider EUCM block (W = 13) took 35 us.
+    const int WS = W | 1;
+    double *fr_lds = tile + kGramRowsPerTile * WS;
     const int h = lane >> 5, sl = lane & (kGramHalf - 1);
     const unsigned int b = bA + h;
     const bool bvalid = b < a.n_blocks;
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(kGramMaxWavesPerBlock *kWave) void vg_gram_fused_ke
 
         // rows are written unconditionally; lanes without a corner then overwrite theirs with zeros (a branch
         // no lane takes on full boards) -- cheaper than a select per element
-        double *ru = tile + (size_t)(kWave * h + 2 * sl) * W, *rv = ru + W;
+        double *ru = tile + (size_t)(kWave * h + 2 * sl) * WS, *rv = ru + WS;
 #pragma unroll
         for (int i = 0; i < K; i++) {
             ru[i] = e.Ju[i];
@@ -217,15 +220,15 @@ __global__ __launch_bounds__(kGramMaxWavesPerBlock *kWave) void vg_gram_fused_ke
         // always 16 groups of 4 rows per image: rows of lanes without a corner are zero, so a ragged last
         // step only wastes matrix-pipe time, and the fixed trip count lets the LDS reads be pipelined
         constexpr int n_steps = kGramHalf / 2;
-        const double *rowA = tile + (size_t)k4 * W, *rowB = rowA + (size_t)kWave * W;
+        const double *rowA = tile + (size_t)k4 * WS, *rowB = rowA + (size_t)kWave * WS;
 #pragma unroll 4
         for (int t = 0; t < n_steps; t++) {
             double vA[T], vB[T];
 #pragma unroll
             for (int j = 0; j < T; j++) {
                 const int col = 16 * j + c16;
-                vA[j] = col < W ? rowA[(size_t)(4 * t) * W + col] : 0.;
-                vB[j] = col < W ? rowB[(size_t)(4 * t) * W + col] : 0.;
+                vA[j] = col < W ? rowA[(size_t)(4 * t) * WS + col] : 0.;
+                vB[j] = col < W ? rowB[(size_t)(4 * t) * WS + col] : 0.;
             }
 #pragma unroll
             for (int ti = 0; ti < T; ti++)
