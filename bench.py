@@ -305,9 +305,11 @@ def main():
 
     W = p.gram_width(ds)
     jtj = {"unit": "ms/iter", "gram_width": W, "images_per_gpu": n_img, "allreduce": dist is not None,
-           "fused_ms_per_iter": wall_ms(it_fused, a.steps),
-           "two_pass_ms_per_iter": wall_ms(it_two_pass, a.steps),
-           "second_pass_only_ms": wall_ms(it_second_pass_only, a.steps),
+           # secondary legs: best of three timed runs (a single run picked up a host hiccup once: 0.12 vs 0.05 ms);
+           # the headline `value` above stays ONE timed run of exactly K steps, as the contract says
+           "fused_ms_per_iter": min(wall_ms(it_fused, a.steps) for _ in range(3)),
+           "two_pass_ms_per_iter": min(wall_ms(it_two_pass, a.steps) for _ in range(3)),
+           "second_pass_only_ms": min(wall_ms(it_second_pass_only, a.steps) for _ in range(3)),
            "fused_algorithmic_bytes_per_obs": 16 + 8.0 * W * W / N,
            "two_pass_read_bytes_per_obs": 16 + 16 * (K + 6)}
 
