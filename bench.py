@@ -32,8 +32,8 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--images", type=int, default=10000, help="images per GPU")
     ap.add_argument("--model", default="eucm", choices=["eucm", "ucm", "mei"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -156,14 +156,19 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    import gc
+
     for _ in range(a.warmup):
         step()
+    gc.collect()
+    gc.disable()   # no collector pause between two launches of the timed loop
     fence()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         all_reduce_(t, op=dist.ReduceOp.MAX)
