@@ -158,10 +158,18 @@ def main():
 
     import gc
 
-    for _ in range(a.warmup):
-        step()
     gc.collect()
     gc.disable()   # no collector pause between two launches of the timed loop
+    # bring the device to its steady clocks before the contract's W warm-up steps: the first ~300 evaluations after an
+    # idle period of a few milliseconds run up to 5 % slower (tools/exp/step_overhead_probe.py), whatever W and K the
+    # caller picked; nothing but the fence may sit between this and the timed loop
+    t_spin = time.perf_counter()
+    while time.perf_counter() - t_spin < 0.1:
+        for _ in range(50):
+            step()
+        torch.cuda.synchronize()
+    for _ in range(a.warmup):
+        step()
     fence()
     t0 = time.perf_counter()
     for _ in range(a.steps):

@@ -18,3 +18,14 @@ for K in (20, 50, 200, 1000, 5000):
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     print("K %5d  enqueue %.1f us/step   total %.2f us/step" % (K, (t1 - t0) / K * 1e6, (t2 - t0) / K * 1e6))
+
+# GPU-side time of consecutive windows of one long run (events every 50 steps)
+torch.cuda.synchronize()
+time.sleep(0.5)
+evs = [torch.cuda.Event(enable_timing=True) for _ in range(41)]
+evs[0].record()
+for w in range(40):
+    for _ in range(50): step()
+    evs[w + 1].record()
+torch.cuda.synchronize()
+print("us/step per 50-step window:", " ".join("%.1f" % (evs[i].elapsed_time(evs[i + 1]) / 50 * 1e3) for i in range(40)))
