@@ -208,7 +208,7 @@ __global__ __launch_bounds__(kGramMaxWavesPerBlock *kWave) void vg_gram_fused_ke
 #pragma unroll
                 for (int c = r; c < kCornerMax; c++, q++) cacc[q] += cu[r] * cu[c] + cv[r] * cv[c];
         }
-        if (RCOL) {
+        if constexpr (RCOL) {
             // this lane's own two rows (just written, zeroed when the lane has no corner): column 16 against all 17
             const double su = ru[16], sv = rv[16];
 #pragma unroll
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(kGramMaxWavesPerBlock *kWave) void vg_gram_fused_ke
     }
     store_gram<T, CORNER>(accA, a.gram + (size_t)bA * W * W, W, lane);
     if (bA + 1 < a.n_blocks) store_gram<T, CORNER>(accB, a.gram + (size_t)(bA + 1) * W * W, W, lane);
-    if (RCOL) {
+    if constexpr (RCOL) {
         // sum over the 32 lanes of each image (fixed butterfly inside the half-wave), lane 0 of the half stores
 #pragma unroll
         for (int q = 0; q < 17; q++)
