@@ -550,3 +550,41 @@ def test_degenerate_structures(vg):
     s = p.solve(max_num_iterations=100)
     assert np.max(np.abs(p.get_parameters()[6:] - d["gt_poses"][0])) < 2e-3
     p.close()
+
+
+def test_no_device_memory_leak_over_repeated_problems(vg):
+    """create -> evaluate -> Gram -> solve -> close, many times: the library's own hipMalloc'ed workspaces (frames,
+    partials, solver buffers, pinned host memory) must all be returned; device-wide free memory stays put."""
+    import torch
+
+    from visgeom_amd import synthetic as S
+
+    d = S.make_mono("eucm", 300, 2, sigma=0.1)
+
+    def once():
+        p, cam, seq, ds = mono_problem(vg, d, "eucm")
+        res, ji, jm = p.alloc_outputs(ds)
+        gram, gsum = p.alloc_gram(ds)
+        p.prepare()
+        p.evaluate_dataset(ds, res, ji, jm)
+        p.gram_fused(ds, gram)
+        p.gram_sum(ds, gram, gsum)
+        hres = np.empty((300, 192))
+        hji = np.empty((300, 192, 6))
+        hjm = [np.empty((300, 192, 6))]
+        p.evaluate_dataset_to_host(ds, hres, hji, hjm)
+        p.solve(max_num_iterations=5)
+        p.close()
+        del res, ji, jm, gram, gsum
+
+    for _ in range(3):
+        once()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(40):
+        once()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 8 << 20, "leaked %.1f MiB over 40 problems" % ((free0 - free1) / 2**20)
