@@ -198,3 +198,39 @@ def test_odometry_parse_errors_mirror_the_reference(tmp_path, what, msg):
         c.addResiduals(path)
     assert msg in str(e.value)
     c.close()
+
+
+def test_json_parser_survives_mutated_input(tmp_path):
+    """truncations, random byte flips and structural edits of a valid calibration file must come back as an error
+    code (or parse), never crash the host library"""
+    d, path = _write(tmp_path, prior=True)
+    text = open(path).read()
+    rng = np.random.default_rng(7)
+    variants = [text[:k] for k in rng.integers(0, len(text), 60)]
+    for _ in range(120):
+        b = bytearray(text.encode())
+        for _ in range(int(rng.integers(1, 6))):
+            pos = int(rng.integers(0, len(b)))
+            op = int(rng.integers(0, 3))
+            if op == 0:
+                b[pos] = int(rng.integers(32, 127))
+            elif op == 1:
+                del b[pos]
+            else:
+                b.insert(pos, int(rng.choice(list(b'{}[]",:0-9eE.tfn \n'))))
+        variants.append(b.decode(errors="replace"))
+    variants += ["", "[]", "{}", "nul", '{"a":', '{"transformations": 3, "cameras": [], "data": []}', "[" * 5000, '{"a":' * 2000,
+                 '{"transformations": [], "cameras": [], "data": [{"type": "ir_data"}]}', "1e999", '"\\u12"', '{"x": "\\q"}']
+    ok = bad = 0
+    for i, v in enumerate(variants):
+        f = tmp_path / ("mut_%d.json" % i)
+        f.write_text(v)
+        c = GenericCameraCalibration()
+        try:
+            c.addResiduals(str(f))
+            ok += 1
+        except capi.VisgeomError:
+            bad += 1
+        finally:
+            c.close()
+    assert ok + bad == len(variants) and bad > len(variants) // 2
