@@ -95,8 +95,17 @@ private:
     {
         while (i < s.size() && std::isspace((unsigned char)s[i])) i++;
     }
+    // recursion guard: a calibration file nests 6 levels deep; a hostile "[[[[..." must not exhaust the stack
+    struct Depth {
+        int &d;
+        explicit Depth(int &depth) : d(depth) { d++; }
+        ~Depth() { d--; }
+    };
+    int depth = 0;
     Value value()
     {
+        Depth guard(depth);
+        if (depth > 256) fail("nesting too deep");
         ws();
         if (i >= s.size()) fail("unexpected end");
         const char c = s[i];
