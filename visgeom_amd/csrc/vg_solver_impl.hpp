@@ -818,8 +818,11 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
                 VG_HIP(hipMemcpyAsync(ps + 5, d_gmax.p, sizeof(double), hipMemcpyDeviceToHost, st));
             }
             if (G) VG_HIP(hipMemcpyAsync(ps + 6, d_xg.p, sizeof(double) * G, hipMemcpyDeviceToHost, st));
-            VG_HIP(hipStreamSynchronize(st));
             t_schur += now_s() - t0;
+            // No wait here: the candidate evaluation does not depend on these scalars, it is queued right behind the
+            // step on the same stream, and its own read-back synchronises once for both (one host round trip per
+            // iteration less; the wait is booked under "evaluate").
+            VG_TRY(evaluate(d_xc.p, cand, Uc, ggc, cost2_c));
 
             // |x|^2 of this rank's pose parameters (summed over ranks below) and of the replicated global block
             for (int a2 = 0; a2 < G; a2++) h_xg[a2] = ps[6 + a2];
@@ -827,7 +830,6 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             for (int a2 = 0; a2 < G; a2++) xg2 += h_xg[a2] * h_xg[a2];
             double gdp = ps[0] + host_scal[0], ddp = ps[1] + host_scal[1], dp2 = ps[2] + host_scal[2],
                    gp2 = ps[3] + host_scal[3], xp2 = ps[4], gmax_p = ps[5] > host_scal[4] ? ps[5] : host_scal[4];
-            VG_TRY(evaluate(d_xc.p, cand, Uc, ggc, cost2_c));
             for (auto &c2 : coupled) {
                 VG_HIP(hipMemcpy(c2.xc.data(), d_xc.p + c2.param_off, sizeof(double) * c2.xc.size(), hipMemcpyDeviceToHost));
                 cost2_c += c2.cost2(c2.xc);
