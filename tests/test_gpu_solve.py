@@ -588,3 +588,41 @@ def test_no_device_memory_leak_over_repeated_problems(vg):
     torch.cuda.empty_cache()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < 8 << 20, "leaked %.1f MiB over 40 problems" % ((free0 - free1) / 2**20)
+
+
+def test_argument_errors_of_the_block_level_entries(vg):
+    """error behaviour of the prior / odometry / constant-pose entries: codes, not crashes; state errors after finalize"""
+    from visgeom_amd import capi, synthetic as S
+
+    d = S.make_mono("eucm", 4, 2)
+    p = vg.CalibrationProblem(0)
+    cam = p.add_camera("eucm", d["init_intrinsics"])
+    glob = p.add_transform(True, [0.1, 0, 0, 0, 0, 0])
+    seq = p.add_transform(False, d["init_poses"])
+    xi = d["init_poses"]
+    bad = [lambda: p.add_odometry_prior(glob, 0, 0.1, 0.1, 0.1, xi[0], xi[1]),       # not a sequence
+           lambda: p.add_odometry_prior(seq, 3, 0.1, 0.1, 0.1, xi[0], xi[1]),        # couples 3 and 4: out of range
+           lambda: p.add_odometry_prior(seq, -1, 0.1, 0.1, 0.1, xi[0], xi[1]),
+           lambda: p.add_odometry_prior(seq, 0, 0.1, 0.1, 0.0, xi[0], xi[1]),        # lambda must be positive
+           lambda: p.add_odometry_prior(99, 0, 0.1, 0.1, 0.1, xi[0], xi[1]),
+           lambda: p.set_pose_constant(glob, 0),
+           lambda: p.set_pose_constant(seq, 4),
+           lambda: p.add_transformation_prior(42, np.ones(6))]
+    for f in bad:
+        with pytest.raises(capi.VisgeomError):
+            f()
+    with pytest.raises(ValueError):
+        p.add_transformation_prior(glob, np.ones(5))
+    p.add_dataset(cam, [(glob, 1), (seq, 0)], d["board"], d["corners"])
+    p.add_odometry_prior(seq, 0, 0.1, 0.1, 0.1, xi[0], xi[1])
+    p.finalize()
+    for f in (lambda: p.add_odometry_prior(seq, 1, 0.1, 0.1, 0.1, xi[1], xi[2]), lambda: p.set_pose_constant(seq, 0),
+              lambda: p.add_transformation_prior(glob, np.ones(6))):
+        with pytest.raises(capi.VisgeomError) as e:
+            f()
+        assert "finalized" in str(e.value)
+    # odometry blocks + a multi-rank all-reduce callback: refused (the coupled chain cannot be cut without an exchange)
+    with pytest.raises(capi.VisgeomError) as e:
+        p.solve(allreduce=lambda buf: None, max_num_iterations=2)
+    assert "all-reduce" in str(e.value)
+    p.close()
