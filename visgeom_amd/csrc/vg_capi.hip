@@ -714,16 +714,23 @@ int vg_block_create(vg_block **out, int device, int model, int chain_len, const 
     if (rc == VG_OK) rc = vg_problem_finalize(b->p);
     if (rc == VG_OK) {
         const size_t rows = 2 * (size_t)n_points;
-        hipError_t e = hipMalloc(&b->d_res, sizeof(double) * rows);
-        if (e == hipSuccess) e = hipMalloc(&b->d_jintr, sizeof(double) * rows * K);
-        for (int l = 0; l < chain_len && e == hipSuccess; l++) e = hipMalloc(&b->d_jm[l], sizeof(double) * rows * 6);
+        const size_t total = rows * (1 + (size_t)K + 6 * (size_t)chain_len);
+        hipError_t e = hipMalloc(&b->d_out, sizeof(double) * total);
+        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&b->h_out), sizeof(double) * total, hipHostMallocDefault);
+        if (e == hipSuccess)
+            e = hipHostMalloc(reinterpret_cast<void **>(&b->h_params), sizeof(double) * ((size_t)K + 6 * (size_t)chain_len),
+                              hipHostMallocDefault);
         if (e != hipSuccess) rc = fail(VG_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+        else {
+            b->d_res = b->d_out;
+            b->d_jintr = b->d_out + rows;
+            for (int l = 0; l < chain_len; l++) b->d_jm[l] = b->d_out + rows * (1 + (size_t)K + 6 * (size_t)l);
+        }
     }
     if (rc != VG_OK) {
         vg_block_destroy(b);
         return rc;
     }
-    b->h_params.assign((size_t)K + 6 * (size_t)chain_len, 0.);
     *out = b;
     return VG_OK;
 }
@@ -742,28 +749,37 @@ int vg_block_evaluate(vg_block *b, double const *const *parameters, double *resi
     for (int i = 0; i <= b->L; i++)
         if (!parameters[i]) return fail(VG_ERR_INVALID_ARGUMENT, "NULL parameter block");
     // parameter vector layout of the one-image problem: [intrinsics | member 0 | member 1 ...]
-    std::memcpy(b->h_params.data(), parameters[0], sizeof(double) * b->K);
-    for (int l = 0; l < b->L; l++) std::memcpy(b->h_params.data() + b->K + 6 * l, parameters[1 + l], sizeof(double) * 6);
-    int rc = vg_problem_set_parameters(b->p, b->h_params.data());
-    if (rc != VG_OK) return rc;
-    rc = vg_problem_prepare(b->p);
+    std::memcpy(b->h_params, parameters[0], sizeof(double) * b->K);
+    for (int l = 0; l < b->L; l++) std::memcpy(b->h_params + b->K + 6 * l, parameters[1 + l], sizeof(double) * 6);
+    vg_problem *p = b->p;
+    VG_HIP(hipSetDevice(p->device));
+    hipStream_t s = p->stream;
+    VG_HIP(hipMemcpyAsync(p->d_params, b->h_params, sizeof(double) * (size_t)p->n_params, hipMemcpyHostToDevice, s));
+    int rc = vgi::prepare_at(p, p->d_params);
     if (rc != VG_OK) return rc;
     double *jm[vg::kMaxChain] = {nullptr};
     double *ji = nullptr;
-    if (jacobians) {
-        if (jacobians[0]) ji = b->d_jintr;
-        for (int l = 0; l < b->L; l++)
-            if (jacobians[1 + l]) jm[l] = b->d_jm[l];
-    }
-    rc = vg_dataset_evaluate(b->p, 0, b->d_res, ji, jm);
-    if (rc != VG_OK) return rc;
+    size_t last = 2 * (size_t)b->N;  // doubles to bring back: up to the end of the last requested block
     const size_t rows = 2 * (size_t)b->N;
-    hipStream_t s = b->p->stream;
-    VG_HIP(hipMemcpyAsync(residuals, b->d_res, sizeof(double) * rows, hipMemcpyDeviceToHost, s));
-    if (ji) VG_HIP(hipMemcpyAsync(jacobians[0], ji, sizeof(double) * rows * b->K, hipMemcpyDeviceToHost, s));
-    for (int l = 0; l < b->L; l++)
-        if (jm[l]) VG_HIP(hipMemcpyAsync(jacobians[1 + l], jm[l], sizeof(double) * rows * 6, hipMemcpyDeviceToHost, s));
+    if (jacobians) {
+        if (jacobians[0]) {
+            ji = b->d_jintr;
+            last = rows * (1 + (size_t)b->K);
+        }
+        for (int l = 0; l < b->L; l++)
+            if (jacobians[1 + l]) {
+                jm[l] = b->d_jm[l];
+                last = rows * (1 + (size_t)b->K + 6 * (size_t)(l + 1));
+            }
+    }
+    rc = vg_dataset_evaluate(p, 0, b->d_res, ji, jm);
+    if (rc != VG_OK) return rc;
+    VG_HIP(hipMemcpyAsync(b->h_out, b->d_out, sizeof(double) * last, hipMemcpyDeviceToHost, s));
     VG_HIP(hipStreamSynchronize(s));
+    std::memcpy(residuals, b->h_out, sizeof(double) * rows);
+    if (ji) std::memcpy(jacobians[0], b->h_out + rows, sizeof(double) * rows * b->K);
+    for (int l = 0; l < b->L; l++)
+        if (jm[l]) std::memcpy(jacobians[1 + l], b->h_out + rows * (1 + (size_t)b->K + 6 * (size_t)l), sizeof(double) * rows * 6);
     return VG_OK;
 }
 
@@ -771,10 +787,9 @@ void vg_block_destroy(vg_block *b)
 {
     if (!b) return;
     if (b->p) (void)hipSetDevice(b->p->device);
-    if (b->d_res) (void)hipFree(b->d_res);
-    if (b->d_jintr) (void)hipFree(b->d_jintr);
-    for (int l = 0; l < vg::kMaxChain; l++)
-        if (b->d_jm[l]) (void)hipFree(b->d_jm[l]);
+    if (b->d_out) (void)hipFree(b->d_out);
+    if (b->h_out) (void)hipHostFree(b->h_out);
+    if (b->h_params) (void)hipHostFree(b->h_params);
     vg_problem_destroy(b->p);
     delete b;
 }

@@ -88,9 +88,12 @@ struct vg_problem {
 struct vg_block {
     vg_problem *p = nullptr;
     int model = 0, K = 0, L = 0, N = 0;
+    // one device allocation [res | jac_intr | jac_member 0 | ...] and one pinned host mirror of it: a call is one
+    // H2D of the parameters, two launches, ONE D2H and one synchronisation
+    double *d_out = nullptr, *h_out = nullptr;
     double *d_res = nullptr, *d_jintr = nullptr;
     double *d_jm[vg::kMaxChain] = {nullptr};
-    std::vector<double> h_params;
+    double *h_params = nullptr;  // pinned, K + 6L doubles
 };
 
 
