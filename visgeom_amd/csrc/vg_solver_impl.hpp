@@ -552,12 +552,16 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
     VG_TRY(d_rgram.alloc((size_t)C * C));
     VG_TRY(d_dg.alloc((size_t)(G ? G : 1)));
     const unsigned int n_bs_groups = (unsigned int)((n_poses + vg::kBsPosesPerBlock - 1) / vg::kBsPosesPerBlock);
-    DevBuf<double> d_scal_sum, d_xg;
-    DevBuf<unsigned long long> d_gmax;
+    // [scalar sums 5 | max |g_pose| (bit pattern) 1 | current global values G]: one allocation, one D2H per iteration
+    DevBuf<double> d_small;
+    struct { double *p; } d_scal_sum{nullptr}, d_xg{nullptr};
+    struct { unsigned long long *p; } d_gmax{nullptr};
     VG_TRY(d_scal.alloc((size_t)n_bs_groups * 5));
-    VG_TRY(d_scal_sum.alloc(5));
-    VG_TRY(d_xg.alloc((size_t)(G ? G : 1)));
-    VG_TRY(d_gmax.alloc(1));
+    VG_TRY(d_small.alloc((size_t)6 + (size_t)(G ? G : 1)));
+    VG_HIP(hipMemsetAsync(d_small.p, 0, sizeof(double) * (6 + (size_t)(G ? G : 1)), st));
+    d_scal_sum.p = d_small.p;
+    d_gmax.p = reinterpret_cast<unsigned long long *>(d_small.p + 5);
+    d_xg.p = d_small.p + 6;
     VG_TRY(d_bad.alloc(1));
     VG_HIP(hipMemsetAsync(d_delta.p, 0, sizeof(double) * (size_t)(n_params ? n_params : 1), st));
     VG_HIP(hipMemcpyAsync(d_x.p, p->d_params, sizeof(double) * (size_t)n_params, hipMemcpyDeviceToDevice, st));
@@ -812,12 +816,8 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
                 VG_HIP(hipGetLastError());
             }
             double *ps = pin_small.p + G;  // [scalars 5 | gmax 1 | xg G]
-            for (int k = 0; k < 6; k++) ps[k] = 0.;
-            if (n_poses) {
-                VG_HIP(hipMemcpyAsync(ps, d_scal_sum.p, sizeof(double) * 5, hipMemcpyDeviceToHost, st));
-                VG_HIP(hipMemcpyAsync(ps + 5, d_gmax.p, sizeof(double), hipMemcpyDeviceToHost, st));
-            }
-            if (G) VG_HIP(hipMemcpyAsync(ps + 6, d_xg.p, sizeof(double) * G, hipMemcpyDeviceToHost, st));
+            // without poses the five sums stay at the zeros they were initialised with (nothing writes them)
+            VG_HIP(hipMemcpyAsync(ps, d_small.p, sizeof(double) * (6 + (size_t)G), hipMemcpyDeviceToHost, st));
             t_schur += now_s() - t0;
             // No wait here: the candidate evaluation does not depend on these scalars, it is queued right behind the
             // step on the same stream, and its own read-back synchronises once for both (one host round trip per
