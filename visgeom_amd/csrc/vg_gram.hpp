@@ -367,10 +367,10 @@ __global__ __launch_bounds__(kGramMaxWavesPerBlock *kWave) void vg_gram_rows_ker
 // ------------------------------------------------------------------------------------------
 constexpr int kSlab = 32;
 
-__global__ __launch_bounds__(256) void vg_gram_slab_sum_kernel(const double *__restrict__ in, unsigned int n_items,
-                                                                int entries, double *__restrict__ out)
+__device__ __forceinline__ void gram_slab_sum_body(const double *__restrict__ in, unsigned int n_items, int entries,
+                                                   double *__restrict__ out, unsigned int slab)
 {
-    const unsigned int i0 = blockIdx.x * kSlab;
+    const unsigned int i0 = slab * kSlab;
     for (int e = threadIdx.x; e < entries; e += blockDim.x) {
         double v[kSlab];
 #pragma unroll
@@ -380,15 +380,21 @@ __global__ __launch_bounds__(256) void vg_gram_slab_sum_kernel(const double *__r
         for (int w = 1; w < kSlab; w *= 2)
 #pragma unroll
             for (int k = 0; k + w < kSlab; k += 2 * w) v[k] += v[k + w];
-        out[(size_t)blockIdx.x * entries + e] = v[0];
+        out[(size_t)slab * entries + e] = v[0];
     }
 }
 
-__global__ __launch_bounds__(256) void vg_gram_final_sum_kernel(const double *__restrict__ in, unsigned int n_items,
-                                                                 int entries, double *__restrict__ out)
+__global__ __launch_bounds__(256) void vg_gram_slab_sum_kernel(const double *__restrict__ in, unsigned int n_items,
+                                                                int entries, double *__restrict__ out)
+{
+    gram_slab_sum_body(in, n_items, entries, out, blockIdx.x);
+}
+
+__device__ __forceinline__ void gram_final_sum_body(const double *__restrict__ in, unsigned int n_items, int entries,
+                                                    double *__restrict__ out, unsigned int block)
 {
     const int lane = threadIdx.x & (kWave - 1);
-    const int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // one wave per entry
+    const int e = block * (blockDim.x >> 6) + (threadIdx.x >> 6);  // one wave per entry
     if (e >= entries) return;
     // four independent partial sums per lane (item i goes to accumulator (i / 64) % 4): the loads of a group of four
     // are in flight together -- with thousands of partials a single dependent chain made this kernel latency bound
@@ -407,6 +413,41 @@ __global__ __launch_bounds__(256) void vg_gram_final_sum_kernel(const double *__
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, kWave);  // fixed butterfly order
     if (lane == 0) out[e] = s;
+}
+
+__global__ __launch_bounds__(256) void vg_gram_final_sum_kernel(const double *__restrict__ in, unsigned int n_items,
+                                                                 int entries, double *__restrict__ out)
+{
+    gram_final_sum_body(in, n_items, entries, out, blockIdx.x);
+}
+
+// The same two stages for SEVERAL datasets in one launch each (a rig has one Gram array per camera; their sums are
+// launch-latency bound, so four datasets cost two launches instead of eight).  Identical arithmetic and order per
+// dataset as the single-dataset kernels.
+struct SumDataset {
+    const double *gram;     // [n_items][entries]
+    double *partials;       // [n_slabs][entries]
+    double *out;            // [entries]
+    unsigned int n_items, n_slabs;
+    int entries;
+    unsigned int first_slab_block;   // first workgroup of this dataset in the slab launch
+    unsigned int first_final_block;  // ... in the final launch (4 entries per workgroup)
+};
+
+__global__ __launch_bounds__(256) void vg_gram_slab_sum_multi_kernel(const SumDataset *__restrict__ ds, int n_ds)
+{
+    int d = 0;
+    while (d + 1 < n_ds && blockIdx.x >= ds[d + 1].first_slab_block) d++;
+    const SumDataset D = ds[d];
+    gram_slab_sum_body(D.gram, D.n_items, D.entries, D.partials, blockIdx.x - D.first_slab_block);
+}
+
+__global__ __launch_bounds__(256) void vg_gram_final_sum_multi_kernel(const SumDataset *__restrict__ ds, int n_ds)
+{
+    int d = 0;
+    while (d + 1 < n_ds && blockIdx.x >= ds[d + 1].first_final_block) d++;
+    const SumDataset D = ds[d];
+    gram_final_sum_body(D.partials, D.n_slabs, D.entries, D.out, blockIdx.x - D.first_final_block);
 }
 
 }  // namespace vg

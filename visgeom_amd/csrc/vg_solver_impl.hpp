@@ -573,6 +573,36 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
     VG_TRY(pin_rgram.alloc(h_rgram.size()));
     VG_TRY(pin_small.alloc((size_t)2 * G + 8));
 
+    // several datasets: their fixed-order sums run as ONE slab launch and ONE final launch (descriptor tables for
+    // the two alternating Gram sets); a single dataset keeps the plain kernels
+    std::vector<DevBuf<double>> sum_partials(n_ds);
+    DevBuf<vg::SumDataset> d_sumA, d_sumB;
+    unsigned int sum_slab_blocks = 0, sum_final_blocks = 0;
+    if (n_ds > 1) {
+        std::vector<vg::SumDataset> ta, tb;
+        for (int d = 0; d < n_ds; d++) {
+            const unsigned int n = (unsigned int)p->dss[d].n_blocks;
+            if (!n) continue;   // its slot of d_sums stays zero (cleared below)
+            vg::SumDataset sd;
+            sd.n_items = n;
+            sd.n_slabs = (n + vg::kSlab - 1) / vg::kSlab;
+            sd.entries = Wd[d] * Wd[d];
+            VG_TRY(sum_partials[d].alloc((size_t)sd.n_slabs * sd.entries));
+            sd.partials = sum_partials[d].p;
+            sd.out = d_sums.p + (size_t)d * Wmax * Wmax;
+            sd.first_slab_block = sum_slab_blocks;
+            sd.first_final_block = sum_final_blocks;
+            sum_slab_blocks += sd.n_slabs;
+            sum_final_blocks += (unsigned int)((sd.entries + 3) / 4);
+            sd.gram = gramA[d].p;
+            ta.push_back(sd);
+            sd.gram = gramB[d].p;
+            tb.push_back(sd);
+        }
+        VG_HIP(hipMemsetAsync(d_sums.p, 0, sizeof(double) * (size_t)n_ds * Wmax * Wmax, st));
+        VG_TRY(d_sumA.upload(ta));
+        VG_TRY(d_sumB.upload(tb));
+    }
     // evaluate the Gram matrices at a device parameter buffer into gram set `set`, assemble U / gg / cost
     auto evaluate = [&](const double *x_dev, DevBuf<double> *set, std::vector<double> &Uo, std::vector<double> &go,
                         double &cost2) -> int {
@@ -589,7 +619,16 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
                                    Wd[d] * Wd[d], opt.soft_l1_scale * opt.soft_l1_scale);
                 VG_HIP(hipGetLastError());
             }
-            if ((r = vgi::gram_sum_into(p, d, set[d].p, d_sums.p + (size_t)d * Wmax * Wmax)) != VG_OK) return r;
+            if (!sum_slab_blocks && (r = vgi::gram_sum_into(p, d, set[d].p, d_sums.p + (size_t)d * Wmax * Wmax)) != VG_OK) return r;
+        }
+        if (sum_slab_blocks) {
+            const vg::SumDataset *tab = set == gramA ? d_sumA.p : d_sumB.p;
+            int n_tab = 0;
+            for (int d = 0; d < n_ds; d++) n_tab += p->dss[d].n_blocks ? 1 : 0;
+            hipLaunchKernelGGL(vg::vg_gram_slab_sum_multi_kernel, dim3(sum_slab_blocks), dim3(256), 0, st, tab, n_tab);
+            VG_HIP(hipGetLastError());
+            hipLaunchKernelGGL(vg::vg_gram_final_sum_multi_kernel, dim3(sum_final_blocks), dim3(256), 0, st, tab, n_tab);
+            VG_HIP(hipGetLastError());
         }
         VG_HIP(hipMemcpyAsync(pin_sums.p, d_sums.p, sizeof(double) * h_sums.size(), hipMemcpyDeviceToHost, st));
         VG_HIP(hipStreamSynchronize(st));
