@@ -251,8 +251,8 @@ typedef struct vg_solve_summary {
 } vg_solve_summary;
 
 void vg_solve_options_init(vg_solve_options *o); /* the defaults listed above */
-/* Limits: at most 63 global columns (sum of the cameras' K + 6 per global transform: e.g. six EUCM cameras and four
- * global transforms); any number of pose blocks below 2^28.  Beyond that VG_ERR_INVALID_ARGUMENT. */
+/* Limits: at most 127 global columns (sum of the cameras' K + 6 per global transform: e.g. eight Mei cameras and
+ * seven global transforms); any number of pose blocks below 2^28.  Beyond that VG_ERR_INVALID_ARGUMENT. */
 int vg_problem_solve(vg_problem *p, const vg_solve_options *options, vg_solve_summary *summary);
 
 /* Host-only helper of the solver, exported so the host logic can be tested without a GPU:

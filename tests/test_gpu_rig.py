@@ -78,3 +78,41 @@ def test_rig_parity_gram_and_solve(vg):
         o = p.transform_offset(x1k[k])
         assert np.max(np.abs(x[o:o + 6] - r["gt_xi1k"][k])) < 1e-6
     p.close()
+
+
+def test_wide_rig_more_than_63_global_columns(vg):
+    """eight Mei cameras on one rig: G = 8 * 10 intrinsics + 7 * 6 global transforms = 122 global columns -- the reduced
+    system is handled as 8 x 8 MFMA tiles (tile-pair kernel) and 8 columns per lane in the back-substitution.
+    Noise-free data: the solve must return the generating values."""
+    from visgeom_amd import synthetic as S
+
+    n_cam, n_frames = 8, 40
+    board = S.board_points()
+    gts = [S.GT_MEI * (1 + 0.002 * k * np.array([1, 0, 0, 0, 0, 0, 1, 1, 0.2, 0.2])) for k in range(n_cam)]
+    xi1k = [np.array([0.06 * (k % 4), 0.06 * (k // 4), 0.0, 0.004 * k, -0.003 * k, 0.002 * k]) for k in range(1, n_cam)]
+    cams = [("mei", gts[0], np.eye(3), np.zeros(3))]
+    for k in range(n_cam - 1):
+        R = S.rodrigues(xi1k[k][3:])
+        cams.append(("mei", gts[k + 1], R.T, -R.T @ xi1k[k][:3]))
+    poses = S.make_poses(S.BASE_SEED + 11, n_frames, cams, board)
+    X1 = np.einsum("nij,kj->nki", S.rodrigues(poses[:, 3:]), board) + poses[:, None, :3]
+    p = vg.CalibrationProblem(0)
+    cids = [p.add_camera("mei", S.INIT["mei"]) for _ in range(n_cam)]
+    tids = [p.add_transform(True, x + 0.004) for x in xi1k]
+    seq = p.add_transform(False, poses + 0.005)
+    for k, (m, intr, Rc, tc) in enumerate(cams):
+        uv, ok = S.project(m, intr, np.einsum("ij,nkj->nki", Rc, X1) + tc)
+        assert ok.all()
+        chain = [(seq, 0)] if k == 0 else [(tids[k - 1], 1), (seq, 0)]
+        p.add_dataset(cids[k], chain, board, uv)
+    p.finalize()
+    s = p.solve(max_num_iterations=300)
+    x = p.get_parameters()
+    print("wide rig", s["termination"], s["num_iterations"], "G", s["num_global_columns"], "cost %.3e -> %.3e" % (s["initial_cost"], s["final_cost"]))
+    assert s["num_global_columns"] == 122
+    assert s["final_cost"] < 1e-15 * s["initial_cost"]
+    for k in range(n_cam):
+        assert np.max(np.abs(x[10 * k:10 * k + 10] - gts[k]) / np.maximum(np.abs(gts[k]), 1.0)) < 1e-6
+    for k in range(n_cam - 1):
+        assert np.max(np.abs(x[80 + 6 * k:86 + 6 * k] - xi1k[k])) < 1e-6
+    p.close()

@@ -222,6 +222,7 @@ constexpr int kBsThreads = 256;
 constexpr int kBsPosesPerGroup = 2;
 constexpr int kBsPosesPerBlock = (kBsThreads / kBsGroup) * kBsPosesPerGroup;
 
+template <int kJ>
 __global__ __launch_bounds__(kBsThreads) void vg_backsub_kernel(BacksubArgs b)
 {
     const SchurArgs &a = b.s;
@@ -256,9 +257,8 @@ __global__ __launch_bounds__(kBsThreads) void vg_backsub_kernel(BacksubArgs b)
             yl[k] = rows[k * C + a.G];
         }
         const bool active = rec[33] != 0.;
-        // G <= 63: at most four columns per lane and row; all 24 loads are issued before the first use (a loop over
-        // a run-time G waits for every load in turn)
-        constexpr int kJ = 4;
+        // G <= 16 kJ - 1: at most kJ columns per lane and row (kJ = 4 up to 63 global columns, 8 up to 127); all
+        // 6 kJ loads are issued before the first use (a loop over a run-time G waits for every load in turn)
         double dgv[kJ], rv[6][kJ];
 #pragma unroll
         for (int j = 0; j < kJ; j++) {
@@ -368,6 +368,44 @@ __global__ __launch_bounds__(256) void vg_dense_gram_kernel(const double *__rest
             for (int tj = ti; tj < T; tj++) acc[ti][tj] = mfma_f64_16x16x4(v[ti], v[tj], acc[ti][tj]);
     }
     store_gram<T>(acc, out + (size_t)grp * C * C, C, lane);
+}
+
+// The same Gram for wide matrices (C > 64, i.e. more than 63 global columns): one wave per (row group, tile pair),
+// blockIdx.y enumerates the upper-triangle tile pairs; every pair writes its own entries of out[group].
+__global__ __launch_bounds__(256) void vg_dense_gram_pair_kernel(const double *__restrict__ X, unsigned int n_rows, int C,
+                                                                  unsigned int rows_per_group, unsigned int n_groups,
+                                                                  double *__restrict__ out)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const unsigned int grp = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (grp >= n_groups) return;
+    // pair index -> (ti <= tj)
+    int ti = 0, rest = (int)blockIdx.y, T = (C + 15) / 16;
+    while (rest >= T - ti) {
+        rest -= T - ti;
+        ti++;
+    }
+    const int tj = ti + rest;
+    const int c = lane & 15, k = lane >> 4;
+    const unsigned int row0 = grp * rows_per_group;
+    f64x4 acc = {0., 0., 0., 0.};
+    for (unsigned int t = 0; t < rows_per_group / 4; t++) {
+        const unsigned int row = row0 + 4 * t + k;
+        const int ci = 16 * ti + c, cj = 16 * tj + c;
+        const double vi = (ci < C && row < n_rows) ? X[(size_t)row * C + ci] : 0.;
+        const double vj = (cj < C && row < n_rows) ? X[(size_t)row * C + cj] : 0.;
+        acc = mfma_f64_16x16x4(vi, vj, acc);
+    }
+    double *g = out + (size_t)grp * C * C;
+    const int row0l = lane >> 4;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int i = 16 * ti + row0l + 4 * r, j = 16 * tj + c;
+        if (i < C && j < C) {
+            g[i * C + j] = acc[r];
+            if (ti != tj) g[j * C + i] = acc[r];
+        }
+    }
 }
 
 }  // namespace vg

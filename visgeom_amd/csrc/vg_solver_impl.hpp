@@ -96,7 +96,10 @@ int launch_dense_gram(hipStream_t st, const double *X, unsigned n_rows, int C, u
     if (T == 1) hipLaunchKernelGGL((vg::vg_dense_gram_kernel<1>), grid, blk, 0, st, X, n_rows, C, rows_per_group, n_groups, out);
     else if (T == 2) hipLaunchKernelGGL((vg::vg_dense_gram_kernel<2>), grid, blk, 0, st, X, n_rows, C, rows_per_group, n_groups, out);
     else if (T == 3) hipLaunchKernelGGL((vg::vg_dense_gram_kernel<3>), grid, blk, 0, st, X, n_rows, C, rows_per_group, n_groups, out);
-    else hipLaunchKernelGGL((vg::vg_dense_gram_kernel<4>), grid, blk, 0, st, X, n_rows, C, rows_per_group, n_groups, out);
+    else if (T == 4) hipLaunchKernelGGL((vg::vg_dense_gram_kernel<4>), grid, blk, 0, st, X, n_rows, C, rows_per_group, n_groups, out);
+    else  // wide reduced systems: one wave per (row group, tile pair)
+        hipLaunchKernelGGL(vg::vg_dense_gram_pair_kernel, dim3(grid.x, (unsigned)(T * (T + 1) / 2)), blk, 0, st, X, n_rows, C,
+                           rows_per_group, n_groups, out);
     VG_HIP(hipGetLastError());
     return VG_OK;
 }
@@ -382,7 +385,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
     for (size_t c = 0; c < p->cams.size(); c++) { cam_goff[c] = G; G += p->cams[c].K; }
     for (size_t t = 0; t < p->tfs.size(); t++)
         if (p->tfs[t].global) { tf_goff[t] = G; G += 6; }
-    if (G > 63) return fail(VG_ERR_INVALID_ARGUMENT, "more than 63 global columns are not supported");
+    if (G > 127) return fail(VG_ERR_INVALID_ARGUMENT, "more than 127 global columns are not supported");
     int64_t n_poses = 0;
     for (size_t t = 0; t < p->tfs.size(); t++)
         if (!p->tfs[t].global) { tf_pbase[t] = n_poses; n_poses += p->tfs[t].count; }
@@ -830,7 +833,8 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             ba.xg = d_xg.p;
             if (n_poses || G) {  // G <= kBsThreads: one workgroup is enough for the global columns alone
                 const unsigned int bs_grid = n_bs_groups ? n_bs_groups : 1u;
-                hipLaunchKernelGGL(vg::vg_backsub_kernel, dim3(bs_grid), dim3(vg::kBsThreads), 0, st, ba);
+                if (G < 64) hipLaunchKernelGGL(vg::vg_backsub_kernel<4>, dim3(bs_grid), dim3(vg::kBsThreads), 0, st, ba);
+                else hipLaunchKernelGGL(vg::vg_backsub_kernel<8>, dim3(bs_grid), dim3(vg::kBsThreads), 0, st, ba);
                 VG_HIP(hipGetLastError());
             }
             if (n_bs_groups) {  // fixed-order sum of the per-workgroup partials
