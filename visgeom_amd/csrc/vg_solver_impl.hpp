@@ -517,8 +517,8 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
     const unsigned int rows_per_group = 96;  // 16 poses per wave: enough waves to fill the chip at 5 k poses
     const unsigned int n_groups = n_rows ? (n_rows + rows_per_group - 1) / rows_per_group : 0;
     const unsigned int n_slabs = (n_groups + vg::kSlab - 1) / vg::kSlab;
-    DevBuf<double> gramA[64], gramB[64];
-    if (n_ds > 64) return fail(VG_ERR_INVALID_ARGUMENT, "more than 64 datasets are not supported");
+    std::vector<DevBuf<double>> gramA_v((size_t)(n_ds ? n_ds : 1)), gramB_v((size_t)(n_ds ? n_ds : 1));  // sized once, never resized
+    DevBuf<double> *const gramA = gramA_v.data(), *const gramB = gramB_v.data();
     DevBuf<double> d_sums, d_x, d_xc, d_delta, d_lo, d_hi, d_rec, d_rows, d_rgroups, d_rslabs, d_rgram, d_dg, d_scal;
     DevBuf<vg::SolveDatasetDev> d_dsA, d_dsB;
     DevBuf<int> d_inv, d_ref_ptr, d_ref_ds, d_ref_blk, d_bad;
