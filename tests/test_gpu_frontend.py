@@ -247,3 +247,33 @@ def test_two_files_into_one_problem(gpu, tmp_path):
     with pytest.raises(Exception):
         c.addResiduals(p2)
     c.close()
+
+
+def test_do_not_solve_global_keeps_the_dataset_out_of_the_problem(gpu, tmp_path):
+    """flag "do_not_solve_global" (unified_calibration.cpp:516): no residual blocks for that dataset in the global
+    problem; its poses are still initialised and its residual file is still written (:85-88)."""
+    import json
+
+    from visgeom_amd import synthetic as S
+    from visgeom_amd.calibration import GenericCameraCalibration
+
+    d1 = S.make_mono("eucm", 15, 0, sigma=0.0)
+    d2 = S.make_mono("eucm", 8, 9, sigma=0.0)
+    d2["corners"] = d2["corners"] + 4.0           # a shifted detector: would bias the intrinsics if it were used
+    p1 = S.write_calibration_json(str(tmp_path), d1, "eucm", name="a", sequence="xiA", prior=False, init=True)
+    p2 = S.write_calibration_json(str(tmp_path), d2, "eucm", name="b", sequence="xiB", prior=False, init=True,
+                                  flags=["do_not_solve_global"])
+    r = json.load(open(p2))
+    r["cameras"] = []
+    json.dump(r, open(p2, "w"))
+    c = GenericCameraCalibration()
+    c.addResiduals(p1)
+    c.addResiduals(p2)
+    c.compute(max_num_iterations=200)
+    assert c.summary["num_pose_blocks"] == 23
+    assert rel(c.intrinsics("cam"), d1["gt_intrinsics"]) < 1e-6          # untouched by the shifted set
+    sig, _ = c.writeImageResidual(1, tmp_path / "image_error_1.txt", n_images=8)
+    assert np.all(sig > 0.5)                                              # ... which does not fit, and says so
+    sig0, _ = c.writeImageResidual(0, tmp_path / "image_error_0.txt", n_images=15)
+    assert np.all(sig0 < 1e-6)
+    c.close()

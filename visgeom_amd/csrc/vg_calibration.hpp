@@ -679,7 +679,9 @@ int vg_calibration_compute(vg_calibration *c, const vg_solve_options *options, v
         std::vector<double> board, corners;
         std::vector<int32_t> idx;
         for (auto &pt : data.board) board.insert(board.end(), pt.begin(), pt.end());
-        for (size_t i = 0; i < data.detectedCornersVec.size(); i++)
+        // "do_not_solve_global" (:516): the dataset adds no residual blocks to the global problem -- it is registered
+        // without images so that dataset ids keep matching dataVec (its residual file is still written afterwards)
+        for (size_t i = 0; i < data.detectedCornersVec.size() && !data.doNotSolveGlobal; i++)
             if (!data.detectedCornersVec[i].empty()) {  // :520
                 idx.push_back((int32_t)i);
                 corners.insert(corners.end(), data.detectedCornersVec[i].begin(), data.detectedCornersVec[i].end());
