@@ -74,13 +74,24 @@ size_t emit_lds_bytes(bool want_jac, bool frames_lds, int N, int frame_stride)
     return bytes;
 }
 
-template <int MODEL>
-int launch_emit(hipStream_t stream, const vg::EmitArgs &a, bool want_jac)
+bool emit_frames_in_lds(int N, int frame_stride)
 {
-    const int max_frames = vg::kEmitThreads / (int)a.N + 2;
-    const bool frames_lds = (size_t)max_frames * a.frame_stride_d * sizeof(double) <= 32 * 1024;
+    const int max_frames = vg::kEmitThreads / N + 2;
+    return (size_t)max_frames * frame_stride * sizeof(double) <= 32 * 1024;
+}
+
+template <int MODEL>
+int launch_emit(hipStream_t stream, const vg::EmitArgs &a, bool want_jac, bool inline_chain)
+{
+    const bool frames_lds = emit_frames_in_lds((int)a.N, a.frame_stride_d);
     const size_t lds = emit_lds_bytes<MODEL>(want_jac, frames_lds, (int)a.N, a.frame_stride_d);
     const unsigned int grid = (a.n_obs + vg::kEmitThreads - 1) / vg::kEmitThreads;
+    if (inline_chain) {  // the caller checked: one DIRECT member, frames fit the LDS
+        if (want_jac) hipLaunchKernelGGL((vg::vg_emit_kernel<MODEL, true, true, true>), dim3(grid), dim3(vg::kEmitThreads), lds, stream, a);
+        else hipLaunchKernelGGL((vg::vg_emit_kernel<MODEL, false, true, true>), dim3(grid), dim3(vg::kEmitThreads), lds, stream, a);
+        VG_HIP(hipGetLastError());
+        return VG_OK;
+    }
     if (want_jac) {
         if (frames_lds)
             hipLaunchKernelGGL((vg::vg_emit_kernel<MODEL, true, true>), dim3(grid), dim3(vg::kEmitThreads), lds, stream, a);
@@ -400,6 +411,7 @@ int vg_problem_finalize(vg_problem *p)
         // image b uses element b of its sequence (the common case): no index array -> one dependent load less
         bool identity = true;
         for (size_t i = 0; i < d.h_seq.size() && identity; i++) identity = d.h_seq[i] == (int32_t)i;
+        d.seq_identity = identity;
         pd.seq_index = identity ? nullptr : d.d_seq;
         pd.frames = d.d_frames;
         pd.first = first;
@@ -441,6 +453,7 @@ int vg_problem_set_parameters(vg_problem *p, const double *host_params)
     VG_HIP(hipSetDevice(p->device));
     VG_HIP(hipMemcpyAsync(p->d_params, host_params, sizeof(double) * (size_t)p->n_params, hipMemcpyHostToDevice, p->stream));
     VG_HIP(hipStreamSynchronize(p->stream));
+    p->frames_stale = true;
     return VG_OK;
 }
 
@@ -467,8 +480,18 @@ int vg_dataset_num_intrinsics(const vg_problem *p, int d)
 
 }  // extern "C"
 
+int vgi::ensure_frames(vg_problem *p)
+{
+    if (!p->frames_stale) return VG_OK;
+    const int rc = vgi::prepare_at(p, p->d_params);
+    if (rc == VG_OK) p->frames_stale = false;
+    return rc;
+}
+
 int vgi::prepare_at(vg_problem *p, const double *d_params)
 {
+    // whatever point this is, the frames no longer belong to an earlier vg_problem_prepare
+    p->frames_stale = d_params != p->d_params;
     if (!p->prep_blocks) return VG_OK;
     const unsigned int grid = (unsigned int)((p->prep_blocks + 63) / 64);
     hipLaunchKernelGGL(vg::vg_chain_prep_multi_kernel, dim3(grid), dim3(64), 0, p->stream, d_params,
@@ -484,7 +507,10 @@ int vg_problem_prepare(vg_problem *p)
     if (!p) return fail(VG_ERR_INVALID_ARGUMENT, "problem is NULL");
     if (!p->finalized) return fail(VG_ERR_STATE, "problem not finalized");
     VG_HIP(hipSetDevice(p->device));
-    return vgi::prepare_at(p, p->d_params);
+    // Lazy: the frames are rebuilt by the first consumer that reads them from HBM (ensure_frames); an evaluation of
+    // a single-member DIRECT chain derives them inside the emit kernel and never needs this launch.
+    p->frames_stale = true;
+    return VG_OK;
 }
 
 int vg_dataset_evaluate(vg_problem *p, int dataset_id, double *residuals, double *jac_intr, double *const *jac_member)
@@ -502,6 +528,10 @@ int vg_dataset_evaluate(vg_problem *p, int dataset_id, double *residuals, double
     bool want_jac = jac_intr != nullptr;
     for (int l = 0; l < d.L; l++)
         if (jac_member && jac_member[l]) want_jac = true;
+    // one DIRECT member and stale frames: the emit kernel walks the (trivial) chain itself -- one launch per evaluation
+    const bool inline_chain = p->frames_stale && d.L == 1 && d.status[0] == VG_TRANSFORM_DIRECT &&
+                              emit_frames_in_lds(d.N, d.frame_stride);
+    if (!inline_chain && (rc = vgi::ensure_frames(p)) != VG_OK) return rc;
 
     // 32-bit observation indices inside a launch: chunk very large datasets by whole images
     int64_t max_obs = (int64_t)1 << 30;
@@ -524,10 +554,14 @@ int vg_dataset_evaluate(vg_problem *p, int dataset_id, double *residuals, double
         a.N = (unsigned int)d.N;
         a.L = d.L;
         a.frame_stride_d = d.frame_stride;
+        a.chain_params = d.L ? p->d_params + d.chain.base[0] : nullptr;
+        a.chain_stride = d.L ? d.chain.stride[0] : 0;
+        a.seq_index = d.seq_identity ? nullptr : d.d_seq + b0;
+        a.first_block = b0;
         switch (cam.model) {
-        case VG_MODEL_EUCM: rc = launch_emit<vg::kEUCM>(p->stream, a, want_jac); break;
-        case VG_MODEL_UCM: rc = launch_emit<vg::kUCM>(p->stream, a, want_jac); break;
-        default: rc = launch_emit<vg::kMEI>(p->stream, a, want_jac); break;
+        case VG_MODEL_EUCM: rc = launch_emit<vg::kEUCM>(p->stream, a, want_jac, inline_chain); break;
+        case VG_MODEL_UCM: rc = launch_emit<vg::kUCM>(p->stream, a, want_jac, inline_chain); break;
+        default: rc = launch_emit<vg::kMEI>(p->stream, a, want_jac, inline_chain); break;
         }
         if (rc != VG_OK) return rc;
     }
@@ -619,6 +653,7 @@ int vg_dataset_gram_fused(vg_problem *p, int dataset_id, double *gram)
     if (rc != VG_OK) return rc;
     if (!p->finalized) return fail(VG_ERR_STATE, "problem not finalized");
     VG_HIP(hipSetDevice(p->device));
+    if ((rc = vgi::ensure_frames(p)) != VG_OK) return rc;
     return vgi::gram_fused_at(p, dataset_id, p->d_params, gram);
 }
 
@@ -755,8 +790,8 @@ int vg_block_evaluate(vg_block *b, double const *const *parameters, double *resi
     VG_HIP(hipSetDevice(p->device));
     hipStream_t s = p->stream;
     VG_HIP(hipMemcpyAsync(p->d_params, b->h_params, sizeof(double) * (size_t)p->n_params, hipMemcpyHostToDevice, s));
-    int rc = vgi::prepare_at(p, p->d_params);
-    if (rc != VG_OK) return rc;
+    p->frames_stale = true;  // new parameters: vg_dataset_evaluate rebuilds the frames (in-kernel for a single DIRECT member)
+    int rc = VG_OK;
     double *jm[vg::kMaxChain] = {nullptr};
     double *ji = nullptr;
     size_t last = 2 * (size_t)b->N;  // doubles to bring back: up to the end of the last requested block

@@ -287,4 +287,29 @@ VG_HD void build_frame(int L, const int *status, MemberFn member, double *frame)
     frame[9] = acc.t[0]; frame[10] = acc.t[1]; frame[11] = acc.t[2];
 }
 
+// The frame of a chain with ONE member used DIRECT (the mono calibration case): xiAcc = identity o xi23 = xi23.
+// build_frame() gets there through the reference's rotvec -> quaternion -> rotvec round trip and a second Rodrigues
+// evaluation; that round trip is the identity up to rounding (|dR| < 1e-15, also across its first-order branches,
+// where the rotation vector moves by theta^3 / 24 < 4e-16), so this routine evaluates the trig once and is short enough
+// (about 300 instructions) to run inside the emit kernel instead of as a launch of its own.
+VG_HD void build_frame_single_direct(const double *xi, double *frame)
+{
+    const double r[3] = {xi[3], xi[4], xi[5]};
+    const RotTrig g = rot_trig(r, true, true);
+    double R[9], Rb[9], M[9], R12[9], M12[9];
+    rotation_matrix(r, 1., g, R);     // R13 = R(xiAcc.rot)
+    rotation_matrix(r, -1., g, Rb);   // xi23.rotMatInv()
+    mat3_mul(R, Rb, R12);             // jacobian.h:142 (the identity up to rounding, kept as computed)
+    inter_omega_rot(r, g, M);
+    mat3_mul(R12, M, M12);
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        frame[i] = R[i];
+        frame[12 + i] = R12[i];
+        frame[21 + i] = M12[i];
+    }
+    frame[9] = xi[0]; frame[10] = xi[1]; frame[11] = xi[2];
+    frame[30] = xi[0]; frame[31] = xi[1]; frame[32] = xi[2];
+}
+
 }  // namespace vg

@@ -47,6 +47,7 @@ struct Dataset {
     int64_t n_blocks = 0;
     std::vector<double> h_board, h_obs;
     std::vector<int32_t> h_seq;
+    bool seq_identity = true;  // image b uses element b of its sequence: no index array needed on the device
     double *d_board = nullptr, *d_obs = nullptr, *d_frames = nullptr;
     int32_t *d_seq = nullptr;
     unsigned long long *d_failed = nullptr;
@@ -83,6 +84,9 @@ struct vg_problem {
     vg::PrepDataset *d_prep = nullptr;  // one descriptor per non-empty dataset (vg_chain_prep_multi_kernel)
     int n_prep = 0;
     int64_t prep_blocks = 0;
+    // vg_problem_prepare marks the frames stale; they are rebuilt on demand (chain-prep kernel) by whoever reads
+    // them from HBM -- or never, when every consumer derives them in-kernel (single-member DIRECT chains)
+    bool frames_stale = true;
 };
 
 struct vg_block {
@@ -101,6 +105,7 @@ namespace vgi {
 // kernel launches on an explicit parameter buffer (the solver evaluates candidate points without
 // touching the problem's own parameter vector); implemented in vg_capi.hip
 int prepare_at(vg_problem *p, const double *d_params);
+int ensure_frames(vg_problem *p);  // chain prep at the problem's own parameters if the frames are stale
 int gram_fused_at(vg_problem *p, int dataset_id, const double *d_params, double *gram);
 int gram_sum_into(vg_problem *p, int dataset_id, const double *gram, double *sum);
 }  // namespace vgi

@@ -81,6 +81,12 @@ struct EmitArgs {
     double *jac_member[kMaxChain];  // [n_blocks][2N][6] or NULL
     unsigned long long *failed;     // failed-projection counter word: (epoch << 40) | count  (may be NULL)
     unsigned long long epoch;       // evaluation number (24 bits); a stale epoch in the word means count 0
+    // INLINE_CHAIN variant only (single-member DIRECT chain): where the member's 6-vector of image b of this launch
+    // lives: chain_params + chain_stride * (seq_index ? seq_index[b] : first_block + b)
+    const double *chain_params;
+    const int *seq_index;
+    long long chain_stride;
+    long long first_block;
     unsigned int n_obs;    // n_blocks * N  (< 2^31 per launch; the host chunks larger problems)
     unsigned int N;
     int L;
@@ -182,9 +188,13 @@ __device__ __forceinline__ unsigned int xcd_contiguous_block(unsigned int b, uns
 }
 
 // dynamic LDS: 4 wave tiles, then (FRAMES_LDS) the frames of the images this workgroup touches
-template <int MODEL, bool WANT_JAC, bool FRAMES_LDS>
+// INLINE_CHAIN (with FRAMES_LDS, chain = one DIRECT member): the workgroup derives the <= 4 frames it needs itself
+// (thread f walks image b_first + f with build_frame_single_direct) instead of reading them from the chain-prep
+// kernel's output -- a full evaluation is then ONE launch.
+template <int MODEL, bool WANT_JAC, bool FRAMES_LDS, bool INLINE_CHAIN = false>
 __global__ __launch_bounds__(kEmitThreads) void vg_emit_kernel(EmitArgs a)
 {
+    static_assert(!INLINE_CHAIN || FRAMES_LDS, "the inline chain writes its frames to LDS");
     constexpr int K = CameraTraits<MODEL>::K;
     using d2 = HIP_vector_type<double, 2>;
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -199,16 +209,28 @@ __global__ __launch_bounds__(kEmitThreads) void vg_emit_kernel(EmitArgs a)
     const unsigned int b = oc / a.N;
     const unsigned int c = oc - b * a.N;
 
+    // issued before the frames are staged / derived: their latency overlaps the barrier below
+    const double g0 = a.board[3 * c], g1 = a.board[3 * c + 1], g2 = a.board[3 * c + 2];
+    const d2 ob = reinterpret_cast<const d2 *>(a.obs)[oc];
+
     const double *fr;
     if (FRAMES_LDS) {
         double *fr_lds = smem + (kEmitThreads / kWave) * emit_stage_doubles_per_wave<MODEL>();
         const unsigned int b_first = o0 / a.N;
         const unsigned int o_last = (o0 + kEmitThreads - 1 < a.n_obs) ? o0 + kEmitThreads - 1 : a.n_obs - 1;
         const unsigned int nf = o_last / a.N - b_first + 1;
-        const int n16 = (int)(nf * (unsigned)a.frame_stride_d) >> 1;
-        const d2 *src = reinterpret_cast<const d2 *>(a.frames + (size_t)b_first * a.frame_stride_d);
-        d2 *dst = reinterpret_cast<d2 *>(fr_lds);
-        for (int i = tid; i < n16; i += kEmitThreads) dst[i] = src[i];
+        if (INLINE_CHAIN) {
+            for (unsigned int f = tid; f < nf; f += kEmitThreads) {
+                const long long bi = (long long)b_first + f;
+                const long long si = a.seq_index ? (long long)a.seq_index[bi] : a.first_block + bi;
+                build_frame_single_direct(a.chain_params + a.chain_stride * si, fr_lds + f * a.frame_stride_d);
+            }
+        } else {
+            const int n16 = (int)(nf * (unsigned)a.frame_stride_d) >> 1;
+            const d2 *src = reinterpret_cast<const d2 *>(a.frames + (size_t)b_first * a.frame_stride_d);
+            d2 *dst = reinterpret_cast<d2 *>(fr_lds);
+            for (int i = tid; i < n16; i += kEmitThreads) dst[i] = src[i];
+        }
         __syncthreads();
         fr = fr_lds + (b - b_first) * a.frame_stride_d;
     } else {
@@ -216,12 +238,9 @@ __global__ __launch_bounds__(kEmitThreads) void vg_emit_kernel(EmitArgs a)
     }
 
     // pointCam = R(xiAcc.rot) * grid + xiAcc.trans     calib_cost_functions.cpp:49-50
-    const double g0 = a.board[3 * c], g1 = a.board[3 * c + 1], g2 = a.board[3 * c + 2];
     const double X0 = (fr[0] * g0 + fr[1] * g1 + fr[2] * g2) + fr[9];
     const double X1 = (fr[3] * g0 + fr[4] * g1 + fr[5] * g2) + fr[10];
     const double X2 = (fr[6] * g0 + fr[7] * g1 + fr[8] * g2) + fr[11];
-
-    const d2 ob = reinterpret_cast<const d2 *>(a.obs)[oc];
 
     CornerEval<K> e;
     eval_corner<MODEL, WANT_JAC, WANT_JAC>(a.intr, X0, X1, X2, e);
