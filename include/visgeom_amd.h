@@ -157,9 +157,11 @@ int vg_dataset_chain_len(const vg_problem *p, int dataset_id);
 int vg_dataset_num_intrinsics(const vg_problem *p, int dataset_id);
 
 /* ---- evaluation (asynchronous on the problem's stream; sync with vg_problem_synchronize) ----
- * vg_problem_prepare: kernel 1 -- composes every block's transform chain at the CURRENT device
- *   parameters (the two chain walks of calib_cost_functions.cpp:32-46 and :76-92, the InterJacobian
- *   ctor jacobian.h:139-152) into a per-block frame.  Call after every parameter change.
+ * vg_problem_prepare: declares the device parameters changed.  Every block's transform chain (the two chain walks
+ *   of calib_cost_functions.cpp:32-46 and :76-92, the InterJacobian ctor jacobian.h:139-152) is composed into a
+ *   per-block frame by kernel 1 the next time a kernel reads frames from memory (Gram kernels, multi-member chains);
+ *   for a chain of ONE member used DIRECT (mono calibration) kernel 2 derives the frame itself and an evaluation is a
+ *   single launch.  Call after every parameter change (vg_problem_set_parameters implies it).
  * vg_dataset_evaluate: kernel 2 -- one thread per (image, corner): residuals + Jacobian rows in the
  *   Ceres block layout, block after block:
  *     residuals  [n_blocks][2N]            jac_intr [n_blocks][2N][K]   (row-major)

@@ -400,3 +400,41 @@ def test_chunked_launches_for_huge_datasets(vg, S, monkeypatch):
     p.synchronize()
     assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1]) and torch.equal(out[2][0], ref[2][0])
     p.close()
+
+
+@pytest.mark.parametrize("model", MODELS)
+def test_inline_chain_and_prepared_frames_agree(vg, S, model):
+    """single-member DIRECT chain: with stale frames the emit kernel walks the chain itself (one launch); once a Gram
+    launch has forced the chain-prep kernel, the same evaluate reads the frames from memory.  Both must give the same
+    rows up to the rounding of the skipped rotvec -> quaternion -> rotvec round trip (|dR| < 1e-15), and both must
+    meet the oracle."""
+    import torch
+
+    d = S.make_mono(model, 40, 3)
+    d["init_poses"][3, 3:] = [1e-7, -2e-7, 1e-7]          # first-order quaternion branch
+    d["init_poses"][4, 3:] = [3.0e-6, 5.0e-6, -7.0e-6]    # between the 1e-6 and 1e-5 thresholds
+    d["init_poses"][5, 3:] *= 3.5 / np.linalg.norm(d["init_poses"][5, 3:])   # |rot| > pi
+    p = vg.CalibrationProblem(0)
+    cam = p.add_camera(model, d["init_intrinsics"])
+    seq = p.add_transform(False, d["init_poses"])
+    ds = p.add_dataset(cam, [(seq, 0)], d["board"], d["corners"])
+    p.finalize()
+    a = p.alloc_outputs(ds)
+    b = p.alloc_outputs(ds)
+    p.prepare()
+    p.evaluate_dataset(ds, a[0], a[1], a[2])              # inline chain
+    gram, _ = p.alloc_gram(ds)
+    p.gram_fused(ds, gram)                                # forces the chain-prep kernel: frames now valid
+    p.evaluate_dataset(ds, b[0], b[1], b[2])              # frames from memory
+    p.synchronize()
+    for x, y, name in ((a[0], b[0], "res"), (a[1], b[1], "jac_intr"), (a[2][0], b[2][0], "jac_pose")):
+        x, y = x.cpu().numpy(), y.cpu().numpy()
+        scale = np.maximum(np.abs(y), np.max(np.abs(y), axis=tuple(range(1, y.ndim)), keepdims=True) * 1e-3 + 1e-300)
+        assert np.max(np.abs(x - y) / scale) < 1e-11, name
+    pv = p.get_parameters()
+    K = len(d["init_intrinsics"])
+    rr, ji, jm = vgo.eval_dataset(vgo.MODELS[model], [0], d["board"], d["corners"], pv, 0, [K], [6], np.arange(40))
+    for got in (a, b):
+        assert_block_parity(got[0].cpu().numpy().reshape(40, -1)[7], [got[1].cpu().numpy()[7], got[2][0].cpu().numpy()[7]],
+                            rr[7], [ji[7], jm[0][7]], d["corners"][7], model)
+    p.close()
