@@ -210,6 +210,9 @@ def main():
     # ~2 us of marker overhead per launch and is kept only as a cross-check.
     emit_ms = b2b_ms
     achieved = bytes_per_obs * n_obs / (emit_ms * 1e-3) / 1e9
+    from visgeom_amd import capi
+
+    single_launch = capi.load().vg_dataset_single_launch(p._h, ds) == 1
     traffic = None
     prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(prof):
@@ -219,8 +222,10 @@ def main():
             traffic = None
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                # single-member DIRECT chain: the emit kernel derives the frames itself, the step is this ONE launch
-                "kernel": "vg_emit_kernel<%s,jac,frames-in-LDS,inline-chain>" % a.model,
+                # single-member DIRECT chain, output within reach of the Infinity Cache: the emit kernel derives the
+                # frames itself and the step is this ONE launch; larger sets run chain prep + emit
+                "kernel": "vg_emit_kernel<%s,jac,frames-in-LDS%s>" % (a.model, ",inline-chain" if single_launch else ""),
+                "launches_per_step": 1 if single_launch else 2,
                 "algorithmic_bytes_per_launch": bytes_per_obs * n_obs, "bytes_per_obs": bytes_per_obs,
                 "avg_launch_ms": emit_ms, "event_pair_per_launch_ms": float(np.mean(per_launch_ms)),
                 "event_pair_median_ms": float(np.median(per_launch_ms))}
@@ -371,7 +376,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": "%s mono, %d images x %d corners (8x12 board) per GPU, chain [xiCamBoard DIRECT], "
                                "residual + all Jacobian blocks (K=%d intrinsics + 6 pose) emitted to HBM in Ceres "
-                               "block layout; step = ONE launch: the emit kernel walks the single-member chain itself" % (a.model.upper(), n_img, N, K),
+                               "block layout; step = vg_problem_prepare + vg_dataset_evaluate (%s)" % (a.model.upper(), n_img, N, K, "one launch: the emit kernel walks the single-member chain itself" if single_launch else "chain-prep kernel + emit kernel"),
                    "images_per_gpu": n_img, "corners_per_image": N, "camera_model": a.model, "chain": ["DIRECT"],
                    "seed": int(d["seed"]), "sharding": "images sharded over ranks, no data-path collective"},
         "roofline": roofline,

@@ -154,6 +154,9 @@ int vg_problem_num_datasets(const vg_problem *p);
 int64_t vg_dataset_num_blocks(const vg_problem *p, int dataset_id);
 int vg_dataset_num_points(const vg_problem *p, int dataset_id);
 int vg_dataset_chain_len(const vg_problem *p, int dataset_id);
+/* 1 when an evaluation of this dataset after a parameter change is a single launch (one DIRECT chain member, output
+ * of the launch within reach of the Infinity Cache), 0 when it is chain prep + emit, -1 on a bad id */
+int vg_dataset_single_launch(const vg_problem *p, int dataset_id);
 int vg_dataset_num_intrinsics(const vg_problem *p, int dataset_id);
 
 /* ---- evaluation (asynchronous on the problem's stream; sync with vg_problem_synchronize) ----

@@ -88,6 +88,7 @@ SIGNATURES = {
     "vg_dataset_num_blocks": (ctypes.c_int64, [_vp, ctypes.c_int]),
     "vg_dataset_num_points": (ctypes.c_int, [_vp, ctypes.c_int]),
     "vg_dataset_chain_len": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "vg_dataset_single_launch": (ctypes.c_int, [_vp, ctypes.c_int]),
     "vg_dataset_num_intrinsics": (ctypes.c_int, [_vp, ctypes.c_int]),
     "vg_problem_prepare": (ctypes.c_int, [_vp]),
     "vg_dataset_evaluate": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vpp]),

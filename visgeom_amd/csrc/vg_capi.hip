@@ -74,6 +74,20 @@ size_t emit_lds_bytes(bool want_jac, bool frames_lds, int N, int frame_stride)
     return bytes;
 }
 
+// Largest evaluation (bytes of residuals + Jacobian rows + observations per launch) for which the emit kernel walks a
+// single-member chain itself.  While the output fits the 256 MiB Infinity Cache the in-kernel walk beats the extra
+// launch (EUCM 12 k images, 258 MB: 40.7 vs 54.1 us; 10 k: 35.4 vs 39.9 us); once the launch streams to HBM the
+// walk slows the store stream by more than the ~6.5 us launch it saves (15 k images, 322 MB: 76.0 vs 70.2 us).
+// tools/exp/inline_chain_probe.py
+int64_t inline_chain_max_bytes()
+{
+    static const int64_t v = [] {
+        const char *e = getenv("VG_INLINE_CHAIN_MAX_BYTES");  // measurement hook
+        return e ? (int64_t)atoll(e) : (int64_t)288000000;
+    }();
+    return v;
+}
+
 bool emit_frames_in_lds(int N, int frame_stride)
 {
     const int max_frames = vg::kEmitThreads / N + 2;
@@ -105,6 +119,12 @@ int launch_emit(hipStream_t stream, const vg::EmitArgs &a, bool want_jac, bool i
     }
     VG_HIP(hipGetLastError());
     return VG_OK;
+}
+
+bool single_launch_dataset(const vg_problem *p, const Dataset &d)
+{
+    return d.L == 1 && d.status[0] == VG_TRANSFORM_DIRECT && emit_frames_in_lds(d.N, d.frame_stride) &&
+           d.n_blocks * (int64_t)d.N * (32 + 16 * (p->cams[d.camera].K + 6)) <= inline_chain_max_bytes();
 }
 
 int valid_dataset(const vg_problem *p, int d)
@@ -471,6 +491,10 @@ double *vg_problem_parameters_device(vg_problem *p) { return p && p->finalized ?
 
 int vg_problem_num_datasets(const vg_problem *p) { return p ? (int)p->dss.size() : -1; }
 int64_t vg_dataset_num_blocks(const vg_problem *p, int d) { return valid_dataset(p, d) == VG_OK ? p->dss[d].n_blocks : -1; }
+int vg_dataset_single_launch(const vg_problem *p, int d)
+{
+    return valid_dataset(p, d) == VG_OK && p->finalized ? (single_launch_dataset(p, p->dss[d]) ? 1 : 0) : -1;
+}
 int vg_dataset_num_points(const vg_problem *p, int d) { return valid_dataset(p, d) == VG_OK ? p->dss[d].N : -1; }
 int vg_dataset_chain_len(const vg_problem *p, int d) { return valid_dataset(p, d) == VG_OK ? p->dss[d].L : -1; }
 int vg_dataset_num_intrinsics(const vg_problem *p, int d)
@@ -529,8 +553,8 @@ int vg_dataset_evaluate(vg_problem *p, int dataset_id, double *residuals, double
     for (int l = 0; l < d.L; l++)
         if (jac_member && jac_member[l]) want_jac = true;
     // one DIRECT member and stale frames: the emit kernel walks the (trivial) chain itself -- one launch per evaluation
-    const bool inline_chain = p->frames_stale && d.L == 1 && d.status[0] == VG_TRANSFORM_DIRECT &&
-                              emit_frames_in_lds(d.N, d.frame_stride);
+    // (only while the launch's output fits the Infinity Cache, see inline_chain_max_bytes)
+    const bool inline_chain = p->frames_stale && single_launch_dataset(p, d);
     if (!inline_chain && (rc = vgi::ensure_frames(p)) != VG_OK) return rc;
 
     // 32-bit observation indices inside a launch: chunk very large datasets by whole images
