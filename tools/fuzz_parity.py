@@ -19,6 +19,7 @@ n_problems = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 worst = {}
 n_failed_rows = 0
+n_gram_blocks = 0
 for it in range(n_problems):
     model = ["eucm", "ucm", "mei"][rng.integers(3)]
     K = len(S.GT[model])
@@ -59,6 +60,27 @@ for it in range(n_problems):
     idx = image_index if L and seq_pos >= 0 else np.arange(n_img)
     rr, rji, rjm = vgo.eval_dataset(vgo.MODELS[model], status, board, corners, x, 0, bases, strides, idx)
     R = res.cpu().numpy().reshape(n_img, -1)
+    # fused Gram of [J | r] against the long-double Gram of the oracle's rows (blocks with finite rows only)
+    gram, gsum = p.alloc_gram(ds)
+    p.gram_fused(ds, gram)
+    p.gram_sum(ds, gram, gsum)
+    p.synchronize()
+    Gd = gram.cpu().numpy()
+    finite = [b for b in range(n_img) if np.all(np.isfinite(rr[b])) and np.all(np.isfinite(rji[b])) and all(np.all(np.isfinite(m[b])) for m in rjm)]
+    for b in finite:
+        Gref = vgo.block_gram(rr[b], rji[b], [m[b] for m in rjm])
+        dg = np.sqrt(np.abs(np.diag(Gref)))
+        scale = np.maximum(np.outer(dg, dg), 1e-300)
+        v = float(np.max(np.abs(Gd[b] - Gref) / scale)) / 1e-10
+        n_gram_blocks += 1
+        if v > worst.get("gram", (0,))[0]:
+            worst["gram"] = (v, model, status, N, n_img, it)
+        assert np.array_equal(Gd[b], Gd[b].T)
+    if len(finite) == n_img:
+        ref_sum = np.sum([vgo.block_gram(rr[b], rji[b], [m[b] for m in rjm]).astype(np.longdouble) for b in range(n_img)], axis=0).astype(np.float64)
+        v = float(np.linalg.norm(gsum.cpu().numpy() - ref_sum) / max(np.linalg.norm(ref_sum), 1e-300)) / 1e-10
+        if v > worst.get("gramsum", (0,))[0]:
+            worst["gramsum"] = (v, model, status, N, n_img, it)
     for b in range(n_img):
         jacs = [None if null_intr else ji.cpu().numpy()[b]] + [None if null_member[l] else jm[l].cpu().numpy()[b] for l in range(L)]
         refs = [None if null_intr else rji[b]] + [None if null_member[l] else rjm[l][b] for l in range(L)]
@@ -71,7 +93,7 @@ for it in range(n_problems):
             if v > worst.get(key, (0,))[0]:
                 worst[key] = (v, model, status, N, n_img, it)
     p.close()
-print("problems", n_problems, "failed-projection corners seen", n_failed_rows)
+print("problems", n_problems, "failed-projection corners seen", n_failed_rows, "Gram blocks checked", n_gram_blocks)
 for k, v in sorted(worst.items()):
     print("worst %-9s %.3e x tol (1e-10)   %s chain %s N=%d images=%d problem #%d" % ((k,) + v))
 bad = {k: v for k, v in worst.items() if not v[0] <= 1.0}
