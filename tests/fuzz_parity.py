@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Randomised parity sweep of the batched path against the oracle (tools only; the committed tests hold the curated
-cases).  Random model, chain length 0..5 with random DIRECT / INVERSE members and a random position of the sequence
+"""Randomised parity sweep of the batched path against the oracle (test infrastructure: run by test_gpu_fuzz.py or
+by hand; the other tests hold the curated cases).  Random model, chain length 0..5 with random DIRECT / INVERSE members and a random position of the sequence
 member, random board size, image count, image-index subsets, NULL Jacobian patterns, tiny / huge rotations.
 
-usage: python tools/fuzz_parity.py [n_problems] [seed]
+usage: python tests/fuzz_parity.py [n_problems] [seed]
 """
 import os
 import sys
