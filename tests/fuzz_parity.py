@@ -29,7 +29,7 @@ for it in range(n_problems):
     n_seq = int(rng.integers(1, 40))
     n_img = int(rng.integers(1, n_seq + 1))
     image_index = np.sort(rng.choice(n_seq, n_img, replace=False)).astype(np.int32)
-    seq_pos = int(rng.integers(L)) if L else -1
+    seq_pos = int(rng.integers(L)) if L and rng.random() > 0.15 else -1   # -1: a chain of global transforms only
     board = np.stack([rng.uniform(0, 1.1, N), rng.uniform(0, 0.7, N), rng.uniform(-0.05, 0.05, N)], -1)
     intr = S.GT[model] * (1 + 0.02 * rng.standard_normal(K))
     p = CalibrationProblem(0)
