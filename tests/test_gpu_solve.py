@@ -541,6 +541,20 @@ def test_degenerate_structures(vg):
     assert rel(x[:6], d["gt_intrinsics"]) < 2e-2 and s["final_cost"] < 1e-3 * s["initial_cost"]
     assert np.array_equal(x[6 + 72:], d["init_poses"][:3].ravel())      # unreferenced poses do not move
     p.close()
+    # (4) no sequence member at all: five noisy views of ONE board pose held by a global transform (no pose blocks)
+    pose = d["gt_poses"][0]
+    uv, ok = S.project("eucm", d["gt_intrinsics"], (S.rodrigues(pose[3:]) @ d["board"].T).T + pose[:3])
+    assert ok.all()
+    views = uv[None] + 0.1 * np.random.default_rng(2).standard_normal((5, 96, 2))
+    p = vg.CalibrationProblem(0)
+    cam = p.add_camera("eucm", d["gt_intrinsics"], constant=True)
+    glob = p.add_transform(True, pose + 0.01)
+    p.add_dataset(cam, [(glob, 0)], d["board"], views)
+    p.finalize()
+    s = p.solve(max_num_iterations=100)
+    assert s["num_pose_blocks"] == 0 and s["num_global_columns"] == 12
+    assert np.max(np.abs(p.get_parameters()[6:12] - pose)) < 1e-3 and s["final_cost"] < 1e-2 * s["initial_cost"]
+    p.close()
     # (3) a single image: 6 + 6 unknowns against 192 residuals
     p = vg.CalibrationProblem(0)
     cam = p.add_camera("eucm", d["gt_intrinsics"], constant=True)
