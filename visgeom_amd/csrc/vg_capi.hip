@@ -121,10 +121,19 @@ int launch_emit(hipStream_t stream, const vg::EmitArgs &a, bool want_jac, bool i
     return VG_OK;
 }
 
-bool single_launch_dataset(const vg_problem *p, const Dataset &d)
+bool dataset_can_inline_chain(const vg_problem *p, const Dataset &d)
 {
     return d.L == 1 && d.status[0] == VG_TRANSFORM_DIRECT && emit_frames_in_lds(d.N, d.frame_stride) &&
            d.n_blocks * (int64_t)d.N * (32 + 16 * (p->cams[d.camera].K + 6)) <= inline_chain_max_bytes();
+}
+
+// The in-kernel chain pays off when it REPLACES the chain-prep launch.  That launch serves all datasets of a problem
+// at once, so as soon as one dataset needs it (a multi-member chain, a very large set) the others read its frames too.
+bool single_launch_dataset(const vg_problem *p, const Dataset &d)
+{
+    for (const Dataset &o : p->dss)
+        if (o.n_blocks && !dataset_can_inline_chain(p, o)) return false;
+    return dataset_can_inline_chain(p, d);
 }
 
 int valid_dataset(const vg_problem *p, int d)
