@@ -155,7 +155,8 @@ int64_t vg_dataset_num_blocks(const vg_problem *p, int dataset_id);
 int vg_dataset_num_points(const vg_problem *p, int dataset_id);
 int vg_dataset_chain_len(const vg_problem *p, int dataset_id);
 /* 1 when an evaluation of this dataset after a parameter change is a single launch (one DIRECT chain member, output
- * of the launch within reach of the Infinity Cache), 0 when it is chain prep + emit, -1 on a bad id */
+ * of the launch within reach of the Infinity Cache, and no other dataset of the problem needing the chain-prep launch
+ * anyway), 0 when it is chain prep + emit, -1 on a bad id */
 int vg_dataset_single_launch(const vg_problem *p, int dataset_id);
 int vg_dataset_num_intrinsics(const vg_problem *p, int dataset_id);
 
