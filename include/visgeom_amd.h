@@ -198,6 +198,12 @@ int vg_dataset_gram_width(const vg_problem *p, int dataset_id); /* W */
  * J is never written to HBM.  gram: device [n_blocks][W*W], row-major, full symmetric.  Needs
  * vg_problem_prepare at the current parameters, like vg_dataset_evaluate. */
 int vg_dataset_gram_fused(vg_problem *p, int dataset_id, double *gram);
+/* the same per-block matrices AND their fixed-order sum over the dataset's blocks (sum[W*W] device, full symmetric)
+ * in two launches: narrow row blocks (W <= 13: EUCM / UCM mono) are contracted on the FP64 vector pipe with the
+ * chain walked in-kernel, each workgroup leaves the sum of its images, one final launch adds those.  Wider blocks:
+ * vg_dataset_gram_fused + vg_dataset_gram_sum.  The sum equals vg_dataset_gram_sum's to rounding (different fixed
+ * order) and is run-to-run reproducible. */
+int vg_dataset_gram_fused_sum(vg_problem *p, int dataset_id, double *gram, double *sum);
 /* two-pass: the same Gram matrices from rows already materialised by vg_dataset_evaluate
  * (all of residuals, jac_intr and every jac_member[l] are required). */
 int vg_dataset_gram_from_rows(vg_problem *p, int dataset_id, const double *residuals, const double *jac_intr,

@@ -261,13 +261,17 @@ VG_HD void eval_corner_fast(const double *__restrict__ p, double x, double y, do
     const double rho = sqrt(z * z + beta * x2y2);
     const double gamma = 1. - alpha;
     const double eta = alpha * rho + gamma * z;
-    const double ie = 1. / eta, ir = 1. / rho;
+    const double ie_raw = 1. / eta;
     bool ok = !(eta < 1e-3);
     if (alpha > 0.5) {
         const double C = (alpha - 1.) / (alpha + alpha - 1.);
-        if (z * ie < C) ok = false;
+        if (z * ie_raw < C) ok = false;
     }
     e.ok = ok;
+    // failed projection -> zero rows (eucm.h:141-150,198-206).  The two reciprocals are SELECTED to zero, so every
+    // masked product below is 0 * finite = exactly 0 (eta or rho == 0 would otherwise give 0 * inf = NaN)
+    const double ie = ok ? ie_raw : 0., ir = ok ? 1. / rho : 0.;
+    const double m = ok ? 1. : 0.;
     const double xn = x * ie, yn = y * ie;
     e.u = fu * xn + u0;
     e.v = fv * yn + v0;
@@ -276,25 +280,24 @@ VG_HD void eval_corner_fast(const double *__restrict__ p, double x, double y, do
     const double Jxy = k * abrho * x * y;
     const double Jz = k * (gamma + alpha * z * ir);
     const double Jx = gamma * z + alpha * rho;
-    const double m = ok ? 1. : 0.;  // failed projection -> zero rows (eucm.h:141-150,198-206)
-    const double fuk = m * fu * k, fvk = m * fv * k;
+    const double fuk = fu * k, fvk = fv * k;
     e.P[0] = fuk * (Jx - abrho * x * x);
-    e.P[1] = -m * fu * Jxy;
-    e.P[2] = -m * fu * x * Jz;
-    e.P[3] = -m * fv * Jxy;
+    e.P[1] = -fu * Jxy;
+    e.P[2] = -fu * x * Jz;
+    e.P[3] = -fv * Jxy;
     e.P[4] = fvk * (Jx - abrho * y * y);
-    e.P[5] = -m * fv * y * Jz;
+    e.P[5] = -fv * y * Jz;
     const double db = 0.5 * alpha * x2y2 * k * ir;
     e.Ju[0] = -fuk * x * (rho - z);
-    e.Ju[1] = -m * fu * x * db;
-    e.Ju[2] = m * xn;
+    e.Ju[1] = -fu * x * db;
+    e.Ju[2] = xn;
     e.Ju[3] = 0.;
     e.Ju[4] = m;
     e.Ju[5] = 0.;
     e.Jv[0] = -fvk * y * (rho - z);
-    e.Jv[1] = -m * fv * y * db;
+    e.Jv[1] = -fv * y * db;
     e.Jv[2] = 0.;
-    e.Jv[3] = m * yn;
+    e.Jv[3] = yn;
     e.Jv[4] = 0.;
     e.Jv[5] = m;
 }

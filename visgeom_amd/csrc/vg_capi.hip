@@ -9,6 +9,7 @@
 
 #include "vg_internal.hpp"
 #include "vg_gram.hpp"
+#include "vg_gram_valu.hpp"
 #include "vg_transf_host.hpp"
 
 namespace {
@@ -50,7 +51,8 @@ void free_dataset(Dataset &d)
     if (d.d_seq) (void)hipFree(d.d_seq);
     if (d.d_failed) (void)hipFree(d.d_failed);
     if (d.d_partials) (void)hipFree(d.d_partials);
-    d.d_partials = nullptr;
+    if (d.d_wg_partials) (void)hipFree(d.d_wg_partials);
+    d.d_partials = d.d_wg_partials = nullptr;
     if (d.d_out_res) (void)hipFree(d.d_out_res);
     if (d.d_out_ji) (void)hipFree(d.d_out_ji);
     d.d_out_res = d.d_out_ji = nullptr;
@@ -187,6 +189,45 @@ int launch_gram_fused(hipStream_t stream, const vg::GramArgs &a)
     else hipLaunchKernelGGL((vg::vg_gram_fused_kernel<MODEL, 3>), dim3(grid), blk, lds, stream, a);
     VG_HIP(hipGetLastError());
     return VG_OK;
+}
+
+
+// Narrow row blocks (W <= 13, chain of at most one member) take the vector-pipe kernel of vg_gram_valu.hpp; a single
+// DIRECT member is walked in-kernel.  Both are pure functions of the problem (never of call history).
+bool gram_uses_valu(const vg_problem *p, const Dataset &d)
+{
+    static const bool force_mfma = getenv("VG_GRAM_FORCE_MFMA") != nullptr;  // measurement hook (A/B of the two kernels)
+    return !force_mfma && d.L <= 1 && p->cams[d.camera].K + 6 * d.L + 1 <= vg::kValuMaxW;
+}
+
+bool gram_inline_chain(const vg_problem *p, const Dataset &d)
+{
+    return gram_uses_valu(p, d) && d.L == 1 && d.status[0] == VG_TRANSFORM_DIRECT;
+}
+
+template <int MODEL, int CH>
+int launch_gram_valu_ch(hipStream_t stream, const vg::GramValuArgs &a, int L, bool inline_chain)
+{
+    constexpr int K = vg::CameraTraits<MODEL>::K;
+    const dim3 grid(a.n_wg), blk(vg::kValuThreads);
+    if (L == 0) {
+        hipLaunchKernelGGL((vg::vg_gram_valu_kernel<MODEL, 0, false, CH>), grid, blk, 0, stream, a);
+    } else if constexpr (K + 7 <= vg::kValuMaxW) {
+        if (inline_chain) hipLaunchKernelGGL((vg::vg_gram_valu_kernel<MODEL, 1, true, CH>), grid, blk, 0, stream, a);
+        else hipLaunchKernelGGL((vg::vg_gram_valu_kernel<MODEL, 1, false, CH>), grid, blk, 0, stream, a);
+    } else {
+        return fail(VG_ERR_STATE, "row block too wide for the vector-pipe Gram kernel");
+    }
+    VG_HIP(hipGetLastError());
+    return VG_OK;
+}
+
+template <int MODEL>
+int launch_gram_valu(hipStream_t stream, const vg::GramValuArgs &a, int L, bool inline_chain)
+{
+    // corners per lane and chunk: small boards (at most one corner per lane of the half-wave) do not pay for three
+    return a.g.N <= (unsigned)vg::kValuLanesPerImage ? launch_gram_valu_ch<MODEL, 1>(stream, a, L, inline_chain)
+                                                     : launch_gram_valu_ch<MODEL, 3>(stream, a, L, inline_chain);
 }
 
 }  // namespace
@@ -663,19 +704,59 @@ int vg_dataset_gram_width(const vg_problem *p, int d)
 
 }  // extern "C"
 
-int vgi::gram_fused_at(vg_problem *p, int dataset_id, const double *d_params, double *gram)
+bool vgi::gram_needs_frames(const vg_problem *p)
+{
+    for (const Dataset &d : p->dss)
+        if (d.n_blocks && !gram_inline_chain(p, d)) return true;
+    return false;
+}
+
+int vgi::gram_fused_at(vg_problem *p, int dataset_id, const double *d_params, double *gram, double *sum)
 {
     Dataset &d = p->dss[dataset_id];
-    if (!d.n_blocks) return VG_OK;
+    const Camera &cam = p->cams[d.camera];
+    const int W = cam.K + 6 * d.L + 1;
+    if (!d.n_blocks) {
+        if (sum) VG_HIP(hipMemsetAsync(sum, 0, sizeof(double) * W * W, p->stream));
+        return VG_OK;
+    }
     if (!gram) return fail(VG_ERR_INVALID_ARGUMENT, "gram is NULL");
     if (d.n_blocks > 0x7fffffff) return fail(VG_ERR_INVALID_ARGUMENT, "too many blocks for one launch");
+    int rc;
+    if (gram_uses_valu(p, d)) {
+        vg::GramValuArgs a;
+        fill_gram_args(p, d, a.g, gram, d_params);
+        const bool inl = gram_inline_chain(p, d);
+        a.chain_params = d.L ? d_params + d.chain.base[0] : nullptr;
+        a.chain_stride = d.L ? d.chain.stride[0] : 0;
+        a.seq_index = d.seq_identity ? nullptr : d.d_seq;
+        a.n_wg = (unsigned int)((d.n_blocks + vg::kValuImagesPerBlock - 1) / vg::kValuImagesPerBlock);
+        a.partials = nullptr;
+        const int E = W * (W + 1) / 2;
+        if (sum) {
+            if (!d.d_wg_partials) VG_HIP(hipMalloc(&d.d_wg_partials, sizeof(double) * (size_t)E * a.n_wg));
+            a.partials = d.d_wg_partials;
+        }
+        switch (cam.model) {
+        case VG_MODEL_EUCM: rc = launch_gram_valu<vg::kEUCM>(p->stream, a, d.L, inl); break;
+        case VG_MODEL_UCM: rc = launch_gram_valu<vg::kUCM>(p->stream, a, d.L, inl); break;
+        default: rc = launch_gram_valu<vg::kMEI>(p->stream, a, d.L, inl); break;
+        }
+        if (rc != VG_OK || !sum) return rc;
+        hipLaunchKernelGGL(vg::vg_gram_partials_sum_kernel, dim3(E), dim3(256), 0, p->stream,
+                           (const double *)d.d_wg_partials, a.n_wg, W, sum);
+        VG_HIP(hipGetLastError());
+        return VG_OK;
+    }
     vg::GramArgs a;
     fill_gram_args(p, d, a, gram, d_params);
-    switch (p->cams[d.camera].model) {
-    case VG_MODEL_EUCM: return launch_gram_fused<vg::kEUCM>(p->stream, a);
-    case VG_MODEL_UCM: return launch_gram_fused<vg::kUCM>(p->stream, a);
-    default: return launch_gram_fused<vg::kMEI>(p->stream, a);
+    switch (cam.model) {
+    case VG_MODEL_EUCM: rc = launch_gram_fused<vg::kEUCM>(p->stream, a); break;
+    case VG_MODEL_UCM: rc = launch_gram_fused<vg::kUCM>(p->stream, a); break;
+    default: rc = launch_gram_fused<vg::kMEI>(p->stream, a); break;
     }
+    if (rc != VG_OK || !sum) return rc;
+    return vgi::gram_sum_into(p, dataset_id, gram, sum);
 }
 
 extern "C" {
@@ -686,8 +767,19 @@ int vg_dataset_gram_fused(vg_problem *p, int dataset_id, double *gram)
     if (rc != VG_OK) return rc;
     if (!p->finalized) return fail(VG_ERR_STATE, "problem not finalized");
     VG_HIP(hipSetDevice(p->device));
-    if ((rc = vgi::ensure_frames(p)) != VG_OK) return rc;
-    return vgi::gram_fused_at(p, dataset_id, p->d_params, gram);
+    if (!gram_inline_chain(p, p->dss[dataset_id]) && (rc = vgi::ensure_frames(p)) != VG_OK) return rc;
+    return vgi::gram_fused_at(p, dataset_id, p->d_params, gram, nullptr);
+}
+
+int vg_dataset_gram_fused_sum(vg_problem *p, int dataset_id, double *gram, double *sum)
+{
+    int rc = valid_dataset(p, dataset_id);
+    if (rc != VG_OK) return rc;
+    if (!p->finalized) return fail(VG_ERR_STATE, "problem not finalized");
+    if (!sum) return fail(VG_ERR_INVALID_ARGUMENT, "sum is NULL");
+    VG_HIP(hipSetDevice(p->device));
+    if (!gram_inline_chain(p, p->dss[dataset_id]) && (rc = vgi::ensure_frames(p)) != VG_OK) return rc;
+    return vgi::gram_fused_at(p, dataset_id, p->d_params, gram, sum);
 }
 
 int vg_dataset_gram_from_rows(vg_problem *p, int dataset_id, const double *residuals, const double *jac_intr,

@@ -312,4 +312,52 @@ VG_HD void build_frame_single_direct(const double *xi, double *frame)
     frame[30] = xi[0]; frame[31] = xi[1]; frame[32] = xi[2];
 }
 
+// The same frame for consumers that only need it to rounding-level agreement (the fused Gram kernels, whose rows never
+// leave the CU and are held to 1e-10 of the reference-order Gram): ONE sincos (half angle; sin th = 2 sh ch,
+// 1 - cos th = 2 sh^2), R12 = R(r) R(-r) taken as the identity it is to 1e-16, M from uhat^2 = u u^T - I.  About a third
+// of the dependent instruction chain of build_frame_single_direct -- the chain walk is a serial prologue of every
+// workgroup of vg_gram_valu_kernel.  Below the reference's first-order threshold (theta < 1e-5, where its R12 is
+// I - hat(r)^2, 1e-10 away from I) the reference-order routine is used unchanged.
+VG_HD void build_frame_single_direct_fast(const double *xi, double *frame)
+{
+#pragma clang fp contract(fast)
+    const double r0 = xi[3], r1 = xi[4], r2 = xi[5];
+    const double th = sqrt(r0 * r0 + r1 * r1 + r2 * r2);
+    if (th < 1e-5) {
+        build_frame_single_direct(xi, frame);
+        return;
+    }
+    const double ti = 1. / th;
+    const double u0 = r0 * ti, u1 = r1 * ti, u2 = r2 * ti;
+    const double h = 0.5 * th;
+    double sh, ch;
+    sincos_(h, &sh, &ch);
+    const double s = 2. * sh * ch, cv = 2. * sh * sh;  // sin(theta), 1 - cos(theta)
+    // Rodrigues, geometry_core.h:53-75
+    frame[0] = 1. + cv * (u0 * u0 - 1.);
+    frame[4] = 1. + cv * (u1 * u1 - 1.);
+    frame[8] = 1. + cv * (u2 * u2 - 1.);
+    frame[1] = -s * u2 + cv * u0 * u1;
+    frame[2] = s * u1 + cv * u0 * u2;
+    frame[5] = -s * u0 + cv * u1 * u2;
+    frame[3] = s * u2 + cv * u1 * u0;
+    frame[6] = -s * u1 + cv * u2 * u0;
+    frame[7] = s * u0 + cv * u2 * u1;
+    // interOmegaRot, geometry_core.h:170-179: I + K1 uhat + K2 uhat^2,  K1 = h sinc(h)^2,  K2 = 1 - sinc(theta)
+    const double K1 = sh * sh / h, K2 = 1. - s * ti;
+    frame[21] = 1. + K2 * (u0 * u0 - 1.);
+    frame[25] = 1. + K2 * (u1 * u1 - 1.);
+    frame[29] = 1. + K2 * (u2 * u2 - 1.);
+    frame[22] = -K1 * u2 + K2 * u0 * u1;
+    frame[23] = K1 * u1 + K2 * u0 * u2;
+    frame[26] = -K1 * u0 + K2 * u1 * u2;
+    frame[24] = K1 * u2 + K2 * u1 * u0;
+    frame[27] = -K1 * u1 + K2 * u2 * u0;
+    frame[28] = K1 * u0 + K2 * u2 * u1;
+#pragma unroll
+    for (int i = 0; i < 9; i++) frame[12 + i] = (i % 4 == 0) ? 1. : 0.;
+    frame[9] = xi[0]; frame[10] = xi[1]; frame[11] = xi[2];
+    frame[30] = xi[0]; frame[31] = xi[1]; frame[32] = xi[2];
+}
+
 }  // namespace vg

@@ -1,0 +1,375 @@
+// vg_gram_valu.hpp -- fused evaluate + Gram for NARROW row blocks (W = K + 6L + 1 <= 13: EUCM / UCM mono, the headline
+// workload), entirely on the FP64 vector pipe: "J^T J / J^T r block reductions with wavefront shuffles".
+//
+// Why not the matrix cores here: on gfx950 v_mfma_f64_16x16x4_f64 runs at the FP64 VECTOR rate and shares its datapath
+// (profiles/r01d_fp64_pipes_probe.txt), so its only merit is the built-in cross-lane sum -- and a 16 x 16 tile spends
+// 256 multiply-adds per row on the 91 distinct entries of a symmetric 13 x 13 block, with an LDS write + read per operand
+// in front of it.  Here every lane keeps the upper triangle of ITS corners' Gram sum in registers (only the products of
+// structurally non-zero columns: 110 FMAs per corner for EUCM instead of 2 x 91), and the 32 lanes of an image are
+// combined once per image by a recursive-halving reduction: at step s a lane hands half of its entries to its partner
+// (lane xor 2^s) and receives the partner's copy of the half it keeps, so five steps move 46 + 23 + 12 + 6 + 3 values
+// instead of 5 x 91, all through DPP / swizzle (no LDS memory, no barrier).  The order of every sum is fixed.
+//
+// Work split: one 32-lane half-wave per image (an 8 x 12 board is 3 corners per lane, no idle lanes), 8 images per
+// 256-thread workgroup.  Chains of ONE member used DIRECT are walked in-kernel (thread f of the workgroup derives the
+// frame of image f), so the normal-equation build needs no chain-prep launch.  Optionally the workgroup also leaves the
+// sum of its 8 images (all entries, fixed order) in `partials`, transposed [entry][workgroup], for the one final-sum
+// launch that replaces the slab + final pair.
+#pragma once
+
+#include "vg_gram.hpp"
+
+namespace vg {
+
+constexpr int kValuThreads = 256;
+constexpr int kValuLanesPerImage = 32;
+constexpr int kValuImagesPerBlock = kValuThreads / kValuLanesPerImage;
+constexpr int kValuMaxW = 13;
+
+struct GramValuArgs {
+    GramArgs g;                  // frames (prepared route), board, obs, intr, gram, n_blocks, N, (L, W, stride: template)
+    const double *chain_params;  // INLINE route: member 0 of image b at chain_params + chain_stride * seq(b)
+    const int *seq_index;        // or NULL (identity)
+    long long chain_stride;
+    double *partials;            // [E][n_wg] or NULL
+    unsigned int n_wg;
+};
+
+// structurally non-zero columns of the two intrinsic-Jacobian rows (eucm.h:169-226, ucm.h:153-197, mei.h:193-285)
+template <int MODEL>
+__host__ __device__ constexpr bool intr_nonzero(int row /*0 = u, 1 = v*/, int i)
+{
+    if (MODEL == kEUCM) return row == 0 ? (i != 3 && i != 5) : (i != 2 && i != 4);
+    if (MODEL == kUCM) return row == 0 ? (i != 2 && i != 4) : (i != 1 && i != 3);
+    return row == 0 ? (i != 7 && i != 9) : (i != 6 && i != 8);  // Mei
+}
+
+// One halving step between a lane and its partner (lane xor DIST inside the 32 lanes of an image).  The lane owns the pair
+// (lo, hi); lanes with the DIST bit clear keep lo, lanes with it set keep hi, and each adds the partner's copy of what
+// it keeps:   result = bit ? hi + partner.hi : lo + partner.lo.
+// DIST 16 / 8 / 4 need no select at all: a masked cross-lane move overwrites exactly the half of the lanes that does NOT
+// keep a value with the partner's copy of the value they DO keep, so the sum of the two results is the answer on every
+// lane (v_permlane16_swap_b32 for 16; DPP row_ror:8 / row_shl:4 + row_shr:4 with bank masks for 8 / 4; semantics
+// checked lane by lane with tools/exp/permlane_probe.hip).  DIST 2 / 1 (quad_perm has no per-lane write mask) select.
+template <int DIST>
+__device__ __forceinline__ double halve_pair(double lo, double hi, bool bit)
+{
+    static_assert(DIST == 1 || DIST == 2 || DIST == 4 || DIST == 8 || DIST == 16, "exchange distance");
+    const int lo0 = __double2loint(lo), lo1 = __double2hiint(lo), hi0 = __double2loint(hi), hi1 = __double2hiint(hi);
+    if constexpr (DIST == 16) {
+        // vdst <- lo, src <- hi: rows 1, 3 of vdst receive the partner's hi, rows 0, 2 of src the partner's lo
+        const auto w0 = __builtin_amdgcn_permlane16_swap(lo0, hi0, false, false);
+        const auto w1 = __builtin_amdgcn_permlane16_swap(lo1, hi1, false, false);
+        return __hiloint2double(w1[0], w0[0]) + __hiloint2double(w1[1], w0[1]);
+    } else if constexpr (DIST == 8) {
+        const int a0 = __builtin_amdgcn_update_dpp(lo0, hi0, 0x128, 0xf, 0xC, false);  // lanes 8-15 <- partner's hi
+        const int a1 = __builtin_amdgcn_update_dpp(lo1, hi1, 0x128, 0xf, 0xC, false);
+        const int b0 = __builtin_amdgcn_update_dpp(hi0, lo0, 0x128, 0xf, 0x3, false);  // lanes 0-7  <- partner's lo
+        const int b1 = __builtin_amdgcn_update_dpp(hi1, lo1, 0x128, 0xf, 0x3, false);
+        return __hiloint2double(a1, a0) + __hiloint2double(b1, b0);
+    } else if constexpr (DIST == 4) {
+        const int a0 = __builtin_amdgcn_update_dpp(lo0, hi0, 0x114, 0xf, 0xA, false);  // row_shr:4 into banks 1, 3
+        const int a1 = __builtin_amdgcn_update_dpp(lo1, hi1, 0x114, 0xf, 0xA, false);
+        const int b0 = __builtin_amdgcn_update_dpp(hi0, lo0, 0x104, 0xf, 0x5, false);  // row_shl:4 into banks 0, 2
+        const int b1 = __builtin_amdgcn_update_dpp(hi1, lo1, 0x104, 0xf, 0x5, false);
+        return __hiloint2double(a1, a0) + __hiloint2double(b1, b0);
+    } else {
+        constexpr int ctrl = DIST == 1 ? 0xB1 : 0x4E;  // quad_perm [1,0,3,2] / [2,3,0,1]
+        const double give = bit ? lo : hi, keep = bit ? hi : lo;
+        const int g0 = __builtin_amdgcn_mov_dpp(__double2loint(give), ctrl, 0xf, 0xf, true);
+        const int g1 = __builtin_amdgcn_mov_dpp(__double2hiint(give), ctrl, 0xf, 0xf, true);
+        return keep + __hiloint2double(g1, g0);
+    }
+}
+
+// halving level 1..5 works at lane distance 16, 8, 4, 2, 1: the widest level (46 pairs) gets the cheapest exchange
+__host__ __device__ constexpr int level_dist(int level) { return 32 >> level; }
+
+__host__ __device__ constexpr int halved(int n, int steps) { return steps == 0 ? n : halved((n + 1) / 2, steps - 1); }
+
+// entry index of the row-major upper triangle -> (row, column)
+template <int W>
+__host__ __device__ constexpr int tri_row(int e)
+{
+    int r = 0;
+    while (e >= W - r) {
+        e -= W - r;
+        r++;
+    }
+    return r;
+}
+template <int W>
+__host__ __device__ constexpr int tri_col(int e)
+{
+    int r = 0;
+    while (e >= W - r) {
+        e -= W - r;
+        r++;
+    }
+    return r + e;
+}
+
+template <int W>
+struct TriTable {
+    signed char r[W * (W + 1) / 2], c[W * (W + 1) / 2];
+    constexpr TriTable() : r(), c()
+    {
+        for (int e = 0; e < W * (W + 1) / 2; e++) {
+            r[e] = (signed char)tri_row<W>(e);
+            c[e] = (signed char)tri_col<W>(e);
+        }
+    }
+};
+template <int W>
+__device__ constexpr TriTable<W> kTriTable{};
+
+// The rows of the CH corners a lane owns in one chunk, and the lane's side of every halving step.
+template <int MODEL, int L, int CH>
+struct ValuRows {
+    static constexpr int K = CameraTraits<MODEL>::K, W = K + 6 * L + 1, E = W * (W + 1) / 2;
+    double rw[CH][2][W];  // [corner][u / v][column]; structurally zero columns are never read
+    bool bit[5];          // lane bit of halving level 1..5 (distance 16, 8, 4, 2, 1)
+
+    static __host__ __device__ constexpr bool nz(int half, int col) { return col >= K || intr_nonzero<MODEL>(half, col); }
+
+    // entry IDX of the lane's own Gram sum over its CH corners: products of structurally non-zero columns only
+    template <int IDX>
+    __device__ __forceinline__ double entry() const
+    {
+#pragma clang fp contract(fast)
+        constexpr int r = tri_row<W>(IDX), c = tri_col<W>(IDX);
+        double s = 0.;
+        bool first = true;  // folded at compile time: the first product is a plain multiplication, not 0 + a * b
+#pragma unroll
+        for (int j = 0; j < CH; j++)
+#pragma unroll
+            for (int half = 0; half < 2; half++)
+                if (nz(half, r) && nz(half, c)) {
+                    s = first ? rw[j][half][r] * rw[j][half][c] : s + rw[j][half][r] * rw[j][half][c];
+                    first = false;
+                }
+        return s;
+    }
+
+    // Recursive halving, evaluated depth first: element IDX of level LEVEL is the lane's kept one of the level below's
+    // elements IDX and IDX + N(LEVEL) plus the partner's copy of the same -- lanes with the level's bit clear keep the
+    // lower half, lanes with it set the upper half (zero padded).  Only the few values of the last level and the rows stay
+    // live; the 91-entry triangle never exists in registers at once.
+    template <int LEVEL, int IDX>
+    __device__ __forceinline__ double tree() const
+    {
+        if constexpr (LEVEL == 0) {
+            if constexpr (IDX < E) return entry<IDX>();
+            else return 0.;
+        } else {
+            constexpr int n_prev = halved(E, LEVEL - 1), n_cur = halved(E, LEVEL);
+            const double lo = tree<LEVEL - 1, IDX>();
+            double hi = 0.;
+            if constexpr (IDX + n_cur < n_prev) hi = tree<LEVEL - 1, IDX + n_cur>();
+            return halve_pair<level_dist(LEVEL)>(lo, hi, bit[LEVEL - 1]);
+        }
+    }
+};
+
+template <class Rows, int N, int... I>
+__device__ __forceinline__ void valu_tree_all(const Rows &R, double (&t)[N], std::integer_sequence<int, I...>)
+{
+    ((t[I] = R.template tree<5, I>()), ...);
+}
+
+// CH = corners per lane and chunk: 3 covers an 8 x 12 board in one chunk (one pass of the halving tree per image);
+// boards of at most 32 points use CH = 1.
+template <int MODEL, int L, bool INLINE, int CH>
+__global__ __launch_bounds__(kValuThreads, 2) void vg_gram_valu_kernel(GramValuArgs a)
+{
+    static_assert(L == 0 || L == 1, "narrow row blocks only");
+    using Rows = ValuRows<MODEL, L, CH>;
+    constexpr int K = Rows::K, W = Rows::W, E = Rows::E, FS = frame_stride(L);
+    static_assert(W <= kValuMaxW, "the upper triangle must fit the register file");
+    constexpr int kOut = halved(E, 5);
+    using d2 = HIP_vector_type<double, 2>;
+    __shared__ __attribute__((aligned(16))) double lds[kValuImagesPerBlock * FS + (kValuThreads / kWave) * E];
+    double *fr_lds = lds, *red = lds + kValuImagesPerBlock * FS;
+
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+    const int sl = lane & (kValuLanesPerImage - 1);
+    const unsigned int b0 = blockIdx.x * kValuImagesPerBlock;
+    const unsigned int b = b0 + (unsigned)(tid / kValuLanesPerImage);
+    const bool bvalid = b < a.g.n_blocks;
+
+    // the first chunk's board points and observations are requested BEFORE the chain walk, so their HBM latency
+    // overlaps it (a wave has one chunk per image on an 8 x 12 board: nothing else could hide that latency)
+    double gb[CH][3];
+    d2 ob[CH];
+    bool ragged[CH];
+    auto load_chunk = [&](unsigned int c0) {
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+            const unsigned int c = c0 + sl + kValuLanesPerImage * j;
+            ragged[j] = !(bvalid && c < a.g.N);
+            const unsigned int cc = c < a.g.N ? c : a.g.N - 1;
+            const unsigned int bb = bvalid ? b : b0;
+            gb[j][0] = a.g.board[3 * cc];
+            gb[j][1] = a.g.board[3 * cc + 1];
+            gb[j][2] = a.g.board[3 * cc + 2];
+            ob[j] = reinterpret_cast<const d2 *>(a.g.obs)[(size_t)bb * a.g.N + cc];
+        }
+    };
+    load_chunk(0);
+
+    // every half-wave derives / fetches the frame of ITS image: no workgroup barrier in front of the arithmetic, the
+    // waves of a workgroup drift apart and cover each other's latencies (with one walker per workgroup three waves
+    // sat at the barrier for the whole dependent chain: 42 % of all wave cycles were waits)
+    double *fr_mine = fr_lds + (tid / kValuLanesPerImage) * FS;
+    if (INLINE) {
+        if (sl == 0 && bvalid) {
+            const long long si = a.seq_index ? (long long)a.seq_index[b] : (long long)b;
+            build_frame_single_direct_fast(a.chain_params + a.chain_stride * si, fr_mine);
+        }
+    } else if (bvalid) {
+        const double *src = a.g.frames + (size_t)b * FS;
+        for (int i = sl; i < FS; i += kValuLanesPerImage) fr_mine[i] = src[i];
+    }
+    wave_lds_fence();
+    const double *fr = fr_mine;
+
+    Rows R;
+#pragma unroll
+    for (int s = 0; s < 5; s++) R.bit[s] = (sl >> (4 - s)) & 1;
+    double out[kOut];
+#pragma unroll
+    for (int k = 0; k < kOut; k++) out[k] = 0.;
+
+    for (unsigned int c0 = 0;;) {
+        // ---- phase 1: the CH corners of this lane, independent of each other (the compiler interleaves their
+        // sqrt / reciprocal chains); no accumulator is live yet
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+            const double g0 = gb[j][0], g1 = gb[j][1], g2 = gb[j][2];
+            const double X0 = (fr[0] * g0 + fr[1] * g1 + fr[2] * g2) + fr[9];
+            const double X1 = (fr[3] * g0 + fr[4] * g1 + fr[5] * g2) + fr[10];
+            const double X2 = (fr[6] * g0 + fr[7] * g1 + fr[8] * g2) + fr[11];
+            CornerEval<K> e;
+            eval_corner_fast<MODEL>(a.g.intr, X0, X1, X2, e);
+#pragma unroll
+            for (int i = 0; i < K; i++) {
+                R.rw[j][0][i] = e.Ju[i];
+                R.rw[j][1][i] = e.Jv[i];
+            }
+            if constexpr (L == 1) {
+                double rows[12];
+                pose_rows_fast(e.P, X0, X1, X2, fr + 12, rows);
+#pragma unroll
+                for (int q = 0; q < 6; q++) {
+                    R.rw[j][0][K + q] = rows[q];
+                    R.rw[j][1][K + q] = rows[6 + q];
+                }
+            }
+            // residual column; a failed projection contributes the in-band 1e15 (calib_cost_functions.cpp:66-70)
+            R.rw[j][0][W - 1] = e.ok ? e.u - ob[j].x : kDoubleBig;
+            R.rw[j][1][W - 1] = e.ok ? e.v - ob[j].y : kDoubleBig;
+        }
+        bool any_ragged = false;
+#pragma unroll
+        for (int j = 0; j < CH; j++) any_ragged |= ragged[j];
+        if (__builtin_amdgcn_ballot_w64(any_ragged)) {  // ragged last chunk / missing image: a scalar branch no wave takes on full boards
+            // the zero comes out of an asm statement so that the selects below cannot be speculated out of this block
+            // (the compiler otherwise turns it into 2 W CH v_cndmask on the hot path)
+            double zero = 0.;
+            asm volatile("; ragged chunk" : "+v"(zero));
+#pragma unroll
+            for (int j = 0; j < CH; j++)
+#pragma unroll
+                for (int i = 0; i < W; i++) {
+                    R.rw[j][0][i] = ragged[j] ? zero : R.rw[j][0][i];
+                    R.rw[j][1][i] = ragged[j] ? zero : R.rw[j][1][i];
+                }
+        }
+        // ---- phase 2: products and the sum over the 32 lanes of the image in one depth-first pass
+        {
+            double t[kOut];
+            valu_tree_all(R, t, std::make_integer_sequence<int, kOut>{});
+#pragma unroll
+            for (int k = 0; k < kOut; k++) out[k] += t[k];
+        }
+        c0 += kValuLanesPerImage * CH;
+        if (c0 >= a.g.N) break;
+        load_chunk(c0);
+    }
+
+    // which entries this lane ended up with: [base, base + real)
+    int base = 0, real = E;
+    {
+        int n = E;
+#pragma unroll
+        for (int s = 0; s < 5; s++) {
+            const int H = (n + 1) / 2;
+            const bool bit = (sl >> (4 - s)) & 1;
+            base += bit ? H : 0;
+            real = bit ? (real - H > 0 ? real - H : 0) : (real < H ? real : H);
+            n = H;
+        }
+    }
+    double *G = a.g.gram + (size_t)(bvalid ? b : 0) * (W * W);
+#pragma unroll
+    for (int k = 0; k < kOut; k++) {
+        const int e = base + k;
+        const bool have = k < real;
+        const int r = kTriTable<W>.r[have ? e : 0], cc = kTriTable<W>.c[have ? e : 0];
+        if (have && bvalid) {
+            G[r * W + cc] = out[k];
+            G[cc * W + r] = out[k];
+        }
+        if (a.partials) {  // both images of the wave: the other half-wave holds the same entry of its image
+            const double tot = out[k] + __shfl_xor(out[k], 32, kWave);
+            if (have && lane < kValuLanesPerImage) red[wave * E + e] = tot;
+        }
+    }
+    if (a.partials) {
+        __syncthreads();
+        if (tid < E) {
+            double s = red[tid];
+#pragma unroll
+            for (int w = 1; w < kValuThreads / kWave; w++) s += red[w * E + tid];  // fixed order
+            a.partials[(size_t)tid * a.n_wg + blockIdx.x] = s;
+        }
+    }
+}
+
+// final sum over the workgroup partials [E][n_wg] -> full symmetric W x W.  One WORKGROUP per entry: every lane's loads
+// (contiguous, up to 8 per lane) are in flight together, so 1 250 partials cost one memory round trip; fixed order.
+__global__ __launch_bounds__(256) void vg_gram_partials_sum_kernel(const double *__restrict__ partials, unsigned int n_wg,
+                                                                    int W, double *__restrict__ out)
+{
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+    const int e = blockIdx.x;
+    const double *src = partials + (size_t)e * n_wg;
+    double s = 0.;
+    for (unsigned int i0 = 0; i0 < n_wg; i0 += 8 * 256) {
+        double v[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const unsigned int i = i0 + q * 256 + tid;
+            v[q] = i < n_wg ? src[i] : 0.;
+        }
+        s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, kWave);
+    __shared__ double red[4];
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    if (tid == 0) {
+        const double t = (red[0] + red[1]) + (red[2] + red[3]);
+        int r = 0, rem = e;
+        while (rem >= W - r) {
+            rem -= W - r;
+            r++;
+        }
+        const int c = r + rem;
+        out[r * W + c] = t;
+        out[c * W + r] = t;
+    }
+}
+
+}  // namespace vg

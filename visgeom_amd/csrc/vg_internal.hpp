@@ -54,6 +54,7 @@ struct Dataset {
     double *d_out_res = nullptr, *d_out_ji = nullptr;  // device staging of vg_dataset_evaluate_to_host
     double *d_out_jm[vg::kMaxChain] = {nullptr};
     double *d_partials = nullptr;  // [ceil(n_blocks / kSlab)][W*W] workspace of vg_dataset_gram_sum
+    double *d_wg_partials = nullptr;  // [W(W+1)/2][n_workgroups] per-workgroup sums of the vector-pipe Gram kernel
     unsigned long long epoch = 0;  // evaluation counter, tags d_failed
     int frame_stride = 0;
     vg::ChainDesc chain;
@@ -106,6 +107,8 @@ namespace vgi {
 // touching the problem's own parameter vector); implemented in vg_capi.hip
 int prepare_at(vg_problem *p, const double *d_params);
 int ensure_frames(vg_problem *p);  // chain prep at the problem's own parameters if the frames are stale
-int gram_fused_at(vg_problem *p, int dataset_id, const double *d_params, double *gram);
+// sum != NULL: also the fixed-order sum over the dataset's blocks, [W*W] (one extra launch on the vector-pipe route)
+int gram_fused_at(vg_problem *p, int dataset_id, const double *d_params, double *gram, double *sum);
+bool gram_needs_frames(const vg_problem *p);  // false when every dataset's Gram kernel walks its chain itself
 int gram_sum_into(vg_problem *p, int dataset_id, const double *gram, double *sum);
 }  // namespace vgi

@@ -611,9 +611,9 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
                         double &cost2) -> int {
         const double t0 = now_s();
         int r;
-        if ((r = vgi::prepare_at(p, x_dev)) != VG_OK) return r;
+        if (vgi::gram_needs_frames(p) && (r = vgi::prepare_at(p, x_dev)) != VG_OK) return r;
         for (int d = 0; d < n_ds; d++) {
-            if ((r = vgi::gram_fused_at(p, d, x_dev, set[d].p)) != VG_OK) return r;
+            if ((r = vgi::gram_fused_at(p, d, x_dev, set[d].p, nullptr)) != VG_OK) return r;
             if (opt.soft_l1_scale > 0. && p->dss[d].n_blocks) {
                 // robustified blocks: J'^T J' = rho' J^T J, J'^T r' = rho' J^T r, cost term rho(s)   (Ceres' Corrector
                 // with rho'' < 0, always the case for SoftLOne) -- re-weight the Gram blocks in place, nothing
@@ -988,6 +988,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
     }
     VG_HIP(hipMemcpyAsync(p->d_params, d_x.p, sizeof(double) * (size_t)n_params, hipMemcpyDeviceToDevice, st));
     VG_HIP(hipStreamSynchronize(st));
+    p->frames_stale = true;  // whatever frames are in HBM belong to some candidate point, not to the solution
     if (sum) {
         std::memset(sum, 0, sizeof *sum);
         sum->initial_cost = initial_cost;

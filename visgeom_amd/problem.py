@@ -235,6 +235,11 @@ class CalibrationProblem:
         """per-image Gram of [J | r], J never materialised (needs prepare() at the current parameters)."""
         capi.check(self._lib.vg_dataset_gram_fused(self._h, d, ctypes.c_void_p(gram.data_ptr())))
 
+    def gram_fused_sum(self, d, gram, out):
+        """gram_fused + the fixed-order sum over the dataset's blocks in two launches (vg_dataset_gram_fused_sum)."""
+        capi.check(self._lib.vg_dataset_gram_fused_sum(self._h, d, ctypes.c_void_p(gram.data_ptr()),
+                                                       ctypes.c_void_p(out.data_ptr())))
+
     def gram_from_rows(self, d, res, jac_intr, jac_member, gram):
         """the same Gram matrices from the rows evaluate_dataset wrote (second pass)."""
         L = self.datasets[d]["L"]
