@@ -2,7 +2,8 @@
 """bench.py -- corner residual + Jacobian evaluations per second on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  (N > 1: one rank per GPU.  Launched bare, bench.py re-executes itself through `python -m torch.distributed.run
+   --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`; launched by torch.distributed.run it reads RANK / WORLD_SIZE.)
 
 Workload (BASELINE.json metric: "corner residual+Jacobian evals/sec ... (EUCM 10k imgs)"):
   synthetic EUCM mono, 10 000 images x 96 corners (8 x 12 board) PER GPU, chain [xiCamBoard DIRECT],
@@ -12,8 +13,10 @@ One step = one full evaluation of the hot path at the current parameters (vg_pro
   the Ceres block layout.  For this single-member DIRECT chain the emit kernel derives the per-image frames itself,
   so the step is ONE launch; multi-member chains and the Gram kernels use the separate chain-prep kernel.
 Inputs are resident in HBM before the timed region.  Multi-GPU: images are sharded over ranks
-(weak scaling, no data-path collective in this pass; the normal-equation build that needs the
-all-reduce is reported separately under "jtj").
+(weak scaling, no data-path collective in this pass).  The normal-equation build that needs the exchange step is
+reported under "jtj" (same weak-scaled set) and under "sharded_mei" (BASELINE.json config 4: Mei, 10 000 images x 96
+corners in TOTAL, split over the N ranks -- strong scaling; one iteration = fused J^T J + ONE packed in-place RCCL
+all-reduce of [H | g | cost | n_failed] on the device buffer through the native vg_comm entry).
 
 Prints ONE JSON line (rank 0).
 """
@@ -27,6 +30,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# floating-point operations of ONE evaluation of the restatement per observation, chain of one member (point transform,
+# projection, d(u,v)/dX, d(u,v)/d(intrinsics), residual, the 2 x 6 pose rows); counted in DESIGN.md section 5.3
+EVAL_FLOPS = {"eucm": 200, "ucm": 197, "mei": 346}
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
@@ -37,6 +43,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--images", type=int, default=10000, help="images per GPU")
     ap.add_argument("--model", default="eucm", choices=["eucm", "ucm", "mei"])
+    ap.add_argument("--sharded-images", type=int, default=10000, help="total images of the sharded Mei case (config 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU-baseline budget per leg")
     return ap.parse_args()
@@ -93,18 +100,33 @@ def cpu_baseline(d, model, budget_s):
             "jtj_ms_per_iter": n * N / vc * 1e3 + gram_ms, "jtj_gram_only_ms": gram_ms}
 
 
+def respawn(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, one per GPU, and pass rank 0's JSON
+    line through.  (`--gpus 1` never comes here: it runs in this process, exactly as before.)"""
+    import socket
+    import subprocess
+
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(respawn(a.gpus))
     import numpy as np
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (a.gpus, a.gpus))
-        a.gpus = world
+    a.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
     # VG_BENCH_BACKEND=gloo lets the multi-rank control flow be rehearsed with several ranks on ONE GPU
     # (RCCL refuses two ranks per device); the driver's runs use the default, nccl = RCCL over xGMI.
@@ -133,6 +155,23 @@ def main():
             t.copy_(h)
 
     from visgeom_amd import CalibrationProblem, synthetic
+
+    # the native RCCL communicator (vg_comm): the normal-equation blocks are reduced through it, on the device buffers.
+    # torch.distributed only carries the unique id and the fences; with the gloo rehearsal backend (several ranks on ONE
+    # GPU, which RCCL refuses) the blocks go through torch instead.
+    comm = None
+    if dist is not None and backend == "nccl":
+        from visgeom_amd import distributed as vdist_
+
+        comm = vdist_.make_comm(local_rank)
+        if rank == 0:
+            print("[bench] native RCCL communicator: world size %d" % comm.n_ranks, file=sys.stderr)
+
+    def sum_over_ranks_(t):
+        if comm is not None:
+            comm.allreduce_sum(t)
+        elif dist is not None:
+            all_reduce_(t)
 
     cfg_index = 1  # the metric's configuration: EUCM mono, 10 k images x 96 corners
     d = synthetic.make_mono(a.model, a.images, cfg_index, first_image=rank * a.images)
@@ -290,13 +329,14 @@ def main():
 
     def finish():
         p.gram_sum(ds, gram, gsum)
-        if dist is not None:
-            all_reduce_(gsum)
+        sum_over_ranks_(gsum)
 
     def it_fused():
+        # narrow row blocks (EUCM / UCM mono): chain walk + evaluate + Gram in ONE launch on the FP64 vector pipe, the
+        # workgroup partial sums added by ONE more launch; then the all-reduce of the W x W block
         p.prepare()
-        p.gram_fused(ds, gram)
-        finish()
+        p.gram_fused_sum(ds, gram, gsum)
+        sum_over_ranks_(gsum)
 
     def it_two_pass():
         p.prepare()
@@ -325,6 +365,8 @@ def main():
 
     W = p.gram_width(ds)
     jtj = {"unit": "ms/iter", "gram_width": W, "images_per_gpu": n_img, "allreduce": dist is not None,
+           "collective": None if dist is None else ("vg_comm_allreduce_sum (RCCL, in place on the device block)" if comm is not None
+                                                    else "torch.distributed " + backend),
            # secondary legs: best of three timed runs (a single run picked up a host hiccup once: 0.12 vs 0.05 ms);
            # the headline `value` above stays ONE timed run of exactly K steps, as the contract says
            "fused_ms_per_iter": min(wall_ms(it_fused, a.steps) for _ in range(3)),
@@ -332,6 +374,67 @@ def main():
            "second_pass_only_ms": min(wall_ms(it_second_pass_only, a.steps) for _ in range(3)),
            "fused_algorithmic_bytes_per_obs": 16 + 8.0 * W * W / N,
            "two_pass_read_bytes_per_obs": 16 + 16 * (K + 6)}
+    # roofline of the fused evaluate + Gram kernel: FP64 vector peak ("report it against the FP64 vector
+    # peak").  Algorithmic flops per observation = Gram 2 (P+1)(P+2) (two rows, upper triangle incl. diagonal, one
+    # multiply-add each; P = K + 6) + one evaluation of the restatement (EVAL_FLOPS, counted operation by operation in
+    # DESIGN.md section 5.3; divisions and square roots count 1).  Kernel time: HIP events around back-to-back launches.
+    p.prepare()
+    for _ in range(20):
+        p.gram_fused(ds, gram)
+    torch.cuda.synchronize()
+    g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    g0.record(stream)
+    for _ in range(a.steps):
+        p.gram_fused(ds, gram)
+    g1.record(stream)
+    torch.cuda.synchronize()
+    gram_ms = g0.elapsed_time(g1) / a.steps
+    flops_per_obs = 2 * (K + 7) * (K + 8) + EVAL_FLOPS[a.model]
+    FP64_PEAK = 78.6  # TFLOP/s, MI355X FP64 vector = FP64 matrix
+    ach = flops_per_obs * n_obs / (gram_ms * 1e-3) / 1e12
+    jtj["roofline"] = {"bound": "fp64", "kernel": "fused evaluate + Gram (vg_dataset_gram_fused)", "flops_per_obs": flops_per_obs,
+                       "gram_flops_per_obs": 2 * (K + 7) * (K + 8), "eval_flops_per_obs": EVAL_FLOPS[a.model],
+                       "avg_launch_ms": gram_ms, "achieved": ach, "peak": FP64_PEAK, "unit": "TFLOP/s",
+                       "frac": ach / FP64_PEAK}
+
+    # ---- BASELINE.json config 4, the north-star multi-GPU case: Mei (K = 10), 10 000 images x 96 corners IN TOTAL,
+    # images sharded over the ranks (strong scaling).  One LM-style iteration = chain prep + fused evaluate + Gram of
+    # this rank's images + fixed-order sum + ONE packed all-reduce of [H (W x W, holds J^T J, J^T r and the cost) |
+    # n_failed] on the device buffer.  Time = max over ranks between fences.
+    sharded = None
+    try:
+        from visgeom_amd import distributed as vdist
+
+        n_total = a.sharded_images
+        lo, hi = vdist.shard_range(n_total, rank, world)
+        dm = synthetic.make_mono("mei", hi - lo, 4, first_image=lo)
+        pm = CalibrationProblem(local_rank)
+        cm = pm.add_camera("mei", dm["init_intrinsics"])
+        sm = pm.add_transform(False, dm["init_poses"])
+        dsm = pm.add_dataset(cm, [(sm, 0)], dm["board"], dm["corners"])
+        pm.finalize()
+        gm, _ = pm.alloc_gram(dsm)
+        Wm = pm.gram_width(dsm)
+        pack = torch.zeros(Wm * Wm + 1, dtype=torch.float64, device="cuda")  # [H | n_failed]
+
+        def it_sharded():
+            pm.prepare()
+            pm.gram_fused_sum(dsm, gm, pack)           # writes the first W*W doubles
+            pack[Wm * Wm:].copy_(torch.floor(pack[Wm * Wm - 1:Wm * Wm] / 2e30 + 0.5))  # failed corners: 2e30 of r^T r each
+            sum_over_ranks_(pack)
+
+        ms = min(wall_ms(it_sharded, a.steps) for _ in range(3))
+        sharded = {"workload": "Mei mono, %d images x %d corners in total, images sharded over %d rank(s)" % (n_total, N, world),
+                   "scaling": "strong", "images_total": n_total, "images_this_rank": hi - lo, "n_ranks": world,
+                   "rccl_world_size": comm.n_ranks if comm is not None else None,
+                   "collective": "none (one rank)" if dist is None else
+                                 ("one vg_comm_allreduce_sum per iteration, %d doubles, in place on the device buffer" % pack.numel()
+                                  if comm is not None else "torch.distributed " + backend),
+                   "ms_per_iter": ms, "evals_per_s": n_total * N / (ms * 1e-3), "gram_width": Wm,
+                   "cost": float(pack[Wm * Wm - 1].item()) * 0.5, "n_failed": float(pack[Wm * Wm].item())}
+        pm.close()
+    except Exception as e:  # never take the headline down
+        sharded = {"error": repr(e)}
 
     # ---- full LM loop on the same set (GPU Gram + Schur, host Cholesky of the 6 x 6 reduced system); with N > 1
     # the images stay sharded and every iteration sums the small normal-equation blocks over ranks (RCCL) ----
@@ -345,7 +448,8 @@ def main():
         ps.add_dataset(cs, [(ss, 0)], d["board"], d["corners"])
         ps.finalize()
         fence()
-        summ = ps.solve(allreduce=vdist.make_allreduce() if dist is not None else None, max_num_iterations=50)
+        summ = ps.solve(comm=comm, allreduce=vdist.make_allreduce() if (dist is not None and comm is None) else None,
+                        max_num_iterations=50)
         fence()
         xs = ps.get_parameters()
         solve = {"iterations": summ["num_iterations"], "successful_steps": summ["num_successful_steps"],
@@ -381,6 +485,7 @@ def main():
                    "seed": int(d["seed"]), "sharding": "images sharded over ranks, no data-path collective"},
         "roofline": roofline,
         "jtj": jtj,
+        "sharded_mei": sharded,
         "solve": solve,
         "pcie_inclusive": pcie,
     }
@@ -388,6 +493,8 @@ def main():
         out["cpu_baseline"] = cpu_baseline(d, a.model, a.cpu_seconds)
         out["gpu_over_cpu_allcores"] = value / out["cpu_baseline"]["value"]
     p.close()
+    if comm is not None:
+        comm.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

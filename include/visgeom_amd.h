@@ -219,7 +219,27 @@ int vg_dataset_gram_sum(vg_problem *p, int dataset_id, const double *gram, doubl
  *    (:604-617); non-constant intrinsics are kept inside the camera's box bounds (:621-627).
  *    The result is written to the problem's parameter vector.
  * ===================================================================================== */
-/* Sums host_buf[0..n) over all ranks in place (every rank must end with the same values).  NULL = one GPU. */
+/* ---- multi-GPU: one process per GPU, images sharded over ranks (contiguous image ranges, both cameras of a frame on
+ * the same rank), global parameters replicated.  The path has ONE exchange step -- the sum of the small normal-equation
+ * blocks -- done by RCCL on DEVICE buffers, in place, on the problem's stream.  Not in the reference (single process,
+ * SURVEY section 5); it serves the replacement of ceres::Solve at src/calibration/unified_calibration.cpp:53.
+ * RCCL is bound at run time: nothing here is needed, or loaded, on one GPU. */
+typedef struct vg_comm vg_comm;
+#define VG_COMM_ID_BYTES 128
+/* ncclGetUniqueId: rank 0 calls it, the host hands the bytes to every rank (MPI, torch.distributed, a file ...) */
+int vg_comm_unique_id(char *id /* VG_COMM_ID_BYTES */);
+/* ncclCommInitRank on `device`; collective over all n_ranks ranks */
+int vg_comm_create(vg_comm **out, const char *id, int n_ranks, int rank, int device);
+/* wrap an ncclComm_t the host application already owns (not destroyed by vg_comm_destroy) */
+int vg_comm_adopt(vg_comm **out, void *nccl_comm, int device);
+int vg_comm_size(const vg_comm *c);
+int vg_comm_rank(const vg_comm *c);
+/* in-place sum of n doubles at device_buf over all ranks (ncclAllReduce, ncclDouble, ncclSum), enqueued on hip_stream */
+int vg_comm_allreduce_sum(vg_comm *c, double *device_buf, int64_t n, void *hip_stream);
+void vg_comm_destroy(vg_comm *c);
+
+/* Host-staged alternative (tests on CPU-only boxes, non-RCCL transports): sums host_buf[0..n) over all ranks in place
+ * (every rank must end with the same values).  NULL = one GPU. */
 typedef int (*vg_allreduce_fn)(double *host_buf, int64_t n, void *user);
 
 typedef struct vg_solve_options {
@@ -239,8 +259,12 @@ typedef struct vg_solve_options {
                                            ceres::SoftLOneLoss(a) on every grid residual block, rho(s) =
                                            2 a^2 (sqrt(1 + s / a^2) - 1) of the block's squared norm s -- what the two
                                            initial refinements use (a = 25 :1143, a = 1 :379-401) */
-    vg_allreduce_fn allreduce;          /* multi-GPU: images sharded over ranks, global parameters replicated */
+    vg_allreduce_fn allreduce;          /* multi-GPU through host buffers (three calls per iteration) */
     void *allreduce_user;
+    vg_comm *comm;                      /* multi-GPU through RCCL: one in-place all-reduce of the device buffer
+                                           [summed normal-equation blocks | step scalars] per evaluation and one of the
+                                           reduced (Schur) system per linear solve, on the problem's stream.  NULL or a
+                                           one-rank communicator = one GPU.  Exclusive with `allreduce`. */
 } vg_solve_options;
 
 enum vg_termination {

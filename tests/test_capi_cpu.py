@@ -4,6 +4,7 @@ import ctypes
 import os
 import re
 import subprocess
+import sys
 
 import pytest
 
@@ -182,3 +183,51 @@ def test_odometry_prior_host_block_matches_oracle(lib):
         assert lib.vg_odometry_prior_evaluate(errV, errW, lam, P(o1), P(o2), P(x1), P(x2), P(r2), None, None) == 0
         assert np.array_equal(r, r2)
     assert lib.vg_odometry_prior_evaluate(0.1, 0.1, 0.0, P(o1), P(o2), P(x1), P(x2), P(r), None, None) != 0
+
+
+def test_comm_entries_without_a_gpu():
+    """the RCCL binding is resolved at run time: the id can be drawn on a CPU-only box when librccl is installed (or
+    fails cleanly when it is not); argument errors never reach RCCL"""
+    import ctypes
+
+    from visgeom_amd import capi
+
+    L = capi.load()
+    buf = ctypes.create_string_buffer(128)
+    rc = L.vg_comm_unique_id(buf)
+    assert rc in (capi.OK, capi.ERR_STATE, capi.ERR_HIP), L.vg_last_error()
+    assert L.vg_comm_unique_id(None) == capi.ERR_INVALID_ARGUMENT
+    h = ctypes.c_void_p()
+    assert L.vg_comm_create(ctypes.byref(h), buf.raw, 2, 2, 0) == capi.ERR_INVALID_ARGUMENT
+    assert L.vg_comm_create(ctypes.byref(h), buf.raw, 0, 0, 0) == capi.ERR_INVALID_ARGUMENT
+    assert L.vg_comm_size(None) == -1 and L.vg_comm_rank(None) == -1
+    assert L.vg_comm_allreduce_sum(None, None, 4, None) == capi.ERR_INVALID_ARGUMENT
+    L.vg_comm_destroy(None)
+
+
+def test_bench_starts_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus N` must not need a launcher: it re-executes itself under torch.distributed.run with one
+    rank per GPU on 127.0.0.1"""
+    import importlib.util
+    import subprocess
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7"])
+    monkeypatch.delenv("RANK", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "7"] and cmd[-5].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

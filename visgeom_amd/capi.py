@@ -35,7 +35,7 @@ class SolveOptions(ctypes.Structure):
                 ("min_trust_region_radius", ctypes.c_double), ("min_relative_decrease", ctypes.c_double),
                 ("min_lm_diagonal", ctypes.c_double), ("max_lm_diagonal", ctypes.c_double),
                 ("use_bounds", ctypes.c_int), ("verbose", ctypes.c_int), ("soft_l1_scale", ctypes.c_double),
-                ("allreduce", ALLREDUCE_FN), ("allreduce_user", ctypes.c_void_p)]
+                ("allreduce", ALLREDUCE_FN), ("allreduce_user", ctypes.c_void_p), ("comm", ctypes.c_void_p)]
 
 
 class SolveSummary(ctypes.Structure):
@@ -100,6 +100,13 @@ SIGNATURES = {
     "vg_dataset_gram_fused_sum": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp]),
     "vg_dataset_gram_from_rows": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vpp, _vp]),
     "vg_dataset_gram_sum": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp]),
+    "vg_comm_unique_id": (ctypes.c_int, [ctypes.c_char_p]),
+    "vg_comm_create": (ctypes.c_int, [_vpp, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "vg_comm_adopt": (ctypes.c_int, [_vpp, _vp, ctypes.c_int]),
+    "vg_comm_size": (ctypes.c_int, [_vp]),
+    "vg_comm_rank": (ctypes.c_int, [_vp]),
+    "vg_comm_allreduce_sum": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, _vp]),
+    "vg_comm_destroy": (None, [_vp]),
     "vg_solve_options_init": (None, [ctypes.POINTER(SolveOptions)]),
     "vg_problem_solve": (ctypes.c_int, [_vp, ctypes.POINTER(SolveOptions), ctypes.POINTER(SolveSummary)]),
     "vg_host_cholesky_solve": (ctypes.c_int, [ctypes.c_int, _dp, _dp, _dp]),

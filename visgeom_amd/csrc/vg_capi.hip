@@ -982,5 +982,6 @@ int vg_calib_stream_copy(void *hip_stream, double *dst, const double *src, int64
 
 }  // extern "C"
 
+#include "vg_comm.hpp"
 #include "vg_solver_impl.hpp"
 #include "vg_calibration.hpp"

@@ -356,6 +356,7 @@ void vg_solve_options_init(vg_solve_options *o)
     o->soft_l1_scale = 0.;
     o->allreduce = nullptr;
     o->allreduce_user = nullptr;
+    o->comm = nullptr;
 }
 
 int vg_host_cholesky_solve(int n, const double *A, const double *b, double *x)
@@ -461,7 +462,11 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
         c2.x.resize((size_t)c2.n * 6);
         c2.xc.resize((size_t)c2.n * 6);
     }
-    if (!coupled.empty() && opt.allreduce)
+    const vg_comm *comm = opt.comm;
+    const bool multi_rank = opt.allreduce != nullptr || (comm && comm->n_ranks > 1);
+    if (opt.allreduce && comm && comm->n_ranks > 1)
+        return fail(VG_ERR_INVALID_ARGUMENT, "give either an RCCL communicator or a host all-reduce callback, not both");
+    if (!coupled.empty() && multi_rank)
         return fail(VG_ERR_INVALID_ARGUMENT, "OdometryPrior blocks and priors on sequence elements are not supported together with a multi-rank all-reduce");
 
     // per dataset: local -> global column map, pose column offset, pose references
@@ -544,7 +549,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
     VG_TRY(d_gcol_param.upload(gcol_param));
     VG_TRY(d_lo.upload(lo));
     VG_TRY(d_hi.upload(hi));
-    VG_TRY(d_sums.alloc((size_t)n_ds * Wmax * Wmax));
+    VG_TRY(d_sums.alloc((size_t)n_ds * Wmax * Wmax + 5));
     VG_TRY(d_x.alloc((size_t)n_params));
     VG_TRY(d_xc.alloc((size_t)n_params));
     VG_TRY(d_delta.alloc((size_t)n_params));
@@ -555,26 +560,30 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
     VG_TRY(d_rgram.alloc((size_t)C * C));
     VG_TRY(d_dg.alloc((size_t)(G ? G : 1)));
     const unsigned int n_bs_groups = (unsigned int)((n_poses + vg::kBsPosesPerBlock - 1) / vg::kBsPosesPerBlock);
-    // [scalar sums 5 | max |g_pose| (bit pattern) 1 | current global values G]: one allocation, one D2H per iteration
+    // d_sums = [per-dataset summed Gram blocks (n_ds x Wmax^2) | scalar sums of the step (5)]: everything that is SUMMED
+    // over ranks, contiguous, so that one evaluation ends with ONE in-place RCCL all-reduce of this buffer on the
+    // problem's stream and one D2H.  d_small = [max |g_pose| (bit pattern) 1 | current global values G].
+    const size_t n_sums = (size_t)n_ds * Wmax * Wmax, n_pack = n_sums + 5;
     DevBuf<double> d_small;
     struct { double *p; } d_scal_sum{nullptr}, d_xg{nullptr};
     struct { unsigned long long *p; } d_gmax{nullptr};
     VG_TRY(d_scal.alloc((size_t)n_bs_groups * 5));
-    VG_TRY(d_small.alloc((size_t)6 + (size_t)(G ? G : 1)));
-    VG_HIP(hipMemsetAsync(d_small.p, 0, sizeof(double) * (6 + (size_t)(G ? G : 1)), st));
-    d_scal_sum.p = d_small.p;
-    d_gmax.p = reinterpret_cast<unsigned long long *>(d_small.p + 5);
-    d_xg.p = d_small.p + 6;
+    VG_TRY(d_small.alloc((size_t)1 + (size_t)(G ? G : 1)));
+    VG_HIP(hipMemsetAsync(d_small.p, 0, sizeof(double) * (1 + (size_t)(G ? G : 1)), st));
+    VG_HIP(hipMemsetAsync(d_sums.p, 0, sizeof(double) * n_pack, st));
+    d_scal_sum.p = d_sums.p + n_sums;
+    d_gmax.p = reinterpret_cast<unsigned long long *>(d_small.p);
+    d_xg.p = d_small.p + 1;
     VG_TRY(d_bad.alloc(1));
     VG_HIP(hipMemsetAsync(d_delta.p, 0, sizeof(double) * (size_t)(n_params ? n_params : 1), st));
     VG_HIP(hipMemcpyAsync(d_x.p, p->d_params, sizeof(double) * (size_t)n_params, hipMemcpyDeviceToDevice, st));
 
-    std::vector<double> h_sums((size_t)n_ds * Wmax * Wmax), h_rgram((size_t)C * C);
+    std::vector<double> h_sums((size_t)n_ds * Wmax * Wmax + 5), h_rgram((size_t)C * C);
     std::vector<double> U((size_t)G * G), gg(G), Uc((size_t)G * G), ggc(G), S((size_t)G * G), rhs(G), dg(G), h_xg(G);
-    PinnedBuf pin_sums, pin_rgram, pin_small;  // pin_small: [dg (G) | scalars (5) | gmax (1) | xg (G)]
+    PinnedBuf pin_sums, pin_rgram, pin_small;  // pin_small: [dg (G) | gmax (1) | xg (G)]
     VG_TRY(pin_sums.alloc(h_sums.size()));
     VG_TRY(pin_rgram.alloc(h_rgram.size()));
-    VG_TRY(pin_small.alloc((size_t)2 * G + 8));
+    VG_TRY(pin_small.alloc((size_t)2 * G + 2));
 
     // several datasets: their fixed-order sums run as ONE slab launch and ONE final launch (descriptor tables for
     // the two alternating Gram sets); a single dataset keeps the plain kernels
@@ -602,7 +611,6 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             sd.gram = gramB[d].p;
             tb.push_back(sd);
         }
-        VG_HIP(hipMemsetAsync(d_sums.p, 0, sizeof(double) * (size_t)n_ds * Wmax * Wmax, st));
         VG_TRY(d_sumA.upload(ta));
         VG_TRY(d_sumB.upload(tb));
     }
@@ -613,8 +621,12 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
         int r;
         if (vgi::gram_needs_frames(p) && (r = vgi::prepare_at(p, x_dev)) != VG_OK) return r;
         for (int d = 0; d < n_ds; d++) {
-            if ((r = vgi::gram_fused_at(p, d, x_dev, set[d].p, nullptr)) != VG_OK) return r;
-            if (opt.soft_l1_scale > 0. && p->dss[d].n_blocks) {
+            double *sum_d = d_sums.p + (size_t)d * Wmax * Wmax;
+            const bool robust = opt.soft_l1_scale > 0. && p->dss[d].n_blocks;
+            // single dataset, no loss function: Gram blocks and their sum in two launches
+            const bool fused_sum = !sum_slab_blocks && !robust;
+            if ((r = vgi::gram_fused_at(p, d, x_dev, set[d].p, fused_sum ? sum_d : nullptr)) != VG_OK) return r;
+            if (robust) {
                 // robustified blocks: J'^T J' = rho' J^T J, J'^T r' = rho' J^T r, cost term rho(s)   (Ceres' Corrector
                 // with rho'' < 0, always the case for SoftLOne) -- re-weight the Gram blocks in place, nothing
                 // downstream changes
@@ -622,7 +634,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
                                    Wd[d] * Wd[d], opt.soft_l1_scale * opt.soft_l1_scale);
                 VG_HIP(hipGetLastError());
             }
-            if (!sum_slab_blocks && (r = vgi::gram_sum_into(p, d, set[d].p, d_sums.p + (size_t)d * Wmax * Wmax)) != VG_OK) return r;
+            if (!sum_slab_blocks && !fused_sum && (r = vgi::gram_sum_into(p, d, set[d].p, sum_d)) != VG_OK) return r;
         }
         if (sum_slab_blocks) {
             const vg::SumDataset *tab = set == gramA ? d_sumA.p : d_sumB.p;
@@ -633,6 +645,8 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             hipLaunchKernelGGL(vg::vg_gram_final_sum_multi_kernel, dim3(sum_final_blocks), dim3(256), 0, st, tab, n_tab);
             VG_HIP(hipGetLastError());
         }
+        // the ONE collective of an evaluation: [summed Gram blocks | scalar sums of the step], device buffer, in place
+        if ((r = vgc::allreduce_sum(comm, d_sums.p, n_pack, st)) != VG_OK) return r;
         VG_HIP(hipMemcpyAsync(pin_sums.p, d_sums.p, sizeof(double) * h_sums.size(), hipMemcpyDeviceToHost, st));
         VG_HIP(hipStreamSynchronize(st));
         std::memcpy(h_sums.data(), pin_sums.p, sizeof(double) * h_sums.size());
@@ -766,6 +780,11 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             hipLaunchKernelGGL(vg::vg_gram_final_sum_kernel, dim3((C * C + 3) / 4), dim3(256), 0, st,
                                (const double *)d_rslabs.p, n_slabs, C * C, d_rgram.p);
             VG_HIP(hipGetLastError());
+        } else if (comm && comm->n_ranks > 1) {
+            VG_HIP(hipMemsetAsync(d_rgram.p, 0, sizeof(double) * h_rgram.size(), st));  // a rank without poses still joins the sum
+        }
+        if (n_poses || (comm && comm->n_ranks > 1)) {
+            VG_TRY(vgc::allreduce_sum(comm, d_rgram.p, h_rgram.size(), st));  // Schur complement of the poses of all ranks
             VG_HIP(hipMemcpyAsync(pin_rgram.p, d_rgram.p, sizeof(double) * h_rgram.size(), hipMemcpyDeviceToHost, st));
             VG_HIP(hipStreamSynchronize(st));
             std::memcpy(h_rgram.data(), pin_rgram.p, sizeof(double) * h_rgram.size());
@@ -858,9 +877,9 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
                                    (const double *)d_hi.p, (long long)n_params, d_xc.p);
                 VG_HIP(hipGetLastError());
             }
-            double *ps = pin_small.p + G;  // [scalars 5 | gmax 1 | xg G]
-            // without poses the five sums stay at the zeros they were initialised with (nothing writes them)
-            VG_HIP(hipMemcpyAsync(ps, d_small.p, sizeof(double) * (6 + (size_t)G), hipMemcpyDeviceToHost, st));
+            double *ps = pin_small.p + G;  // [gmax 1 | xg G]
+            // without poses the five scalar sums (tail of d_sums) stay at the zeros they were initialised with
+            VG_HIP(hipMemcpyAsync(ps, d_small.p, sizeof(double) * (1 + (size_t)G), hipMemcpyDeviceToHost, st));
             t_schur += now_s() - t0;
             // No wait here: the candidate evaluation does not depend on these scalars, it is queued right behind the
             // step on the same stream, and its own read-back synchronises once for both (one host round trip per
@@ -868,11 +887,12 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             VG_TRY(evaluate(d_xc.p, cand, Uc, ggc, cost2_c));
 
             // |x|^2 of this rank's pose parameters (summed over ranks below) and of the replicated global block
-            for (int a2 = 0; a2 < G; a2++) h_xg[a2] = ps[6 + a2];
+            for (int a2 = 0; a2 < G; a2++) h_xg[a2] = ps[1 + a2];
+            const double *sc = h_sums.data() + n_sums;  // scalar sums of the step, already summed over ranks with an RCCL communicator
             double xg2 = 0.;
             for (int a2 = 0; a2 < G; a2++) xg2 += h_xg[a2] * h_xg[a2];
-            double gdp = ps[0] + host_scal[0], ddp = ps[1] + host_scal[1], dp2 = ps[2] + host_scal[2],
-                   gp2 = ps[3] + host_scal[3], xp2 = ps[4], gmax_p = ps[5] > host_scal[4] ? ps[5] : host_scal[4];
+            double gdp = sc[0] + host_scal[0], ddp = sc[1] + host_scal[1], dp2 = sc[2] + host_scal[2],
+                   gp2 = sc[3] + host_scal[3], xp2 = sc[4], gmax_p = ps[0] > host_scal[4] ? ps[0] : host_scal[4];
             for (auto &c2 : coupled) {
                 VG_HIP(hipMemcpy(c2.xc.data(), d_xc.p + c2.param_off, sizeof(double) * c2.xc.size(), hipMemcpyDeviceToHost));
                 cost2_c += c2.cost2(c2.xc);
@@ -900,7 +920,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
                 // The callback only sums.  With several ranks every rank must take the same branches, so the
                 // pose part of the gradient max-norm is replaced by its (summable) 2-norm, an upper bound:
                 // the gradient test can only fire later than Ceres' max-norm test, never earlier.
-                if (opt.allreduce) gmax_p = std::sqrt(gp2);
+                if (multi_rank) gmax_p = std::sqrt(gp2);
                 if (!p->priors.empty()) {  // global values of the candidate: clamp(x + dg), as vg_apply_step_kernel does
                     std::vector<double> xg_c(G);
                     for (int a2 = 0; a2 < G; a2++) {

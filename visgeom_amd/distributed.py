@@ -5,6 +5,8 @@ cost, Schur contribution) -- a few KB per iteration, latency bound, so the colle
 all-reduce (RCCL through torch.distributed's "nccl" backend on GPUs, "gloo" in the CPU tests).  Per-image data
 never leaves its rank.
 """
+import ctypes
+
 import numpy as np
 
 
@@ -50,3 +52,64 @@ def unpack_normal_blocks(buf, G, n_extra=0):
     g = buf[G * G:G * G + G]
     cost2 = float(buf[G * G + G])
     return U, g, cost2, buf[G * G + G + 1:G * G + G + 1 + n_extra]
+
+
+class Comm:
+    """vg_comm: an RCCL communicator owned by the native library (include/visgeom_amd.h, "multi-GPU").  The solver and
+    the normal-equation build reduce their DEVICE buffers through it, in place, on the problem's stream -- no host
+    staging, no torch tensor in between.  torch.distributed is only the courier of the 128-byte unique id."""
+
+    def __init__(self, id_bytes, n_ranks, rank, device):
+        from . import capi
+
+        self._lib = capi.load()
+        h = ctypes.c_void_p()
+        capi.check(self._lib.vg_comm_create(ctypes.byref(h), bytes(id_bytes), int(n_ranks), int(rank), int(device)))
+        self._h = h
+        self.n_ranks, self.rank, self.device = int(n_ranks), int(rank), int(device)
+
+    @staticmethod
+    def unique_id():
+        from . import capi
+
+        buf = ctypes.create_string_buffer(128)
+        capi.check(capi.load().vg_comm_unique_id(buf))
+        return buf.raw
+
+    @property
+    def handle(self):
+        return self._h
+
+    def allreduce_sum(self, tensor, stream=None):
+        """in-place sum of a float64 CUDA tensor over all ranks, enqueued on `stream` (default: torch's current one)"""
+        import torch
+
+        from . import capi
+
+        assert tensor.is_cuda and tensor.dtype == torch.float64 and tensor.is_contiguous()
+        if stream is None:
+            stream = torch.cuda.current_stream(tensor.device).cuda_stream
+        capi.check(self._lib.vg_comm_allreduce_sum(self._h, ctypes.c_void_p(tensor.data_ptr()), tensor.numel(),
+                                                   ctypes.c_void_p(stream)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.vg_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def make_comm(device, group=None):
+    """One native RCCL communicator spanning the ranks of a torch.distributed group (any backend): rank 0 draws the
+    unique id, the group broadcasts its 128 bytes, every rank joins on its own GPU."""
+    import torch.distributed as dist
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    box = [Comm.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    return Comm(box[0], world, rank, device)

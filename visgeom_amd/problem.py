@@ -255,11 +255,12 @@ class CalibrationProblem:
                                                  ctypes.c_void_p(out.data_ptr())))
 
     # -- solve ------------------------------------------------------------------------------
-    def solve(self, allreduce=None, **options):
+    def solve(self, allreduce=None, comm=None, **options):
         """Levenberg-Marquardt with per-pose Schur elimination; replaces ceres::Solve at
         unified_calibration.cpp:53.  options: fields of vg_solve_options (defaults = the reference's
         Solver::Options, unified_calibration.cpp:42-52).  allreduce(np_array) sums a host buffer over ranks in
-        place (multi-GPU).  Returns the summary as a dict; the solution is in get_parameters()."""
+        place (multi-GPU through host buffers); comm = a visgeom_amd.distributed.Comm (multi-GPU through RCCL on the
+        device buffers, the production route).  Returns the summary as a dict; the solution is in get_parameters()."""
         opt = capi.SolveOptions()
         self._lib.vg_solve_options_init(ctypes.byref(opt))
         for k, v in options.items():
@@ -279,6 +280,8 @@ class CalibrationProblem:
                     return 1
             keep = capi.ALLREDUCE_FN(_cb)
             opt.allreduce = keep
+        if comm is not None:
+            opt.comm = comm.handle
         summ = capi.SolveSummary()
         capi.check(self._lib.vg_problem_solve(self._h, ctypes.byref(opt), ctypes.byref(summ)))
         out = {name: getattr(summ, name) for name, _ in capi.SolveSummary._fields_}
