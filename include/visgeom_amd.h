@@ -172,8 +172,24 @@ int vg_dataset_num_intrinsics(const vg_problem *p, int dataset_id);
  *     jac_member[l] [n_blocks][2N][6]      any of jac_intr / jac_member / jac_member[l] may be NULL
  *   (device pointers; jac_member itself is a HOST array of chain_len device pointers). */
 int vg_problem_prepare(vg_problem *p);
+/* Route selection is a function of the problem alone (see vg_dataset_single_launch): a chain of one DIRECT member is
+ * walked inside the consuming kernel, from xi itself (the reference's rotvec -> quaternion -> rotvec round trip of
+ * compose() is skipped: |dR| < 1e-15); everything else reads the reference-order frames of the chain-prep launch.  Results
+ * are bitwise reproducible per route.  on != 0 forces the chain-prep route for every dataset (tests, A/B measurements). */
+int vg_problem_force_prepared_frames(vg_problem *p, int on);
 int vg_dataset_evaluate(vg_problem *p, int dataset_id, double *residuals, double *jac_intr,
                         double *const *jac_member);
+/* Every dataset of the problem in ONE pass: what Ceres' evaluator does when it walks all residual blocks at a new
+ * point (src/calibration/unified_calibration.cpp:53 -> calib_cost_functions.cpp:28 per block).  outs[d] holds the
+ * device pointers vg_dataset_evaluate would get for dataset d (unused chain slots NULL).  Datasets are merged into
+ * shared launches (up to 8 per launch, any mix of camera models and chains): a stereo pair or a rig is one emit launch
+ * instead of one per camera.  Same results, bit for bit, as the per-dataset entry. */
+typedef struct vg_dataset_outputs {
+    double *residuals;
+    double *jac_intr;
+    double *jac_member[VG_MAX_CHAIN];
+} vg_dataset_outputs;
+int vg_problem_evaluate(vg_problem *p, const vg_dataset_outputs *outs /* [vg_problem_num_datasets] */);
 int vg_problem_synchronize(vg_problem *p);
 /* The same evaluation delivered to HOST memory (what a Ceres EvaluationCallback needs):
  * runs kernel 2 into library-owned device buffers, copies the Ceres-layout arrays to the given host pointers

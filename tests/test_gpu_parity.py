@@ -404,8 +404,8 @@ def test_chunked_launches_for_huge_datasets(vg, S, monkeypatch):
 
 @pytest.mark.parametrize("model", MODELS)
 def test_inline_chain_and_prepared_frames_agree(vg, S, model):
-    """single-member DIRECT chain: with stale frames the emit kernel walks the chain itself (one launch); once a Gram
-    launch has forced the chain-prep kernel, the same evaluate reads the frames from memory.  Both must give the same
+    """single-member DIRECT chain: the emit kernel walks the chain itself (one launch); with the chain-prep route
+    forced, the same evaluate reads the reference-order frames from memory.  Both must give the same
     rows up to the rounding of the skipped rotvec -> quaternion -> rotvec round trip (|dR| < 1e-15), and both must
     meet the oracle."""
     import torch
@@ -421,12 +421,17 @@ def test_inline_chain_and_prepared_frames_agree(vg, S, model):
     p.finalize()
     a = p.alloc_outputs(ds)
     b = p.alloc_outputs(ds)
+    from visgeom_amd import capi
+
+    assert capi.load().vg_dataset_single_launch(p._h, ds) == 1
     p.prepare()
     p.evaluate_dataset(ds, a[0], a[1], a[2])              # inline chain
-    gram, _ = p.alloc_gram(ds)
-    p.gram_fused(ds, gram)                                # forces the chain-prep kernel: frames now valid
-    p.evaluate_dataset(ds, b[0], b[1], b[2])              # frames from memory
+    p.force_prepared_frames(True)
+    assert capi.load().vg_dataset_single_launch(p._h, ds) == 0
+    p.prepare()
+    p.evaluate_dataset(ds, b[0], b[1], b[2])              # frames from memory (chain-prep launch, reference order)
     p.synchronize()
+    assert not torch.equal(a[2][0], b[2][0]), "the two routes differ in the last bits; identical output = one route ran twice"
     for x, y, name in ((a[0], b[0], "res"), (a[1], b[1], "jac_intr"), (a[2][0], b[2][0], "jac_pose")):
         x, y = x.cpu().numpy(), y.cpu().numpy()
         scale = np.maximum(np.abs(y), np.max(np.abs(y), axis=tuple(range(1, y.ndim)), keepdims=True) * 1e-3 + 1e-300)
@@ -438,3 +443,57 @@ def test_inline_chain_and_prepared_frames_agree(vg, S, model):
         assert_block_parity(got[0].cpu().numpy().reshape(40, -1)[7], [got[1].cpu().numpy()[7], got[2][0].cpu().numpy()[7]],
                             rr[7], [ji[7], jm[0][7]], d["corners"][7], model)
     p.close()
+
+
+@pytest.mark.parametrize("model", MODELS)
+def test_rotation_norms_within_an_ulp_of_the_branch_thresholds(vg, S, model):
+    """|rot| within a few ulp -- and within +-1e-15 -- of the reference's thresholds: 1e-6 (Quaternion(rot),
+    quaternion.h:34), 1e-5 (rotationMatrix / interOmegaRot, geometry_core.h:45,163; toRotationVector's s < 1e-5 is
+    reached at |rot| = 2e-5, quaternion.h:88).  The GPU must take the branch the CPU restatement takes, on BOTH routes
+    (in-kernel chain walk from xi, and the chain-prep launch that goes through the quaternion round trip); a wrong
+    side costs 5e-11 relative in R -- inside the residual bar but visible in the pose Jacobian near 2e-5."""
+    rng = np.random.default_rng(77)
+    rots = []
+    for T in (1e-6, 1e-5, 2e-5):
+        for _ in range(6):
+            u = rng.standard_normal(3)
+            u /= np.linalg.norm(u)
+            for k in (-3, -2, -1, 0, 1, 2, 3):
+                rots.append(u * (T * (1.0 + k * 2.220446049250313e-16)))
+            rots.append(u * (T - 1e-15))
+            rots.append(u * (T + 1e-15))
+    rots = np.array(rots)
+    n = rots.shape[0]
+    d = S.make_mono(model, n, 3)
+    poses = d["init_poses"].copy()
+    poses[:, 3:] = rots
+    poses[:, :3] = np.column_stack([rng.uniform(-0.7, -0.4, n), rng.uniform(-0.45, -0.25, n), rng.uniform(0.7, 1.2, n)])
+    K = len(d["init_intrinsics"])
+    glob = np.array([0.05, -0.02, 0.01, 0.0, 0.0, 0.0])
+    for chain_kind in ("D", "ID"):
+        p = vg.CalibrationProblem(0)
+        cam = p.add_camera(model, d["init_intrinsics"])
+        if chain_kind == "ID":   # global member with a rotation ON the 1e-5 threshold in front of the sequence
+            glob[3:] = rots[10] * (1e-5 / np.linalg.norm(rots[10]))
+            g = p.add_transform(True, glob)
+        seq = p.add_transform(False, poses)
+        chain = [(seq, 0)] if chain_kind == "D" else [(g, 1), (seq, 0)]
+        ds = p.add_dataset(cam, chain, d["board"], d["corners"])
+        p.finalize()
+        pv = p.get_parameters()
+        status = [s for _, s in chain]
+        bases = [p.transform_offset(t, 0) for t, _ in chain]
+        strides = [6] if chain_kind == "D" else [0, 6]
+        rr, ji, jm = vgo.eval_dataset(vgo.MODELS[model], status, d["board"], d["corners"], pv, 0, bases, strides, np.arange(n))
+        for forced in (False, True):
+            p.force_prepared_frames(forced)
+            p.prepare()
+            out = p.alloc_outputs(ds)
+            p.evaluate_dataset(ds, out[0], out[1], out[2])
+            p.synchronize()
+            R, JI, JM = out[0].cpu().numpy(), out[1].cpu().numpy(), [m.cpu().numpy() for m in out[2]]
+            for b in range(n):
+                assert_block_parity(R[b], [JI[b]] + [m[b] for m in JM], rr[b], [ji[b]] + [m[b] for m in jm], d["corners"][b],
+                                    "%s chain %s %s route, |rot| = %.17g" % (model, chain_kind, "prepared" if forced else "automatic",
+                                                                               np.linalg.norm(rots[b])))
+        p.close()

@@ -38,6 +38,11 @@ class SolveOptions(ctypes.Structure):
                 ("allreduce", ALLREDUCE_FN), ("allreduce_user", ctypes.c_void_p), ("comm", ctypes.c_void_p)]
 
 
+class DatasetOutputs(ctypes.Structure):
+    """struct vg_dataset_outputs"""
+    _fields_ = [("residuals", ctypes.c_void_p), ("jac_intr", ctypes.c_void_p), ("jac_member", ctypes.c_void_p * MAX_CHAIN)]
+
+
 class SolveSummary(ctypes.Structure):
     """struct vg_solve_summary"""
     _fields_ = [("initial_cost", ctypes.c_double), ("final_cost", ctypes.c_double),
@@ -91,7 +96,9 @@ SIGNATURES = {
     "vg_dataset_single_launch": (ctypes.c_int, [_vp, ctypes.c_int]),
     "vg_dataset_num_intrinsics": (ctypes.c_int, [_vp, ctypes.c_int]),
     "vg_problem_prepare": (ctypes.c_int, [_vp]),
+    "vg_problem_force_prepared_frames": (ctypes.c_int, [_vp, ctypes.c_int]),
     "vg_dataset_evaluate": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vpp]),
+    "vg_problem_evaluate": (ctypes.c_int, [_vp, ctypes.POINTER(DatasetOutputs)]),
     "vg_problem_synchronize": (ctypes.c_int, [_vp]),
     "vg_dataset_evaluate_to_host": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vpp]),
     "vg_dataset_failed_count": (ctypes.c_int, [_vp, ctypes.c_int, _i64p]),

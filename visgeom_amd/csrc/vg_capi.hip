@@ -133,9 +133,34 @@ bool dataset_can_inline_chain(const vg_problem *p, const Dataset &d)
 // at once, so as soon as one dataset needs it (a multi-member chain, a very large set) the others read its frames too.
 bool single_launch_dataset(const vg_problem *p, const Dataset &d)
 {
+    if (p->force_prepared_frames) return false;
     for (const Dataset &o : p->dss)
         if (o.n_blocks && !dataset_can_inline_chain(p, o)) return false;
     return dataset_can_inline_chain(p, d);
+}
+
+void fill_emit_args(const vg_problem *p, const Dataset &d, vg::EmitArgs &a, int64_t b0, int64_t nb, double *residuals,
+                    double *jac_intr, double *const *jac_member)
+{
+    const Camera &cam = p->cams[d.camera];
+    a.frames = d.d_frames + (size_t)b0 * d.frame_stride;
+    a.board = d.d_board;
+    a.obs = d.d_obs + (size_t)b0 * 2 * d.N;
+    a.intr = p->d_params + cam.offset;
+    a.res = residuals + (size_t)b0 * 2 * d.N;
+    a.jac_intr = jac_intr ? jac_intr + (size_t)b0 * 2 * d.N * cam.K : nullptr;
+    for (int l = 0; l < vg::kMaxChain; l++)
+        a.jac_member[l] = (l < d.L && jac_member && jac_member[l]) ? jac_member[l] + (size_t)b0 * 2 * d.N * 6 : nullptr;
+    a.failed = d.d_failed;
+    a.epoch = d.epoch;
+    a.n_obs = (unsigned int)(nb * d.N);
+    a.N = (unsigned int)d.N;
+    a.L = d.L;
+    a.frame_stride_d = d.frame_stride;
+    a.chain_params = d.L ? p->d_params + d.chain.base[0] : nullptr;
+    a.chain_stride = d.L ? d.chain.stride[0] : 0;
+    a.seq_index = d.seq_identity ? nullptr : d.d_seq + b0;
+    a.first_block = b0;
 }
 
 int valid_dataset(const vg_problem *p, int d)
@@ -202,7 +227,7 @@ bool gram_uses_valu(const vg_problem *p, const Dataset &d)
 
 bool gram_inline_chain(const vg_problem *p, const Dataset &d)
 {
-    return gram_uses_valu(p, d) && d.L == 1 && d.status[0] == VG_TRANSFORM_DIRECT;
+    return !p->force_prepared_frames && gram_uses_valu(p, d) && d.L == 1 && d.status[0] == VG_TRANSFORM_DIRECT;
 }
 
 template <int MODEL, int CH>
@@ -576,6 +601,14 @@ int vgi::prepare_at(vg_problem *p, const double *d_params)
 
 extern "C" {
 
+int vg_problem_force_prepared_frames(vg_problem *p, int on)
+{
+    if (!p) return fail(VG_ERR_INVALID_ARGUMENT, "problem is NULL");
+    p->force_prepared_frames = on != 0;
+    p->frames_stale = true;
+    return VG_OK;
+}
+
 int vg_problem_prepare(vg_problem *p)
 {
     if (!p) return fail(VG_ERR_INVALID_ARGUMENT, "problem is NULL");
@@ -602,9 +635,10 @@ int vg_dataset_evaluate(vg_problem *p, int dataset_id, double *residuals, double
     bool want_jac = jac_intr != nullptr;
     for (int l = 0; l < d.L; l++)
         if (jac_member && jac_member[l]) want_jac = true;
-    // one DIRECT member and stale frames: the emit kernel walks the (trivial) chain itself -- one launch per evaluation
-    // (only while the launch's output fits the Infinity Cache, see inline_chain_max_bytes)
-    const bool inline_chain = p->frames_stale && single_launch_dataset(p, d);
+    // one DIRECT member: the emit kernel walks the (trivial) chain itself -- one launch per evaluation (only while the
+    // launch's output fits the Infinity Cache, see inline_chain_max_bytes).  The route is a function of the PROBLEM
+    // alone (vg_dataset_single_launch), never of what ran before: the same parameters always give the same bits.
+    const bool inline_chain = single_launch_dataset(p, d);
     if (!inline_chain && (rc = vgi::ensure_frames(p)) != VG_OK) return rc;
 
     // 32-bit observation indices inside a launch: chunk very large datasets by whole images
@@ -614,24 +648,7 @@ int vg_dataset_evaluate(vg_problem *p, int dataset_id, double *residuals, double
     for (int64_t b0 = 0; b0 < d.n_blocks; b0 += max_blocks_per_launch) {
         const int64_t nb = d.n_blocks - b0 < max_blocks_per_launch ? d.n_blocks - b0 : max_blocks_per_launch;
         vg::EmitArgs a;
-        a.frames = d.d_frames + (size_t)b0 * d.frame_stride;
-        a.board = d.d_board;
-        a.obs = d.d_obs + (size_t)b0 * 2 * d.N;
-        a.intr = p->d_params + cam.offset;
-        a.res = residuals + (size_t)b0 * 2 * d.N;
-        a.jac_intr = jac_intr ? jac_intr + (size_t)b0 * 2 * d.N * cam.K : nullptr;
-        for (int l = 0; l < vg::kMaxChain; l++)
-            a.jac_member[l] = (l < d.L && jac_member && jac_member[l]) ? jac_member[l] + (size_t)b0 * 2 * d.N * 6 : nullptr;
-        a.failed = d.d_failed;
-        a.epoch = d.epoch;
-        a.n_obs = (unsigned int)(nb * d.N);
-        a.N = (unsigned int)d.N;
-        a.L = d.L;
-        a.frame_stride_d = d.frame_stride;
-        a.chain_params = d.L ? p->d_params + d.chain.base[0] : nullptr;
-        a.chain_stride = d.L ? d.chain.stride[0] : 0;
-        a.seq_index = d.seq_identity ? nullptr : d.d_seq + b0;
-        a.first_block = b0;
+        fill_emit_args(p, d, a, b0, nb, residuals, jac_intr, jac_member);
         switch (cam.model) {
         case VG_MODEL_EUCM: rc = launch_emit<vg::kEUCM>(p->stream, a, want_jac, inline_chain); break;
         case VG_MODEL_UCM: rc = launch_emit<vg::kUCM>(p->stream, a, want_jac, inline_chain); break;
@@ -667,6 +684,63 @@ int vg_dataset_evaluate_to_host(vg_problem *p, int dataset_id, double *residuals
     for (int l = 0; l < d.L; l++)
         if (jm[l]) VG_HIP(hipMemcpyAsync(jac_member[l], jm[l], sizeof(double) * rows * 6, hipMemcpyDeviceToHost, p->stream));
     VG_HIP(hipStreamSynchronize(p->stream));
+    return VG_OK;
+}
+
+int vg_problem_evaluate(vg_problem *p, const vg_dataset_outputs *outs)
+{
+    if (!p || !outs) return fail(VG_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!p->finalized) return fail(VG_ERR_STATE, "problem not finalized");
+    VG_HIP(hipSetDevice(p->device));
+    const int n_ds = (int)p->dss.size();
+    int rc;
+    // which datasets can share a launch: every Jacobian-carrying evaluation whose frames fit the LDS and whose
+    // observation count fits one launch; the rest (cost-only calls, huge sets) go through vg_dataset_evaluate
+    std::vector<int> shared, alone;
+    bool need_frames = false;
+    for (int i = 0; i < n_ds; i++) {
+        Dataset &d = p->dss[i];
+        if (!d.n_blocks) {
+            d.epoch = (d.epoch + 1) & 0xFFFFFFull;
+            if (d.epoch == 0) d.epoch = 1;
+            continue;
+        }
+        if (!outs[i].residuals) return fail(VG_ERR_INVALID_ARGUMENT, "residuals is NULL");
+        bool want_jac = outs[i].jac_intr != nullptr;
+        for (int l = 0; l < d.L; l++) want_jac = want_jac || outs[i].jac_member[l] != nullptr;
+        if (want_jac && emit_frames_in_lds(d.N, d.frame_stride) && d.n_blocks * (int64_t)d.N < ((int64_t)1 << 30)) shared.push_back(i);
+        else alone.push_back(i);
+    }
+    if (shared.size() < 2) {  // nothing to merge
+        alone.insert(alone.end(), shared.begin(), shared.end());
+        shared.clear();
+    }
+    for (int i : shared) need_frames = need_frames || !single_launch_dataset(p, p->dss[i]);
+    if (need_frames && (rc = vgi::ensure_frames(p)) != VG_OK) return rc;
+    for (size_t g0 = 0; g0 < shared.size(); g0 += vg::kEmitMultiMax) {
+        vg::EmitMultiArgs m;
+        m.n = (int)(shared.size() - g0 < (size_t)vg::kEmitMultiMax ? shared.size() - g0 : (size_t)vg::kEmitMultiMax);
+        unsigned int tiles = 0;
+        size_t lds = 0;
+        for (int k = 0; k < m.n; k++) {
+            Dataset &d = p->dss[shared[g0 + k]];
+            const vg_dataset_outputs &o = outs[shared[g0 + k]];
+            d.epoch = (d.epoch + 1) & 0xFFFFFFull;
+            if (d.epoch == 0) d.epoch = 1;
+            fill_emit_args(p, d, m.ds[k], 0, d.n_blocks, o.residuals, o.jac_intr, o.jac_member);
+            m.model[k] = p->cams[d.camera].model;
+            m.inline_chain[k] = single_launch_dataset(p, d) ? 1 : 0;
+            m.first_tile[k] = tiles;
+            tiles += (m.ds[k].n_obs + vg::kEmitThreads - 1) / vg::kEmitThreads;
+            const size_t need = emit_lds_bytes<vg::kEUCM>(true, true, d.N, d.frame_stride);  // same tile size for every model
+            lds = need > lds ? need : lds;
+        }
+        for (int k = m.n; k <= vg::kEmitMultiMax; k++) m.first_tile[k] = tiles;
+        hipLaunchKernelGGL(vg::vg_emit_multi_kernel, dim3(tiles), dim3(vg::kEmitThreads), lds, p->stream, m);
+        VG_HIP(hipGetLastError());
+    }
+    for (int i : alone)
+        if ((rc = vg_dataset_evaluate(p, i, outs[i].residuals, outs[i].jac_intr, outs[i].jac_member)) != VG_OK) return rc;
     return VG_OK;
 }
 

@@ -296,8 +296,21 @@ VG_HD void build_frame_single_direct(const double *xi, double *frame)
 {
     const double r[3] = {xi[3], xi[4], xi[5]};
     const RotTrig g = rot_trig(r, true, true);
+    // R13 = R(xiAcc.rot).  The reference's xiAcc.rot is not xi.rot itself but its image under compose()'s round trip
+    // through the quaternion: below |q.xyz| = 1e-5 that is 2 sin(th/2) u (quaternion.h:88-91), SHORTER than th by
+    // th^3/24.  Nothing but rounding for the values -- but just above th = 1e-5 it carries xiAcc.rot back under the
+    // first-order threshold of rotationMatrix (geometry_core.h:45), so the reference takes the first-order R13 there
+    // while th itself says Rodrigues (5e-11 apart: above the 1e-10 bar once projected).  In that band the round trip
+    // is evaluated exactly as the reference does and decides the branch.
+    double racc[3] = {r[0], r[1], r[2]};
+    RotTrig gacc = g;
+    if (!(g.th < 1e-5) && g.th < 1.00000001e-5) {
+        const Quat q = quat_from_rotvec(r, g);   // identity * q == q, component by component
+        quat_to_rotvec(q, racc);
+        gacc.th = norm3(racc);                   // sin / cos of it: those of th to 1e-16 (only used if still >= 1e-5)
+    }
     double R[9], Rb[9], M[9], R12[9], M12[9];
-    rotation_matrix(r, 1., g, R);     // R13 = R(xiAcc.rot)
+    rotation_matrix(racc, 1., gacc, R);  // R13 = R(xiAcc.rot)
     rotation_matrix(r, -1., g, Rb);   // xi23.rotMatInv()
     mat3_mul(R, Rb, R12);             // jacobian.h:142 (the identity up to rounding, kept as computed)
     inter_omega_rot(r, g, M);
@@ -317,13 +330,13 @@ VG_HD void build_frame_single_direct(const double *xi, double *frame)
 // 1 - cos th = 2 sh^2), R12 = R(r) R(-r) taken as the identity it is to 1e-16, M from uhat^2 = u u^T - I.  About a third
 // of the dependent instruction chain of build_frame_single_direct -- the chain walk is a serial prologue of every
 // workgroup of vg_gram_valu_kernel.  Below the reference's first-order threshold (theta < 1e-5, where its R12 is
-// I - hat(r)^2, 1e-10 away from I) the reference-order routine is used unchanged.
+// I - hat(r)^2, 1e-10 away from I) and in the band just above it the reference-order routine is used unchanged.
 VG_HD void build_frame_single_direct_fast(const double *xi, double *frame)
 {
 #pragma clang fp contract(fast)
     const double r0 = xi[3], r1 = xi[4], r2 = xi[5];
     const double th = sqrt(r0 * r0 + r1 * r1 + r2 * r2);
-    if (th < 1e-5) {
+    if (th < 1.00000001e-5) {  // first-order forms, and the band where the reference's round trip decides the branch
         build_frame_single_direct(xi, frame);
         return;
     }

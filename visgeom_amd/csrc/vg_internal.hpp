@@ -88,6 +88,9 @@ struct vg_problem {
     // vg_problem_prepare marks the frames stale; they are rebuilt on demand (chain-prep kernel) by whoever reads
     // them from HBM -- or never, when every consumer derives them in-kernel (single-member DIRECT chains)
     bool frames_stale = true;
+    // test / measurement hook (vg_problem_force_prepared_frames): every kernel reads the reference-order frames of the
+    // chain-prep launch instead of walking single-member chains itself
+    bool force_prepared_frames = false;
 };
 
 struct vg_block {

@@ -191,8 +191,9 @@ __device__ __forceinline__ unsigned int xcd_contiguous_block(unsigned int b, uns
 // INLINE_CHAIN (with FRAMES_LDS, chain = one DIRECT member): the workgroup derives the <= 4 frames it needs itself
 // (thread f walks image b_first + f with build_frame_single_direct) instead of reading them from the chain-prep
 // kernel's output -- a full evaluation is then ONE launch.
-template <int MODEL, bool WANT_JAC, bool FRAMES_LDS, bool INLINE_CHAIN = false>
-__global__ __launch_bounds__(kEmitThreads) void vg_emit_kernel(EmitArgs a)
+// One 256-observation tile of one dataset (o0 = first observation of the tile).
+template <int MODEL, bool WANT_JAC, bool FRAMES_LDS, bool INLINE_CHAIN>
+__device__ __forceinline__ void emit_tile(const EmitArgs &a, const unsigned int o0)
 {
     static_assert(!INLINE_CHAIN || FRAMES_LDS, "the inline chain writes its frames to LDS");
     constexpr int K = CameraTraits<MODEL>::K;
@@ -202,7 +203,6 @@ __global__ __launch_bounds__(kEmitThreads) void vg_emit_kernel(EmitArgs a)
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wave = tid >> 6;
-    const unsigned int o0 = xcd_contiguous_block(blockIdx.x, gridDim.x) * (unsigned)kEmitThreads;
     const unsigned int o = o0 + tid;
     const bool active = o < a.n_obs;
     const unsigned int oc = active ? o : a.n_obs - 1;
@@ -292,6 +292,50 @@ __global__ __launch_bounds__(kEmitThreads) void vg_emit_kernel(EmitArgs a)
             pose_rows(e.P, X0, X1, X2, fr + 12 + 21 * l, rows);
             wave_store_rows<6>(stage, rows, Jm + (size_t)ow * 12, n_valid, lane);
         }
+    }
+}
+
+template <int MODEL, bool WANT_JAC, bool FRAMES_LDS, bool INLINE_CHAIN = false>
+__global__ __launch_bounds__(kEmitThreads) void vg_emit_kernel(EmitArgs a)
+{
+    emit_tile<MODEL, WANT_JAC, FRAMES_LDS, INLINE_CHAIN>(a, xcd_contiguous_block(blockIdx.x, gridDim.x) * (unsigned)kEmitThreads);
+}
+
+// ------------------------------------------------------------------------------------------
+// kernel 2, several datasets in ONE launch (stereo pair, camera rig): a problem's datasets are small launches each
+// (2 000 stereo pairs: 42 + 62 MB) whose ramp-up, drain and inter-kernel gap cost a quarter of the pass.  The tiles of
+// all datasets form one range; XCD x streams the x-th contiguous eighth of it, so a die works inside one dataset's
+// output arrays at a time.  Per-dataset arguments travel by value in the kernel argument segment (no table upload per
+// evaluation); the camera model and the chain route are wave-uniform run-time switches over the same tile routine.
+// ------------------------------------------------------------------------------------------
+constexpr int kEmitMultiMax = 8;
+
+struct EmitMultiArgs {
+    EmitArgs ds[kEmitMultiMax];
+    unsigned int first_tile[kEmitMultiMax + 1];
+    int model[kEmitMultiMax];
+    int inline_chain[kEmitMultiMax];
+    int n;
+};
+
+template <int MODEL>
+__device__ __forceinline__ void emit_tile_route(const EmitArgs &a, unsigned int o0, bool inline_chain)
+{
+    if (inline_chain) emit_tile<MODEL, true, true, true>(a, o0);
+    else emit_tile<MODEL, true, true, false>(a, o0);
+}
+
+__global__ __launch_bounds__(kEmitThreads) void vg_emit_multi_kernel(EmitMultiArgs m)
+{
+    const unsigned int t = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    int d = 0;
+    while (d + 1 < m.n && t >= m.first_tile[d + 1]) d++;
+    const unsigned int o0 = (t - m.first_tile[d]) * (unsigned)kEmitThreads;
+    const bool inl = m.inline_chain[d] != 0;
+    switch (m.model[d]) {
+    case kEUCM: emit_tile_route<kEUCM>(m.ds[d], o0, inl); break;
+    case kUCM: emit_tile_route<kUCM>(m.ds[d], o0, inl); break;
+    default: emit_tile_route<kMEI>(m.ds[d], o0, inl); break;
     }
 }
 

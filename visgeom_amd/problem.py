@@ -209,6 +209,10 @@ class CalibrationProblem:
     def prepare(self):
         capi.check(self._lib.vg_problem_prepare(self._h))
 
+    def force_prepared_frames(self, on=True):
+        """tests / A-B measurements: every kernel reads the chain-prep launch's frames (vg_problem_force_prepared_frames)"""
+        capi.check(self._lib.vg_problem_force_prepared_frames(self._h, int(bool(on))))
+
     def evaluate_dataset(self, d, res, jac_intr=None, jac_member=None):
         """kernel 2 on dataset d; outputs are torch tensors (or None) from alloc_outputs."""
         L = self.datasets[d]["L"]
@@ -219,6 +223,18 @@ class CalibrationProblem:
         capi.check(self._lib.vg_dataset_evaluate(self._h, d, ctypes.c_void_p(res.data_ptr()),
                                                  ctypes.c_void_p(jac_intr.data_ptr()) if jac_intr is not None else None,
                                                  jm))
+
+    def evaluate_all(self, outputs):
+        """every dataset in one pass (vg_problem_evaluate): outputs[d] = (res, jac_intr, [jac_member...]) as returned
+        by alloc_outputs(d); datasets share launches (a stereo pair or a rig is one emit launch)."""
+        arr = (capi.DatasetOutputs * len(self.datasets))()
+        for d, (res, ji, jm) in enumerate(outputs):
+            arr[d].residuals = res.data_ptr() if res is not None else None
+            arr[d].jac_intr = ji.data_ptr() if ji is not None else None
+            for l in range(self.datasets[d]["L"]):
+                t = jm[l] if jm else None
+                arr[d].jac_member[l] = t.data_ptr() if t is not None else None
+        capi.check(self._lib.vg_problem_evaluate(self._h, arr))
 
     # -- normal equations ------------------------------------------------------------------
     def gram_width(self, d):
