@@ -307,6 +307,18 @@ void vg_solve_options_init(vg_solve_options *o); /* the defaults listed above */
  * seven global transforms); any number of pose blocks below 2^28.  Beyond that VG_ERR_INVALID_ARGUMENT. */
 int vg_problem_solve(vg_problem *p, const vg_solve_options *options, vg_solve_summary *summary);
 
+/* The per-image pose refinement of estimateInitialGrid (src/calibration/unified_calibration.cpp:1137-1155) for n
+ * images at once: n INDEPENDENT problems -- one GenericProjectionJac block with chain {DIRECT} each, intrinsics
+ * constant, ceres::SoftLOneLoss(options->soft_l1_scale), every image with its own trust region, step acceptance and
+ * convergence tests (one half-wave per image runs its whole solve inside ONE kernel launch).  Host pointers:
+ *   board [3 N], corners [n_images][2 N], poses [n_images][6] (in: start, out: result); optional per-image outputs
+ *   iterations / final_cost (rho(|r|^2) / 2) / termination (enum vg_termination), each [n_images] or NULL.
+ * options NULL = what the reference runs: Ceres' defaults (function / gradient / parameter tolerance 1e-6 / 1e-10 /
+ * 1e-8) with max_num_iterations = 500 and SoftLOneLoss(25). */
+int vg_refine_poses(int device, void *hip_stream, int model, const double *intrinsics, int n_points, const double *board,
+                    int64_t n_images, const double *corners, double *poses, const vg_solve_options *options,
+                    int32_t *iterations, double *final_cost, int32_t *termination);
+
 /* Host-only helper of the solver, exported so the host logic can be tested without a GPU:
  * solves the symmetric positive definite n x n system A x = b (row-major A, untouched) by Cholesky.
  * Returns VG_ERR_NUMERIC when A is not positive definite. */

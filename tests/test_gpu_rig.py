@@ -116,3 +116,53 @@ def test_wide_rig_more_than_63_global_columns(vg):
     for k in range(n_cam - 1):
         assert np.max(np.abs(x[80 + 6 * k:86 + 6 * k] - xi1k[k])) < 1e-6
     p.close()
+
+
+def test_all_datasets_in_one_launch_equal_the_per_dataset_entry(vg):
+    """vg_problem_evaluate merges the rig's four datasets (UCM, EUCM, EUCM, Mei; chains [D] and [I, D]) into one emit
+    launch: same bits as four vg_dataset_evaluate calls, NULL blocks honoured, failed-projection counters per dataset."""
+    import torch
+
+    from visgeom_amd import synthetic as S
+
+    n = 57
+    r = S.make_rig(n, sigma=0.1)
+    p, cams, x1k, seq, dss = build_rig(vg, r)
+    ref = [p.alloc_outputs(ds) for ds in dss]
+    got = [p.alloc_outputs(ds) for ds in dss]
+    for o in got:
+        o[0].fill_(float("nan"))
+        o[1].fill_(float("nan"))
+        for m in o[2]:
+            m.fill_(float("nan"))
+    p.prepare()
+    for ds, o in zip(dss, ref):
+        p.evaluate_dataset(ds, o[0], o[1], o[2])
+    p.prepare()
+    p.evaluate_all(got)
+    p.synchronize()
+    for a, b in zip(ref, got):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        assert all(torch.equal(x, y) for x, y in zip(a[2], b[2]))
+    assert all(p.failed_count(ds) == 0 for ds in dss)
+    # constant blocks: NULL pointers for camera 1's intrinsics and the first global transform
+    got2 = [p.alloc_outputs(ds) for ds in dss]
+    outs = [(o[0], None if k == 1 else o[1], [None if (k == 1 and l == 0) else m for l, m in enumerate(o[2])]) for k, o in enumerate(got2)]
+    got2[1][1].fill_(7.0)
+    got2[1][2][0].fill_(7.0)
+    p.evaluate_all(outs)
+    p.synchronize()
+    assert torch.all(got2[1][1] == 7.0) and torch.all(got2[1][2][0] == 7.0)
+    assert torch.equal(got2[1][2][1], ref[1][2][1]) and torch.equal(got2[3][1], ref[3][1])
+    # the forced chain-prep route through the same entry
+    p.force_prepared_frames(True)
+    p.prepare()
+    p.evaluate_all(got)
+    p.synchronize()
+    pv = p.get_parameters()
+    rr, jir, jmr = vgo.eval_dataset(vgo.MODELS[r["models"][0]], [0], r["board"], r["corners"][0], pv, p.camera_offset(cams[0]),
+                                    [p.transform_offset(seq, 0)], [6], np.arange(n), threads=2)
+    for b in range(0, n, 9):
+        assert_block_parity(got[0][0][b].cpu().numpy(), [got[0][1][b].cpu().numpy(), got[0][2][0][b].cpu().numpy()],
+                            rr[b], [jir[b], jmr[0][b]], r["corners"][0][b], "merged launch, prepared frames")
+    p.close()

@@ -77,10 +77,12 @@ def main():
 
         def emit():
             p.prepare()
-            for (ds, _, _, _), (res, ji, jm) in zip(dss, outs):
-                p.evaluate_dataset(ds, res, ji, jm)
+            p.evaluate_all(outs)   # every dataset of the problem in one pass (vg_problem_evaluate: merged launches)
 
         def emit_only():
+            p.evaluate_all(outs)
+
+        def emit_per_dataset():
             for (ds, _, _, _), (res, ji, jm) in zip(dss, outs):
                 p.evaluate_dataset(ds, res, ji, jm)
 
@@ -91,6 +93,8 @@ def main():
                 p.gram_sum(ds, gram, gsum)
 
         t_emit, t_emit_only, t_jtj = timed(emit), timed(emit_only), timed(jtj)
+        t_per_ds = timed(emit_per_dataset)
+        spread = sorted(timed(emit_only, max(20, REPS // 5)) for _ in range(5))   # min / median / max of 5 runs
         x0 = p.get_parameters()
         best = None
         for _ in range(3):
@@ -106,6 +110,9 @@ def main():
             off += g.size
         row = {"config": name, "observations": n_obs, "emit_ms": t_emit * 1e3, "evals_per_s": n_obs / t_emit,
                "emit_kernels_GBps": bytes_emit / t_emit_only / 1e9, "emit_bytes": bytes_emit, "jtj_fused_ms": t_jtj * 1e3,
+               "emit_per_dataset_launches_GBps": bytes_emit / t_per_ds / 1e9,
+               "emit_only_ms_min_median_max": [spread[0] * 1e3, spread[2] * 1e3, spread[4] * 1e3],
+               "frac_of_hbm_peak": bytes_emit / t_emit_only / 8e12,
                "solve_ms": best["total_seconds"] * 1e3, "solve_iterations": best["num_iterations"],
                "termination": best["termination"], "global_columns": best["num_global_columns"],
                "max_rel_intrinsics_error_vs_generating": err}

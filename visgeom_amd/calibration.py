@@ -93,3 +93,37 @@ def transform_from_values(values):
     out = np.empty(6)
     capi.check(capi.load().vg_transform_from_values(v.size, v.ctypes.data_as(capi._dp), out.ctypes.data_as(capi._dp)))
     return out
+
+
+def refine_poses(model, intrinsics, board, corners, poses, device=0, **options):
+    """estimateInitialGrid's per-image refinement (unified_calibration.cpp:1137-1155) for all images at once: n
+    INDEPENDENT 6-DOF problems, one kernel launch (vg_refine_poses).  corners [n, N, 2], poses [n, 6] (start).
+    options: fields of vg_solve_options; none = the reference's setting (Ceres defaults, 500 iterations,
+    SoftLOneLoss(25)).  Returns (poses [n, 6], iterations [n], final_cost [n], termination [n])."""
+    L = capi.load()
+    m = capi.MODELS[model] if isinstance(model, str) else int(model)
+    intr = np.ascontiguousarray(intrinsics, dtype=np.float64)
+    board = np.ascontiguousarray(board, dtype=np.float64).reshape(-1, 3)
+    N = board.shape[0]
+    corners = np.ascontiguousarray(corners, dtype=np.float64).reshape(-1, 2 * N)
+    n = corners.shape[0]
+    out = np.array(poses, dtype=np.float64).reshape(n, 6).copy()
+    it = np.zeros(n, dtype=np.int32)
+    cost = np.zeros(n)
+    term = np.zeros(n, dtype=np.int32)
+    opt = None
+    if options:
+        opt = capi.SolveOptions()
+        L.vg_solve_options_init(ctypes.byref(opt))
+        opt.max_num_iterations, opt.function_tolerance, opt.gradient_tolerance, opt.parameter_tolerance = 500, 1e-6, 1e-10, 1e-8
+        opt.soft_l1_scale = 25.0
+        for k, v in options.items():
+            if not hasattr(opt, k):
+                raise TypeError("unknown solver option %r" % k)
+            setattr(opt, k, v)
+    dp = ctypes.POINTER(ctypes.c_double)
+    ip = ctypes.POINTER(ctypes.c_int32)
+    capi.check(L.vg_refine_poses(device, None, m, intr.ctypes.data_as(dp), N, board.ctypes.data_as(dp), n,
+                                 corners.ctypes.data_as(dp), out.ctypes.data_as(dp), ctypes.byref(opt) if opt is not None else None,
+                                 it.ctypes.data_as(ip), cost.ctypes.data_as(dp), term.ctypes.data_as(ip)))
+    return out, it, cost, term

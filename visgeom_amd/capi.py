@@ -116,6 +116,8 @@ SIGNATURES = {
     "vg_comm_destroy": (None, [_vp]),
     "vg_solve_options_init": (None, [ctypes.POINTER(SolveOptions)]),
     "vg_problem_solve": (ctypes.c_int, [_vp, ctypes.POINTER(SolveOptions), ctypes.POINTER(SolveSummary)]),
+    "vg_refine_poses": (ctypes.c_int, [ctypes.c_int, _vp, ctypes.c_int, _dp, ctypes.c_int, _dp, ctypes.c_int64, _dp, _dp,
+                                       ctypes.POINTER(SolveOptions), _i32p, _dp, _i32p]),
     "vg_host_cholesky_solve": (ctypes.c_int, [ctypes.c_int, _dp, _dp, _dp]),
     "vg_calibration_create": (ctypes.c_int, [_vpp, ctypes.c_int]),
     "vg_calibration_destroy": (None, [_vp]),

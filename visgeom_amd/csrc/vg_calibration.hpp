@@ -9,8 +9,9 @@
 //     corner detector (OpenCV) is out of scope.  "ir_data" is read exactly as the reference reads it.
 //   * odometry_intrinsic entries are rejected (OdometryCost is declared with one parameter block but added with three,
 //     broken as shipped); transformation_prior is accepted on global transforms; odometry is accepted.
-//   * the per-image and global-transform initial refinements use plain least squares (the reference wraps them
-//     in SoftLOneLoss(25) / SoftLOneLoss(1)); the main solve has no loss function in the reference either (:539-564).
+//   * the per-image refinement of estimateInitialGrid runs as n INDEPENDENT problems in one launch (vg_refine_poses:
+//     own trust region per image, SoftLOneLoss(25)), the global-transform refinement as one batched problem with
+//     SoftLOneLoss(1) per block -- the reference's semantics (:1137-1155, :358-429), not its one-Ceres-solve-per-image loop.
 #pragma once
 
 #include <algorithm>
@@ -243,7 +244,12 @@ inline Array6d estimate_initial_grid_geometric(vg_calibration *c, const ImageDat
     const int model = c->cameraModelMap[data.cameraName];
     const double *intr = c->intrinsicMap[data.cameraName].data();
     auto recon = [&](int idx, double *X) {
-        reconstruct_point(model, intr, &cv[2 * (size_t)idx], X);
+        // the reference ignores reconstructPoint's return value (:1081-1084) and would go on with an uninitialised
+        // vector; a corner outside the model's valid image region at the initial intrinsics is reported instead
+        if (!reconstruct_point(model, intr, &cv[2 * (size_t)idx], X))
+            throw Error{VG_ERR_INVALID_ARGUMENT, "image " + std::to_string(gridIdx) + ": corner " + std::to_string(idx) +
+                                                     " cannot be reconstructed with the initial intrinsics of " + data.cameraName +
+                                                     " (outside the model's image region); cannot initialise the pose"};
         const double n = std::sqrt(X[0] * X[0] + X[1] * X[1] + X[2] * X[2]);
         for (int k = 0; k < 3; k++) X[k] /= n;
     };
@@ -306,15 +312,29 @@ inline Array6d get_init_transform(vg_calibration *c, Array6d xi, const std::stri
     return xi;
 }
 
-// estimateInitialGrid for a set of images at once: geometric estimate, then (unless do_not_solve) ONE batched
-// refinement of all camera-frame poses with the intrinsics held constant (the reference runs one tiny Ceres
-// problem per image, :1137-1155 -- 10 k sequential solves at the benchmark scale)
+// estimateInitialGrid for a set of images at once: geometric estimate, then (unless do_not_solve) the refinement of
+// every camera-frame pose with the intrinsics held constant -- one INDEPENDENT problem per image as in the reference
+// (:1137-1155: own trust region, SoftLOneLoss(25), at most 500 iterations), all of them inside one kernel launch
+// (vg_refine_poses) instead of 10 k sequential Ceres solves at the benchmark scale
 inline std::vector<Array6d> estimate_initial_grids(vg_calibration *c, const ImageData &data, const std::vector<int> &images)
 {
     std::vector<Array6d> cam_pose(data.detectedCornersVec.size(), Array6d{0, 0, 1, 0, 0, 0});
     for (int img : images) cam_pose[(size_t)img] = estimate_initial_grid_geometric(c, data, img);
-    if (!data.doNotSolve && !images.empty())
-        refine_on_gpu(c, data, images, {"__camera_frame__"}, {VG_TRANSFORM_DIRECT}, {&cam_pose}, {true}, {false}, 500, 25.);  // SoftLOneLoss(25) :1143
+    if (!data.doNotSolve && !images.empty()) {
+        const int N = (int)data.board.size();
+        std::vector<double> board, corners, poses;
+        for (auto &pt : data.board) board.insert(board.end(), pt.begin(), pt.end());
+        for (int img : images) {
+            corners.insert(corners.end(), data.detectedCornersVec[(size_t)img].begin(), data.detectedCornersVec[(size_t)img].end());
+            poses.insert(poses.end(), cam_pose[(size_t)img].begin(), cam_pose[(size_t)img].end());
+        }
+        const int rc = vg_refine_poses(c->device, nullptr, c->cameraModelMap[data.cameraName], c->intrinsicMap[data.cameraName].data(),
+                                       N, board.data(), (int64_t)images.size(), corners.data(), poses.data(), nullptr, nullptr,
+                                       nullptr, nullptr);
+        if (rc != VG_OK) throw Error{rc, vg_last_error()};
+        for (size_t i = 0; i < images.size(); i++)
+            for (int k = 0; k < 6; k++) cam_pose[(size_t)images[i]][k] = poses[6 * i + k];
+    }
     return cam_pose;
 }
 

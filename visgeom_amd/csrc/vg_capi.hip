@@ -1058,4 +1058,6 @@ int vg_calib_stream_copy(void *hip_stream, double *dst, const double *src, int64
 
 #include "vg_comm.hpp"
 #include "vg_solver_impl.hpp"
+#include "vg_pose_lm.hpp"
+#include "vg_refine_impl.hpp"
 #include "vg_calibration.hpp"

@@ -580,7 +580,10 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
 
     std::vector<double> h_sums((size_t)n_ds * Wmax * Wmax + 5), h_rgram((size_t)C * C);
     std::vector<double> U((size_t)G * G), gg(G), Uc((size_t)G * G), ggc(G), S((size_t)G * G), rhs(G), dg(G), h_xg(G);
-    PinnedBuf pin_sums, pin_rgram, pin_small;  // pin_small: [dg (G) | gmax (1) | xg (G)]
+    PinnedBuf pin_sums, pin_rgram, pin_small, pin_bad;
+    long long n_bad_pose_blocks = 0;
+    VG_TRY(pin_bad.alloc(1));
+    *reinterpret_cast<int *>(pin_bad.p) = 0;  // pin_small: [dg (G) | gmax (1) | xg (G)]
     VG_TRY(pin_sums.alloc(h_sums.size()));
     VG_TRY(pin_rgram.alloc(h_rgram.size()));
     VG_TRY(pin_small.alloc((size_t)2 * G + 2));
@@ -786,8 +789,15 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
         if (n_poses || (comm && comm->n_ranks > 1)) {
             VG_TRY(vgc::allreduce_sum(comm, d_rgram.p, h_rgram.size(), st));  // Schur complement of the poses of all ranks
             VG_HIP(hipMemcpyAsync(pin_rgram.p, d_rgram.p, sizeof(double) * h_rgram.size(), hipMemcpyDeviceToHost, st));
+            if (n_poses) VG_HIP(hipMemcpyAsync(pin_bad.p, d_bad.p, sizeof(int), hipMemcpyDeviceToHost, st));
             VG_HIP(hipStreamSynchronize(st));
             std::memcpy(h_rgram.data(), pin_rgram.p, sizeof(double) * h_rgram.size());
+            // poses whose damped 6 x 6 block was not positive definite (NaN / Inf in their Gram block): the step is
+            // invalid as a whole -- rejected like a failed factorisation of the reduced system, and counted
+            if (n_poses && *reinterpret_cast<const int *>(pin_bad.p) > 0) {
+                coupled_ok = false;
+                n_bad_pose_blocks += *reinterpret_cast<const int *>(pin_bad.p);
+            }
         }
         VG_TRY(allreduce(h_rgram));
         t_schur += now_s() - t0;
@@ -1005,6 +1015,10 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
     if (iter > opt.max_num_iterations) {
         iter = opt.max_num_iterations;
         std::snprintf(msg, sizeof msg, "maximum number of iterations reached");
+    }
+    if (n_bad_pose_blocks) {
+        const size_t len = std::strlen(msg);
+        std::snprintf(msg + len, sizeof msg - len, "%s%lld pose block(s) not positive definite", len ? "; " : "", n_bad_pose_blocks);
     }
     VG_HIP(hipMemcpyAsync(p->d_params, d_x.p, sizeof(double) * (size_t)n_params, hipMemcpyDeviceToDevice, st));
     VG_HIP(hipStreamSynchronize(st));
