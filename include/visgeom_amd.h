@@ -87,6 +87,34 @@ int vg_block_evaluate(vg_block *b, double const *const *parameters, double *resi
                       double **jacobians);
 void vg_block_destroy(vg_block *b);
 
+/* ---- block groups: the same per-block entry, amortised.  Blocks created against a group share one resident problem:
+ * the FIRST vg_block_evaluate at a new parameter point evaluates every block of the group in one pass (merged
+ * launches, one D2H into a pinned mirror), every later call at that point compares its parameter values with the ones
+ * the pass used (bitwise) and copies its rows out -- about 2 us per call at 10 000 blocks against ~45 us for a block
+ * on its own and ~9 us for the reference's CPU Evaluate.  A block is never served rows computed from other parameter
+ * values than the ones it passes: on a mismatch it evaluates alone.
+ * The per-block interface shows a block only its own parameter pointers; where the OTHER blocks' parameters are when
+ * a pass opens is learned from the first pass (every block evaluates alone once and is bound to its pointers; pointer
+ * identity tells which blocks share intrinsics or a global transform) and then follows the mode:
+ *   VG_GROUP_IN_PLACE      parameters are read where they were last seen (ceres::Problem::Evaluate, gradient
+ *                          checkers, solvers that evaluate in place);
+ *   VG_GROUP_STATE_VECTOR  the host evaluates candidate points held in state arrays of a fixed layout (ceres::Solve:
+ *                          every variable parameter block of a pass is state + offset): a new pass is the previous
+ *                          one displaced by the displacement of the calling block's pointers; blocks whose pointers
+ *                          never move (constant parameter blocks) are read in place.  The host guarantees that the
+ *                          displaced addresses are readable (they are inside the state array by construction).
+ * Pointers passed to vg_block_evaluate must stay readable until the block is called again.  Not thread safe. */
+typedef struct vg_block_group vg_block_group;
+enum vg_group_mode { VG_GROUP_IN_PLACE = 0, VG_GROUP_STATE_VECTOR = 1 };
+int vg_block_group_create(vg_block_group **out, int device, int mode);
+/* vg_block_create with membership; blocks may be added at any time (the group re-learns its layout) */
+int vg_block_create_in_group(vg_block **out, vg_block_group *g, int model, int chain_len, const int *status, int n_points,
+                             const double *grid /*3N host*/, const double *obs /*2N host*/);
+/* counters since creation: passes over the whole group / calls answered from a pass / calls evaluated alone */
+int vg_block_group_stats(const vg_block_group *g, int64_t *n_blocks, int64_t *batched_evaluations, int64_t *served, int64_t *alone);
+/* destroy the group after (or before) its blocks; surviving blocks continue on the per-block path */
+void vg_block_group_destroy(vg_block_group *g);
+
 /* =====================================================================================
  * 2. Batched problem -- what GenericCameraCalibration assembles
  *    (src/calibration/unified_calibration.cpp:91-180, 514-630), evaluated in ONE pass over
@@ -155,8 +183,7 @@ int64_t vg_dataset_num_blocks(const vg_problem *p, int dataset_id);
 int vg_dataset_num_points(const vg_problem *p, int dataset_id);
 int vg_dataset_chain_len(const vg_problem *p, int dataset_id);
 /* 1 when an evaluation of this dataset after a parameter change is a single launch (one DIRECT chain member, output
- * of the launch within reach of the Infinity Cache, and no other dataset of the problem needing the chain-prep launch
- * anyway), 0 when it is chain prep + emit, -1 on a bad id */
+ * of the launch within reach of the Infinity Cache), 0 when it is chain prep + emit, -1 on a bad id */
 int vg_dataset_single_launch(const vg_problem *p, int dataset_id);
 int vg_dataset_num_intrinsics(const vg_problem *p, int dataset_id);
 

@@ -4,4 +4,4 @@ sub-modules that compute needs visgeom_amd/lib/libvisgeom_amd.so (see __graft_en
 __version__ = "0.1.0"
 
 from . import capi  # noqa: F401
-from .problem import CalibrationProblem, GenericProjectionJac  # noqa: F401
+from .problem import BlockGroup, CalibrationProblem, GenericProjectionJac  # noqa: F401

@@ -70,6 +70,10 @@ SIGNATURES = {
     "vg_block_parameter_block_size": (ctypes.c_int, [_vp, ctypes.c_int]),
     "vg_block_evaluate": (ctypes.c_int, [_vp, _dpp, _dp, _dpp]),
     "vg_block_destroy": (None, [_vp]),
+    "vg_block_group_create": (ctypes.c_int, [_vpp, ctypes.c_int, ctypes.c_int]),
+    "vg_block_create_in_group": (ctypes.c_int, [_vpp, _vp, ctypes.c_int, ctypes.c_int, _ip, ctypes.c_int, _dp, _dp]),
+    "vg_block_group_stats": (ctypes.c_int, [_vp, _i64p, _i64p, _i64p, _i64p]),
+    "vg_block_group_destroy": (None, [_vp]),
     "vg_problem_create": (ctypes.c_int, [_vpp, ctypes.c_int, _vp]),
     "vg_problem_destroy": (None, [_vp]),
     "vg_problem_add_camera": (ctypes.c_int, [_vp, ctypes.c_int, _dp, ctypes.c_int, _ip]),

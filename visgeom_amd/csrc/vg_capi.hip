@@ -129,14 +129,11 @@ bool dataset_can_inline_chain(const vg_problem *p, const Dataset &d)
            d.n_blocks * (int64_t)d.N * (32 + 16 * (p->cams[d.camera].K + 6)) <= inline_chain_max_bytes();
 }
 
-// The in-kernel chain pays off when it REPLACES the chain-prep launch.  That launch serves all datasets of a problem
-// at once, so as soon as one dataset needs it (a multi-member chain, a very large set) the others read its frames too.
+// The route of a dataset is a property of THAT dataset (and of the test hook), never of its neighbours or of what ran
+// before: a block evaluated on its own, inside a block group or inside a rig problem gets the same bits.
 bool single_launch_dataset(const vg_problem *p, const Dataset &d)
 {
-    if (p->force_prepared_frames) return false;
-    for (const Dataset &o : p->dss)
-        if (o.n_blocks && !dataset_can_inline_chain(p, o)) return false;
-    return dataset_can_inline_chain(p, d);
+    return !p->force_prepared_frames && dataset_can_inline_chain(p, d);
 }
 
 void fill_emit_args(const vg_problem *p, const Dataset &d, vg::EmitArgs &a, int64_t b0, int64_t nb, double *residuals,
@@ -924,64 +921,80 @@ int vg_dataset_gram_sum(vg_problem *p, int dataset_id, const double *gram, doubl
 
 /* ------------------------------------------------------------------------------------------ per-block */
 
-int vg_block_create(vg_block **out, int device, int model, int chain_len, const int *status, int n_points,
-                    const double *grid, const double *obs)
+}  // extern "C"
+
+#include "vg_block_group.hpp"
+
+namespace {
+
+int block_new(vg_block **out, int device, int model, int chain_len, const int *status, int n_points, const double *grid,
+              const double *obs)
 {
     if (!out) return fail(VG_ERR_INVALID_ARGUMENT, "out is NULL");
     *out = nullptr;
     const int K = vg::num_intrinsics(model);
     if (K < 0) return fail(VG_ERR_INVALID_ARGUMENT, "unknown camera model");
     if (chain_len < 0 || chain_len > VG_MAX_CHAIN) return fail(VG_ERR_INVALID_ARGUMENT, "chain length must be in [0, 5]");
+    if (chain_len > 0 && !status) return fail(VG_ERR_INVALID_ARGUMENT, "status is NULL");
     if (n_points <= 0 || !grid || !obs) return fail(VG_ERR_INVALID_ARGUMENT, "empty block");
+    for (int l = 0; l < chain_len; l++)
+        if (status[l] != VG_TRANSFORM_DIRECT && status[l] != VG_TRANSFORM_INVERSE)
+            return fail(VG_ERR_INVALID_ARGUMENT, "status must be DIRECT or INVERSE");
+    int rc = check_device(device);
+    if (rc != VG_OK) return rc;
     vg_block *b = new (std::nothrow) vg_block();
     if (!b) return fail(VG_ERR_ALLOC, "out of host memory");
+    b->device = device;
     b->model = model;
     b->K = K;
     b->L = chain_len;
     b->N = n_points;
-    int rc = vg_problem_create(&b->p, device, nullptr);
+    for (int l = 0; l < chain_len; l++) b->status[l] = status[l];
+    b->h_grid.assign(grid, grid + 3 * (size_t)n_points);
+    b->h_obs.assign(obs, obs + 2 * (size_t)n_points);
+    b->used.assign((size_t)K + 6 * (size_t)chain_len, 0.);
+    *out = b;
+    return VG_OK;
+}
+
+}  // namespace
+
+// the block's own one-image problem and its staging buffers
+int vgg::ensure_private(vg_block *b)
+{
+    if (b->p) return VG_OK;
+    int rc = vg_problem_create(&b->p, b->device, nullptr);
     std::vector<double> zeros(VG_MAX_INTRINSICS, 0.);
     int cam = -1, ds = -1, tids[vg::kMaxChain] = {0};
-    if (rc == VG_OK) rc = vg_problem_add_camera(b->p, model, zeros.data(), 0, &cam);
-    for (int l = 0; l < chain_len && rc == VG_OK; l++) rc = vg_problem_add_transform(b->p, 1, 0, 1, nullptr, &tids[l]);
-    if (rc == VG_OK) rc = vg_problem_add_dataset(b->p, cam, chain_len, tids, status, n_points, grid, 1, nullptr, obs, &ds);
+    if (rc == VG_OK) rc = vg_problem_add_camera(b->p, b->model, zeros.data(), 0, &cam);
+    for (int l = 0; l < b->L && rc == VG_OK; l++) rc = vg_problem_add_transform(b->p, 1, 0, 1, nullptr, &tids[l]);
+    if (rc == VG_OK) rc = vg_problem_add_dataset(b->p, cam, b->L, tids, b->status, b->N, b->h_grid.data(), 1, nullptr, b->h_obs.data(), &ds);
     if (rc == VG_OK) rc = vg_problem_finalize(b->p);
     if (rc == VG_OK) {
-        const size_t rows = 2 * (size_t)n_points;
-        const size_t total = rows * (1 + (size_t)K + 6 * (size_t)chain_len);
+        const size_t rows = 2 * (size_t)b->N;
+        const size_t total = rows * (1 + (size_t)b->K + 6 * (size_t)b->L);
         hipError_t e = hipMalloc(&b->d_out, sizeof(double) * total);
         if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&b->h_out), sizeof(double) * total, hipHostMallocDefault);
         if (e == hipSuccess)
-            e = hipHostMalloc(reinterpret_cast<void **>(&b->h_params), sizeof(double) * ((size_t)K + 6 * (size_t)chain_len),
+            e = hipHostMalloc(reinterpret_cast<void **>(&b->h_params), sizeof(double) * ((size_t)b->K + 6 * (size_t)b->L),
                               hipHostMallocDefault);
         if (e != hipSuccess) rc = fail(VG_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
         else {
             b->d_res = b->d_out;
             b->d_jintr = b->d_out + rows;
-            for (int l = 0; l < chain_len; l++) b->d_jm[l] = b->d_out + rows * (1 + (size_t)K + 6 * (size_t)l);
+            for (int l = 0; l < b->L; l++) b->d_jm[l] = b->d_out + rows * (1 + (size_t)b->K + 6 * (size_t)l);
         }
     }
-    if (rc != VG_OK) {
-        vg_block_destroy(b);
-        return rc;
-    }
-    *out = b;
-    return VG_OK;
+    return rc;
 }
 
-int vg_block_num_residuals(const vg_block *b) { return b ? 2 * b->N : -1; }
-int vg_block_num_parameter_blocks(const vg_block *b) { return b ? 1 + b->L : -1; }
-int vg_block_parameter_block_size(const vg_block *b, int idx)
-{
-    if (!b || idx < 0 || idx > b->L) return -1;
-    return idx == 0 ? b->K : 6;
-}
+namespace {
 
-int vg_block_evaluate(vg_block *b, double const *const *parameters, double *residuals, double **jacobians)
+// one block on its own: H2D of its parameters, evaluation, D2H, synchronisation
+int block_evaluate_alone(vg_block *b, double const *const *parameters, double *residuals, double **jacobians)
 {
-    if (!b || !parameters || !residuals) return fail(VG_ERR_INVALID_ARGUMENT, "NULL argument");
-    for (int i = 0; i <= b->L; i++)
-        if (!parameters[i]) return fail(VG_ERR_INVALID_ARGUMENT, "NULL parameter block");
+    int rc = vgg::ensure_private(b);
+    if (rc != VG_OK) return rc;
     // parameter vector layout of the one-image problem: [intrinsics | member 0 | member 1 ...]
     std::memcpy(b->h_params, parameters[0], sizeof(double) * b->K);
     for (int l = 0; l < b->L; l++) std::memcpy(b->h_params + b->K + 6 * l, parameters[1 + l], sizeof(double) * 6);
@@ -990,7 +1003,6 @@ int vg_block_evaluate(vg_block *b, double const *const *parameters, double *resi
     hipStream_t s = p->stream;
     VG_HIP(hipMemcpyAsync(p->d_params, b->h_params, sizeof(double) * (size_t)p->n_params, hipMemcpyHostToDevice, s));
     p->frames_stale = true;  // new parameters: vg_dataset_evaluate rebuilds the frames (in-kernel for a single DIRECT member)
-    int rc = VG_OK;
     double *jm[vg::kMaxChain] = {nullptr};
     double *ji = nullptr;
     size_t last = 2 * (size_t)b->N;  // doubles to bring back: up to the end of the last requested block
@@ -1017,10 +1029,142 @@ int vg_block_evaluate(vg_block *b, double const *const *parameters, double *resi
     return VG_OK;
 }
 
+void group_unseal(vg_block_group *g)
+{
+    if (g->p) vg_problem_destroy(g->p);
+    g->p = nullptr;
+    (void)hipSetDevice(g->device);
+    if (g->d_out) (void)hipFree(g->d_out);
+    if (g->h_mirror) (void)hipHostFree(g->h_mirror);
+    if (g->h_params) (void)hipHostFree(g->h_params);
+    g->d_out = g->h_mirror = g->h_params = nullptr;
+    g->dss.clear();
+    g->sealed = false;
+    g->cooldown = 0;
+    for (vg_block *b : g->blocks) b->used_valid = false;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vg_block_create(vg_block **out, int device, int model, int chain_len, const int *status, int n_points,
+                    const double *grid, const double *obs)
+{
+    int rc = block_new(out, device, model, chain_len, status, n_points, grid, obs);
+    if (rc != VG_OK) return rc;
+    if ((rc = vgg::ensure_private(*out)) != VG_OK) {
+        vg_block_destroy(*out);
+        *out = nullptr;
+    }
+    return rc;
+}
+
+int vg_block_group_create(vg_block_group **out, int device, int mode)
+{
+    if (!out) return fail(VG_ERR_INVALID_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    if (mode != VG_GROUP_IN_PLACE && mode != VG_GROUP_STATE_VECTOR) return fail(VG_ERR_INVALID_ARGUMENT, "unknown group mode");
+    int rc = check_device(device);
+    if (rc != VG_OK) return rc;
+    vg_block_group *g = new (std::nothrow) vg_block_group();
+    if (!g) return fail(VG_ERR_ALLOC, "out of host memory");
+    g->device = device;
+    g->mode = mode;
+    *out = g;
+    return VG_OK;
+}
+
+int vg_block_create_in_group(vg_block **out, vg_block_group *g, int model, int chain_len, const int *status, int n_points,
+                             const double *grid, const double *obs)
+{
+    if (!g) return fail(VG_ERR_INVALID_ARGUMENT, "group is NULL");
+    int rc = block_new(out, g->device, model, chain_len, status, n_points, grid, obs);
+    if (rc != VG_OK) return rc;
+    if (g->sealed) group_unseal(g);  // a new member: the resident problem is rebuilt once it has been seen
+    (*out)->group = g;
+    g->blocks.push_back(*out);
+    return VG_OK;
+}
+
+int vg_block_group_stats(const vg_block_group *g, int64_t *n_blocks, int64_t *batched_evaluations, int64_t *served, int64_t *alone)
+{
+    if (!g) return fail(VG_ERR_INVALID_ARGUMENT, "group is NULL");
+    if (n_blocks) *n_blocks = (int64_t)g->blocks.size();
+    if (batched_evaluations) *batched_evaluations = (int64_t)g->n_batched;
+    if (served) *served = (int64_t)g->n_served;
+    if (alone) *alone = (int64_t)g->n_alone;
+    return VG_OK;
+}
+
+void vg_block_group_destroy(vg_block_group *g)
+{
+    if (!g) return;
+    group_unseal(g);
+    for (vg_block *b : g->blocks) b->group = nullptr;  // surviving blocks fall back to the per-block path
+    delete g;
+}
+
+int vg_block_num_residuals(const vg_block *b) { return b ? 2 * b->N : -1; }
+int vg_block_num_parameter_blocks(const vg_block *b) { return b ? 1 + b->L : -1; }
+int vg_block_parameter_block_size(const vg_block *b, int idx)
+{
+    if (!b || idx < 0 || idx > b->L) return -1;
+    return idx == 0 ? b->K : 6;
+}
+
+int vg_block_evaluate(vg_block *b, double const *const *parameters, double *residuals, double **jacobians)
+{
+    if (!b || !parameters || !residuals) return fail(VG_ERR_INVALID_ARGUMENT, "NULL argument");
+    for (int i = 0; i <= b->L; i++)
+        if (!parameters[i]) return fail(VG_ERR_INVALID_ARGUMENT, "NULL parameter block");
+    vg_block_group *g = b->group;
+    if (!g) return block_evaluate_alone(b, parameters, residuals, jacobians);
+    bool want_jac = false;
+    if (jacobians)
+        for (int i = 0; i <= b->L; i++) want_jac = want_jac || jacobians[i] != nullptr;
+    int rc;
+    if (!g->sealed) {
+        // first pass: every block is seen once on its own and bound to the pointers it was called with
+        if ((rc = block_evaluate_alone(b, parameters, residuals, jacobians)) != VG_OK) return rc;
+        g->n_alone++;
+        vgg::bind(g, b, parameters);
+        if (g->n_bound == (int)g->blocks.size() && (rc = vgg::seal(g)) != VG_OK) {
+            group_unseal(g);  // the group stays usable, block by block
+            g->n_bound = -1;  // ... and does not try again
+            return VG_OK;
+        }
+        return VG_OK;
+    }
+    if (!(vgg::params_match(b, parameters) && (!want_jac || g->point_has_jac)) && vgg::worth_a_pass(g, b, parameters)) {
+        // a new evaluation point (or the Jacobians of a point that so far only had its cost evaluated): one pass over
+        // ALL blocks of the group, at the parameter values the other blocks are expected to be called with
+        if ((rc = vgg::evaluate_all(g, b, parameters, want_jac)) != VG_OK) return rc;
+    }
+    if (vgg::params_match(b, parameters) && (!want_jac || g->point_has_jac)) {
+        vgg::serve(g, b, residuals, jacobians);
+        g->n_served++;
+        g->served_since_batch++;
+    } else {
+        // the prediction of this block's parameters was wrong (a host that does not keep the layout the mode assumes)
+        if ((rc = block_evaluate_alone(b, parameters, residuals, jacobians)) != VG_OK) return rc;
+        g->n_alone++;
+    }
+    vgg::bind(g, b, parameters);
+    return VG_OK;
+}
+
 void vg_block_destroy(vg_block *b)
 {
     if (!b) return;
-    if (b->p) (void)hipSetDevice(b->p->device);
+    if (b->group) {
+        vg_block_group *g = b->group;
+        if (g->sealed) group_unseal(g);
+        g->blocks.erase(std::remove(g->blocks.begin(), g->blocks.end(), b), g->blocks.end());
+        if (b->is_bound && g->n_bound > 0) g->n_bound--;
+        if (b->calls >= 2 && g->n_known > 0) g->n_known--;
+    }
+    (void)hipSetDevice(b->device);
     if (b->d_out) (void)hipFree(b->d_out);
     if (b->h_out) (void)hipHostFree(b->h_out);
     if (b->h_params) (void)hipHostFree(b->h_params);

@@ -93,17 +93,29 @@ struct vg_problem {
     bool force_prepared_frames = false;
 };
 
+struct vg_block_group;
+
 struct vg_block {
-    vg_problem *p = nullptr;
+    vg_problem *p = nullptr;  // the block's own one-image problem (created on first use when the block is in a group)
+    int device = 0;
     int model = 0, K = 0, L = 0, N = 0;
+    int status[vg::kMaxChain] = {0};
+    std::vector<double> h_grid, h_obs;  // kept for the private problem / the group's resident problem
     // one device allocation [res | jac_intr | jac_member 0 | ...] and one pinned host mirror of it: a call is one
     // H2D of the parameters, two launches, ONE D2H and one synchronisation
     double *d_out = nullptr, *h_out = nullptr;
     double *d_res = nullptr, *d_jintr = nullptr;
     double *d_jm[vg::kMaxChain] = {nullptr};
     double *h_params = nullptr;  // pinned, K + 6L doubles
+    // ---- membership in a vg_block_group (vg_block_group.hpp)
+    vg_block_group *group = nullptr;
+    int g_ds = -1, g_idx = -1;
+    const double *bound[1 + vg::kMaxChain] = {nullptr};  // parameter pointers of the last call
+    bool moves[1 + vg::kMaxChain] = {false};             // ... that pointer has differed between two calls
+    bool is_bound = false, used_valid = false;
+    int calls = 0;                                       // evaluations seen (saturates at 2: from then on `moves` is known)
+    std::vector<double> used;                            // parameter values the group's last pass used for this block
 };
-
 
 namespace vgi {
 // kernel launches on an explicit parameter buffer (the solver evaluates candidate points without

@@ -24,6 +24,37 @@ def _ptr(a):
     return a.ctypes.data_as(_dp)
 
 
+class BlockGroup:
+    """vg_block_group: blocks created against it share one resident problem; the first Evaluate at a new parameter
+    point evaluates all of them in one pass, the others copy their rows out (include/visgeom_amd.h, "block groups").
+    mode: "in_place" or "state_vector" (ceres::Solve's candidate points in a fixed-layout state array)."""
+
+    MODES = {"in_place": 0, "state_vector": 1}
+
+    def __init__(self, device=0, mode="in_place"):
+        self._lib = capi.load()
+        h = ctypes.c_void_p()
+        capi.check(self._lib.vg_block_group_create(ctypes.byref(h), device, self.MODES[mode]))
+        self._h = h
+        self.device = device
+
+    def stats(self):
+        v = [ctypes.c_int64(0) for _ in range(4)]
+        capi.check(self._lib.vg_block_group_stats(self._h, *[ctypes.byref(x) for x in v]))
+        return dict(zip(("blocks", "batched", "served", "alone"), (x.value for x in v)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.vg_block_group_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class GenericProjectionJac:
     """One residual block = one image of one camera.
 
@@ -32,7 +63,7 @@ class GenericProjectionJac:
     on the GPU through vg_block_evaluate.
     """
 
-    def __init__(self, proj, grid, model, transform_status_vec, device=0):
+    def __init__(self, proj, grid, model, transform_status_vec, device=0, group=None):
         L = capi.load()
         self._lib = L
         self.model = capi.MODELS[model] if isinstance(model, str) else int(model)
@@ -45,8 +76,12 @@ class GenericProjectionJac:
         self.N = grid.shape[0]
         st = (ctypes.c_int * max(len(self.status), 1))(*self.status)
         h = ctypes.c_void_p()
-        capi.check(L.vg_block_create(ctypes.byref(h), device, self.model, len(self.status), st, self.N,
-                                     _ptr(grid), _ptr(proj)))
+        if group is not None:
+            capi.check(L.vg_block_create_in_group(ctypes.byref(h), group._h, self.model, len(self.status), st, self.N,
+                                                  _ptr(grid), _ptr(proj)))
+        else:
+            capi.check(L.vg_block_create(ctypes.byref(h), device, self.model, len(self.status), st, self.N,
+                                         _ptr(grid), _ptr(proj)))
         self._h = h
 
     def parameter_block_sizes(self):
@@ -59,8 +94,9 @@ class GenericProjectionJac:
     def Evaluate(self, params, want_jacobians=True, jac_mask=None):
         """params = [intrinsics, xi_0 .. xi_{L-1}] -> (residual[2N], list of row-major Jacobians or None).
         jac_mask[b] False passes a NULL pointer for block b (constant parameter block)."""
-        sizes = self.parameter_block_sizes()
-        ps = [_c(p) for p in params]
+        sizes = getattr(self, "_sizes", None) or self.parameter_block_sizes()
+        self._sizes = sizes
+        ps = [_c(p) for p in params]  # contiguous float64 views are passed as they are: the pointers are the caller's
         if len(ps) != len(sizes) or any(p.size != s for p, s in zip(ps, sizes)):
             raise ValueError("parameter blocks must have sizes %s" % sizes)
         pp = (_dp * len(ps))(*[_ptr(p) for p in ps])
