@@ -64,22 +64,30 @@ struct SchurArgs {
     int G;
     int n_poses;
     double mu, dmin, dmax;
+    const double *mu_dev;  // device loop: the damping parameter lives in the LM state (overrides mu when not NULL)
     double *rec;           // [n_poses][kPoseRec]
     double *rows;          // [n_poses * 6][G + 1]
     int *bad;              // number of poses whose damped block was not positive definite
 };
 
-// step 1 of the elimination, one lane per pose: V_i, g_i from the Gram blocks, damping, 6x6 Cholesky -> rec
-__global__ __launch_bounds__(64) void vg_pose_factor_kernel(SchurArgs a)
+// The elimination of pose i: V_i, g_i gathered from the Gram blocks of every dataset that references the pose, damping,
+// 6 x 6 Cholesky.  Evaluated by EVERY lane of the pose in the rows kernel below (a 6 x 6 factorisation is ~150
+// instructions; a separate one-lane-per-pose launch in front of the rows kernel cost 9 us of launch + latency per
+// iteration for a few microseconds of arithmetic).
+struct PoseFactor {
+    double L[21], gp[6], vd[6];
+    bool active, pd;
+    unsigned char mode;
+};
+
+__device__ __forceinline__ void pose_factor(const SchurArgs &a, int i, PoseFactor &f)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.n_poses) return;
     const int r0 = a.ref_ptr[i], r1 = a.ref_ptr[i + 1];
-    double V[21], gp[6], vd[6];
+    double V[21];
 #pragma unroll
     for (int k = 0; k < 21; k++) V[k] = 0.;
 #pragma unroll
-    for (int k = 0; k < 6; k++) gp[k] = 0.;
+    for (int k = 0; k < 6; k++) f.gp[k] = 0.;
     for (int q = r0; q < r1; q++) {
         const SolveDatasetDev D = a.ds[a.ref_ds[q]];
         const double *Gb = D.gram + (size_t)a.ref_blk[q] * D.W * D.W;
@@ -88,75 +96,58 @@ __global__ __launch_bounds__(64) void vg_pose_factor_kernel(SchurArgs a)
         for (int r = 0; r < 6; r++) {
 #pragma unroll
             for (int c = 0; c <= r; c++) V[tri(r, c)] += Gb[(o + r) * D.W + o + c];
-            gp[r] += Gb[(o + r) * D.W + D.W - 1];
+            f.gp[r] += Gb[(o + r) * D.W + D.W - 1];
         }
     }
     // pose_frozen: 0 = eliminated here, 1 = constant, 2 = belongs to a sequence coupled by OdometryPrior blocks:
     // its raw V_i / g_i go to the record and the host eliminates the whole sequence as a block-tridiagonal system
-    const unsigned char mode = a.pose_frozen[i];
-    if (mode == 2) {
-        double *rec = a.rec + (size_t)i * kPoseRec;
+    f.mode = a.pose_frozen[i];
+    f.pd = true;
+    if (f.mode == 2) {
 #pragma unroll
-        for (int k = 0; k < 21; k++) rec[k] = V[k];
+        for (int k = 0; k < 21; k++) f.L[k] = V[k];
 #pragma unroll
-        for (int k = 0; k < 6; k++) {
-            rec[21 + k] = gp[k];
-            rec[27 + k] = V[tri(k, k)];
-        }
-        rec[33] = 0.;
+        for (int k = 0; k < 6; k++) f.vd[k] = V[tri(k, k)];
+        f.active = false;
         return;
     }
-    bool active = mode == 0 && r1 > r0;
+    f.active = f.mode == 0 && r1 > r0;
+    const double mu = a.mu_dev ? *a.mu_dev : a.mu;
 #pragma unroll
     for (int r = 0; r < 6; r++) {
-        vd[r] = V[tri(r, r)];
-        V[tri(r, r)] += a.mu * clampd(vd[r], a.dmin, a.dmax);
+        f.vd[r] = V[tri(r, r)];
+        V[tri(r, r)] += mu * clampd(f.vd[r], a.dmin, a.dmax);
     }
     // in-place Cholesky, packed lower
-    double L[21];
-    bool pd = true;
 #pragma unroll
     for (int r = 0; r < 6; r++) {
 #pragma unroll
         for (int c = 0; c <= r; c++) {
             double s = V[tri(r, c)];
 #pragma unroll
-            for (int k = 0; k < c; k++) s -= L[tri(r, k)] * L[tri(c, k)];
+            for (int k = 0; k < c; k++) s -= f.L[tri(r, k)] * f.L[tri(c, k)];
             if (r == c) {
-                if (!(s > 0.)) { pd = false; s = 1.; }
-                L[tri(r, r)] = sqrt(s);
+                if (!(s > 0.)) { f.pd = false; s = 1.; }
+                f.L[tri(r, r)] = sqrt(s);
             } else {
-                L[tri(r, c)] = s / L[tri(c, c)];
+                f.L[tri(r, c)] = s / f.L[tri(c, c)];
             }
         }
     }
-    if (active && !pd) {
-        atomicAdd(a.bad, 1);
-        active = false;
-    }
-    double *rec = a.rec + (size_t)i * kPoseRec;
-#pragma unroll
-    for (int k = 0; k < 21; k++) rec[k] = L[k];
-#pragma unroll
-    for (int k = 0; k < 6; k++) {
-        rec[21 + k] = gp[k];
-        rec[27 + k] = vd[k];
-    }
-    rec[33] = active ? 1. : 0.;
+    if (f.active && !f.pd) f.active = false;
 }
 
-// step 2, one lane per (pose, global column): column gcol of the six rows  L^-1 W_i^T  (gcol == G: L^-1 g_i)
+// one lane per (pose, global column): column gcol of the six rows  L^-1 W_i^T  (gcol == G: L^-1 g_i; that lane also
+// leaves the pose's record [L | g | diag V | active] for the back-substitution and counts non-positive-definite blocks)
 __global__ __launch_bounds__(256) void vg_schur_rows_kernel(SchurArgs a)
 {
     const int C = a.G + 1;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long long)a.n_poses * C) return;
     const int i = (int)(t / C), gcol = (int)(t - (long long)i * C);
-    const double *rec = a.rec + (size_t)i * kPoseRec;
-    double L[21], w[6], y[6];
-#pragma unroll
-    for (int k = 0; k < 21; k++) L[k] = rec[k];
-    const bool active = rec[33] != 0.;
+    PoseFactor f;
+    pose_factor(a, i, f);
+    double w[6], y[6];
     if (gcol < a.G) {
 #pragma unroll
         for (int c = 0; c < 6; c++) w[c] = 0.;
@@ -172,17 +163,27 @@ __global__ __launch_bounds__(256) void vg_schur_rows_kernel(SchurArgs a)
         }
     } else {
 #pragma unroll
-        for (int c = 0; c < 6; c++) w[c] = rec[21 + c];
+        for (int c = 0; c < 6; c++) w[c] = f.gp[c];
+        double *rec = a.rec + (size_t)i * kPoseRec;
+#pragma unroll
+        for (int k = 0; k < 21; k++) rec[k] = f.L[k];
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            rec[21 + k] = f.gp[k];
+            rec[27 + k] = f.vd[k];
+        }
+        rec[33] = f.active ? 1. : 0.;
+        if (f.mode == 0 && !f.pd && a.ref_ptr[i + 1] > a.ref_ptr[i]) atomicAdd(a.bad, 1);
     }
-    fwd6(L, w, y);
     double *out = a.rows + (size_t)i * 6 * C + gcol;
-    if (a.pose_frozen[i] == 2) {  // host-eliminated sequence: hand over the raw column of W_i^T (last column: g_i)
+    if (f.mode == 2) {  // host-eliminated sequence: hand over the raw column of W_i^T (last column: g_i)
 #pragma unroll
         for (int k = 0; k < 6; k++) out[k * C] = w[k];
         return;
     }
+    fwd6(f.L, w, y);
 #pragma unroll
-    for (int k = 0; k < 6; k++) out[k * C] = active ? y[k] : 0.;
+    for (int k = 0; k < 6; k++) out[k * C] = f.active ? y[k] : 0.;
 }
 
 // ceres::SoftLOneLoss(a) on one residual block = one image: rho(s) = 2 a^2 (sqrt(1 + s / a^2) - 1), s = r^T r.
@@ -209,6 +210,8 @@ struct BacksubArgs {
     unsigned long long *gmax_bits; // max |gp| over active poses, as the bit pattern of a non-negative double
     const double *x;               // current parameter vector
     double *xg;                    // [G] current values of the global columns (gathered for the host)
+    const double *lo, *hi;         // box of every parameter
+    double *x_new;                 // clamp(x + delta, lo, hi) of the global columns and of this kernel's poses
 };
 
 // dp_i = -V_i'^-1 (g_i + W_i^T dg) = -L^-T (L^-1 g_i + (L^-1 W_i^T) dg): everything needed is already in the
@@ -228,8 +231,10 @@ __global__ __launch_bounds__(kBsThreads) void vg_backsub_kernel(BacksubArgs b)
     const SchurArgs &a = b.s;
     const int t = blockIdx.x * kBsThreads + threadIdx.x;
     if (t < a.G) {
-        b.delta[b.gcol_param[t]] = b.dg[t];
-        b.xg[t] = b.x[b.gcol_param[t]];
+        const long long gp = b.gcol_param[t];
+        b.delta[gp] = b.dg[t];
+        b.xg[t] = b.x[gp];
+        b.x_new[gp] = clampd(b.x[gp] + b.dg[t], b.lo[gp], b.hi[gp]);
     }
     if ((int)(blockIdx.x * kBsPosesPerBlock) >= a.n_poses) return;  // workgroups that only carry global columns
     const int gl = threadIdx.x & (kBsGroup - 1), grp = threadIdx.x >> 4;
@@ -288,6 +293,7 @@ __global__ __launch_bounds__(kBsThreads) void vg_backsub_kernel(BacksubArgs b)
             for (int c = 0; c < 6; c++) {
                 const double v = active ? -x[c] : 0.;
                 dp[c] = v;
+                b.x_new[pp + c] = clampd(xk[c] + v, b.lo[pp + c], b.hi[pp + c]);  // the candidate point (poses are unbounded: x + dp)
                 const double g = gk[c];
                 s0 += g * v;
                 s1 += clampd(dk[c], a.dmin, a.dmax) * v * v;

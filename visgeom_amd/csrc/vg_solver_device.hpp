@@ -1,0 +1,299 @@
+// vg_solver_device.hpp -- the two small kernels that keep a Levenberg-Marquardt iteration on the device
+// (vg_solver_impl.hpp, "device loop"): the reduced (Schur) system with the active set of the box bounds, and the step
+// acceptance / trust-region / convergence logic of Ceres' minimizer (what ceres::Solve does between two evaluations,
+// src/calibration/unified_calibration.cpp:42-53 for the options).  With them an iteration is a fixed sequence of
+// launches (+ two in-place RCCL all-reduces when sharded) and ONE host synchronisation -- the host only learns whether
+// the step was accepted (it swaps the current / candidate buffers) and whether the solve is over.
+// Both kernels are one workgroup: G <= 127 global columns.  Same arithmetic, in the same order, as the host versions
+// they replace (chol_solve and the loop body of vg_problem_solve), so both loops walk the same iterates.
+#pragma once
+
+#include "vg_solver.hpp"
+
+namespace vg {
+
+struct LmState {
+    double radius, decrease_factor, mu;
+    double cost2, cost2_c;            // twice the cost at the current point / at the last candidate
+    double grad_max, step_norm, rho, cost_change, model_change;
+    int ucur;                          // which of the two U / g slots belongs to the current point
+    int step_ok, accepted, done, term, iter, n_success, n_bad;
+};
+
+struct LmSolveArgs {
+    LmState *st;
+    const double *U;      // [2][G*G]
+    const double *gg;     // [2][G]
+    const double *rgram;  // [(G+1)*(G+1)] Gram of the pose rows [L^-1 W^T | L^-1 g], summed over poses (and ranks)
+    const double *lo, *hi;             // [G] box of every global column
+    const unsigned char *gfrozen;      // [G] constant parameter blocks
+    const double *xcur;                // [G] values of the global columns at the current point
+    double *dg;                        // [G] out: global step
+    double *S;                         // [G*G] global scratch for the damped reduced matrix, or NULL: it fits the LDS too
+    int G, use_bounds;
+    double dmin, dmax;
+};
+
+constexpr int kLmThreads = 256;
+
+// dynamic LDS: A [G*G] | rhs [G] | b [G] | x [G] | held [G] (as double) ... + 2 flags
+// Launched with ONE wave (64 threads) up to 64 columns -- the factorisation is a chain of G dependent column steps,
+// and a workgroup barrier per step costs more than the step: 64 us at G = 45 with 256 threads, most of it barriers --
+// and with 256 threads above.
+__device__ __forceinline__ void lm_sync()
+{
+    if (blockDim.x == kWave) {  // one wave: its DS operations execute in order, only the compiler needs fencing
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(kLmThreads) void vg_lm_reduced_solve_kernel(LmSolveArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int G = a.G, C = G + 1, tid = threadIdx.x;
+    const int kT = blockDim.x;
+    LmState *st = a.st;
+    if (st->done) return;
+    double *A = sm, *rhs = A + (size_t)G * G, *b = rhs + G, *x = b + G, *heldf = x + G, *flags = heldf + G;
+    double *S = a.S ? a.S : flags + 2;  // the damped matrix survives the active-set passes: LDS when both fit
+    const double mu = st->mu;
+    const double *U = a.U + (size_t)st->ucur * G * G, *gg = a.gg + (size_t)st->ucur * G;
+    for (int i = tid; i < G * G; i += kT) {
+        const int r = i / G, c = i - r * G;
+        double v = U[i] - a.rgram[(size_t)r * C + c];
+        if (r == c) v += mu * clampd(U[i], a.dmin, a.dmax);
+        S[i] = v;
+    }
+    for (int r = tid; r < G; r += kT) {
+        rhs[r] = -gg[r] + a.rgram[(size_t)r * C + G];
+        heldf[r] = a.gfrozen[r] ? 1. : 0.;
+    }
+    if (tid == 0) flags[0] = 1.;  // step_ok
+    lm_sync();
+    // Constant blocks, and the active set of the box bounds: a parameter ON a bound whose step points outwards is held
+    // (row and column leave the reduced system); re-solved until the set is stable.
+    for (int pass = 0; pass <= G; pass++) {
+        for (int i = tid; i < G * G; i += kT) {
+            const int r = i / G, c = i - r * G;
+            const bool h = heldf[r] != 0. || heldf[c] != 0.;
+            A[i] = h ? (r == c ? 1. : 0.) : S[i];
+        }
+        for (int r = tid; r < G; r += kT) b[r] = heldf[r] != 0. ? 0. : rhs[r];
+        lm_sync();
+        // Cholesky, lower triangle in place (right-looking; every entry sees its subtractions in increasing column
+        // order, as the host's row-oriented version does)
+        for (int j = 0; j < G; j++) {
+            if (tid == 0) {
+                const double d = A[(size_t)j * G + j];
+                if (!(d > 0.) || !isfinite(d)) flags[0] = 0.;
+                A[(size_t)j * G + j] = sqrt(d > 0. ? d : 1.);
+            }
+            lm_sync();
+            const double djj = A[(size_t)j * G + j];
+            for (int i = j + 1 + tid; i < G; i += kT) A[(size_t)i * G + j] /= djj;
+            lm_sync();
+            for (int i = j + 1 + tid; i < G; i += kT) {  // a row per lane: no index arithmetic, column j is a broadcast read
+                const double lij = A[(size_t)i * G + j];
+                for (int k = j + 1; k <= i; k++) A[(size_t)i * G + k] -= lij * A[(size_t)k * G + j];
+            }
+            lm_sync();
+        }
+        // L y = b, L^T x = y
+        for (int j = 0; j < G; j++) {
+            if (tid == 0) b[j] = b[j] / A[(size_t)j * G + j];
+            lm_sync();
+            const double yj = b[j];
+            for (int i = j + 1 + tid; i < G; i += kT) b[i] -= A[(size_t)i * G + j] * yj;
+            lm_sync();
+        }
+        for (int j = G - 1; j >= 0; j--) {
+            if (tid == 0) x[j] = b[j] / A[(size_t)j * G + j];
+            lm_sync();
+            const double xj = x[j];
+            for (int i = tid; i < j; i += kT) b[i] -= A[(size_t)j * G + i] * xj;
+            lm_sync();
+        }
+        if (tid == 0) flags[1] = 0.;  // changed
+        lm_sync();
+        if (flags[0] != 0. && a.use_bounds)
+            for (int r = tid; r < G; r += kT) {
+                if (heldf[r] != 0.) continue;
+                if ((a.xcur[r] <= a.lo[r] && x[r] < 0.) || (a.xcur[r] >= a.hi[r] && x[r] > 0.)) {
+                    heldf[r] = 1.;
+                    flags[1] = 1.;
+                }
+            }
+        lm_sync();
+        if (flags[1] == 0. || flags[0] == 0.) break;
+        lm_sync();
+    }
+    for (int r = tid; r < G; r += kT) a.dg[r] = x[r];
+    if (tid == 0) st->step_ok = (G == 0 || flags[0] != 0.) ? 1 : 0;
+}
+
+struct LmAcceptArgs {
+    LmState *st;
+    double *U, *gg;                    // [2][G*G], [2][G]
+    const double *sums;                // [n_ds][Wmax*Wmax] summed Gram blocks | [5] scalar sums of the step
+    const int *inv;                    // [n_ds][G] global column -> local column of that dataset or -1
+    const int *Wd;                     // [n_ds]
+    const double *dg;                  // [G]
+    unsigned long long *gmax_bits;     // max |g_pose| (bit pattern); reset here
+    int *bad;                          // poses whose damped block was not positive definite; reset here
+    double *xcur;                      // [G] global values at the current point (updated on acceptance)
+    const double *x;                   // init: the parameter vector, to gather xcur
+    const long long *gcol_param;       // [G]
+    const double *lo, *hi;
+    const unsigned char *gfrozen;
+    int n_ds, Wmax, G, init, multi_rank;
+    size_t lds_doubles;                // dynamic LDS given to the launch, in doubles
+    double dmin, dmax, ftol, gtol, ptol, min_rel_decrease, max_radius, min_radius;
+};
+
+__global__ __launch_bounds__(kLmThreads) void vg_lm_accept_kernel(LmAcceptArgs a)
+{
+    const int G = a.G, tid = threadIdx.x;
+    LmState *st = a.st;
+    if (st->done) return;
+    const int slot = a.init ? st->ucur : 1 - st->ucur;  // where the freshly evaluated point's blocks go
+    double *Uc = a.U + (size_t)slot * G * G, *gc = a.gg + (size_t)slot * G;
+    const size_t WW = (size_t)a.Wmax * a.Wmax;
+    // the column maps and the summed blocks are read many times: staged in LDS when they fit (a handful of datasets)
+    extern __shared__ __attribute__((aligned(16))) double sm_acc[];
+    const bool staged = a.lds_doubles >= (size_t)a.n_ds * WW + ((size_t)a.n_ds * G + 1) / 2 + 1;
+    const double *sums = a.sums;
+    const int *inv = a.inv;
+    if (staged) {
+        double *s_sums = sm_acc;
+        int *s_inv = reinterpret_cast<int *>(sm_acc + (size_t)a.n_ds * WW);
+        for (size_t i = tid; i < (size_t)a.n_ds * WW; i += kLmThreads) s_sums[i] = a.sums[i];
+        for (int i = tid; i < a.n_ds * G; i += kLmThreads) s_inv[i] = a.inv[i];
+        __syncthreads();
+        sums = s_sums;
+        inv = s_inv;
+    }
+    // U, g of the evaluated point from the per-dataset sums, dataset after dataset (the order the host uses)
+    for (int i = tid; i < G * G; i += kLmThreads) {
+        const int ga = i / G, gb = i - ga * G;
+        double s = 0.;
+        for (int d = 0; d < a.n_ds; d++) {
+            const int la = inv[d * G + ga], lb = inv[d * G + gb], W = a.Wd[d];
+            if (la >= 0 && lb >= 0) s += sums[d * WW + (size_t)la * W + lb];
+        }
+        Uc[i] = s;
+    }
+    for (int ga = tid; ga < G; ga += kLmThreads) {
+        double s = 0.;
+        for (int d = 0; d < a.n_ds; d++) {
+            const int la = inv[d * G + ga], W = a.Wd[d];
+            if (la >= 0) s += sums[d * WW + (size_t)la * W + W - 1];
+        }
+        gc[ga] = s;
+        if (a.init) a.xcur[ga] = a.x[a.gcol_param[ga]];
+    }
+    // everything the scalar logic reads, staged once (a dependent global load per loop step made this kernel 41 us at
+    // G = 45): current U diagonal / g, the step, the current global values, their box
+    __shared__ double s_ud[128], s_g[128], s_dg[128], s_x[128], s_lo[128], s_hi[128];
+    __shared__ unsigned char s_fz[128];
+    {
+        const double *Ucur = a.U + (size_t)st->ucur * G * G, *gcur = a.gg + (size_t)st->ucur * G;
+        for (int k = tid; k < G; k += kLmThreads) {
+            s_ud[k] = a.init ? 0. : Ucur[(size_t)k * G + k];
+            s_g[k] = a.init ? 0. : gcur[k];
+            s_dg[k] = a.dg[k];
+            s_x[k] = a.init ? 0. : a.xcur[k];
+            s_lo[k] = a.lo[k];
+            s_hi[k] = a.hi[k];
+            s_fz[k] = a.gfrozen[k];
+        }
+    }
+    __syncthreads();
+    if (tid != 0) return;
+    double cost2_c = 0.;
+    for (int d = 0; d < a.n_ds; d++) cost2_c += a.sums[d * WW + (size_t)a.Wd[d] * a.Wd[d] - 1];
+    if (a.init) {
+        st->cost2 = cost2_c;
+        st->mu = 1. / st->radius;
+        return;
+    }
+    st->cost2_c = cost2_c;
+    const double *sc = a.sums + (size_t)a.n_ds * WW;
+    const int n_bad = *a.bad;
+    *a.bad = 0;
+    double gmax_p = __longlong_as_double((long long)*a.gmax_bits);
+    *a.gmax_bits = 0ull;
+    st->n_bad += n_bad;
+    const bool step_ok = st->step_ok != 0 && n_bad == 0;
+    const double mu = st->mu;
+    double rho = 0., step2 = 0., cost_change = 0., model_change = 0.;
+    st->iter++;
+    if (step_ok) {
+        double xg2 = 0.;
+        for (int k = 0; k < G; k++) xg2 += s_x[k] * s_x[k];
+        const double gdp = sc[0], ddp = sc[1], dp2 = sc[2], gp2 = sc[3], xp2 = sc[4];
+        // several ranks take the same branches only on summable quantities: the pose part of the gradient max-norm is
+        // replaced by its 2-norm (an upper bound: the gradient test can only fire later than Ceres', never earlier)
+        if (a.multi_rank) gmax_p = sqrt(gp2);
+        double gdg = 0., ddg = 0., dg2 = 0., gmax_g = 0.;
+        for (int k = 0; k < G; k++) {
+            if (s_fz[k]) continue;
+            const double dcl = clampd(s_ud[k], a.dmin, a.dmax);
+            gdg += s_g[k] * s_dg[k];
+            ddg += dcl * s_dg[k] * s_dg[k];
+            dg2 += s_dg[k] * s_dg[k];
+            // projected gradient for bounded parameters: |Project(x - g) - x|
+            const double xv = s_x[k];
+            const double xp = clampd(xv - s_g[k], s_lo[k], s_hi[k]);
+            gmax_g = fmax(gmax_g, fabs(xp - xv));
+        }
+        st->grad_max = fmax(gmax_g, gmax_p);
+        model_change = 0.5 * (mu * (ddg + ddp) - (gdg + gdp));  // 1/2 delta^T (mu D delta - g)
+        step2 = dg2 + dp2;
+        cost_change = 0.5 * (st->cost2 - cost2_c);
+        rho = model_change > 0. ? cost_change / model_change : -1.;
+        if (st->grad_max <= a.gtol) {
+            st->term = VG_TERM_CONVERGENCE_GRADIENT;
+            st->done = 1;
+        } else if (sqrt(step2) <= a.ptol * (sqrt(xg2 + xp2) + a.ptol)) {
+            st->term = VG_TERM_CONVERGENCE_PARAMETER;
+            st->done = 1;
+        }
+    }
+    st->rho = rho;
+    st->step_norm = sqrt(step2);
+    st->cost_change = cost_change;
+    st->model_change = model_change;
+    st->accepted = 0;
+    if (st->done) return;
+    const bool success = step_ok && isfinite(cost2_c) && rho > a.min_rel_decrease;
+    if (success) {
+        st->n_success++;
+        st->accepted = 1;
+        st->ucur = 1 - st->ucur;
+        for (int k = 0; k < G; k++) a.xcur[k] = clampd(s_x[k] + s_dg[k], s_lo[k], s_hi[k]);  // what the step kernel wrote
+        const double prev = st->cost2;
+        st->cost2 = cost2_c;
+        const double t = 2. * rho - 1.;
+        const double f = 1. - t * t * t;
+        st->radius = fmin(st->radius / fmax(f, 1. / 3.), a.max_radius);
+        st->decrease_factor = 2.;
+        if (fabs(prev - cost2_c) <= a.ftol * prev) {
+            st->term = VG_TERM_CONVERGENCE_FUNCTION;
+            st->done = 1;
+        }
+    } else {
+        st->radius /= st->decrease_factor;
+        st->decrease_factor *= 2.;
+        if (st->radius < a.min_radius) {
+            st->term = VG_TERM_RADIUS_TOO_SMALL;
+            st->done = 1;
+        }
+    }
+    st->mu = 1. / st->radius;
+}
+
+}  // namespace vg

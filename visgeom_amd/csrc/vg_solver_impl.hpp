@@ -11,6 +11,7 @@
 
 #include "vg_internal.hpp"
 #include "vg_solver.hpp"
+#include "vg_solver_device.hpp"
 #include "vg_transf_host.hpp"
 
 using vgi::fail;
@@ -617,10 +618,9 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
         VG_TRY(d_sumA.upload(ta));
         VG_TRY(d_sumB.upload(tb));
     }
-    // evaluate the Gram matrices at a device parameter buffer into gram set `set`, assemble U / gg / cost
-    auto evaluate = [&](const double *x_dev, DevBuf<double> *set, std::vector<double> &Uo, std::vector<double> &go,
-                        double &cost2) -> int {
-        const double t0 = now_s();
+    // queue the evaluation of the Gram matrices at a device parameter buffer into gram set `set`, their fixed-order sums
+    // into d_sums and the ONE collective of an evaluation (no host synchronisation)
+    auto enqueue_evaluate = [&](const double *x_dev, DevBuf<double> *set) -> int {
         int r;
         if (vgi::gram_needs_frames(p) && (r = vgi::prepare_at(p, x_dev)) != VG_OK) return r;
         for (int d = 0; d < n_ds; d++) {
@@ -649,7 +649,14 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             VG_HIP(hipGetLastError());
         }
         // the ONE collective of an evaluation: [summed Gram blocks | scalar sums of the step], device buffer, in place
-        if ((r = vgc::allreduce_sum(comm, d_sums.p, n_pack, st)) != VG_OK) return r;
+        return vgc::allreduce_sum(comm, d_sums.p, n_pack, st);
+    };
+    // evaluate at a device parameter buffer and assemble U / gg / cost on the host
+    auto evaluate = [&](const double *x_dev, DevBuf<double> *set, std::vector<double> &Uo, std::vector<double> &go,
+                        double &cost2) -> int {
+        const double t0 = now_s();
+        int r;
+        if ((r = enqueue_evaluate(x_dev, set)) != VG_OK) return r;
         VG_HIP(hipMemcpyAsync(pin_sums.p, d_sums.p, sizeof(double) * h_sums.size(), hipMemcpyDeviceToHost, st));
         VG_HIP(hipStreamSynchronize(st));
         std::memcpy(h_sums.data(), pin_sums.p, sizeof(double) * h_sums.size());
@@ -702,6 +709,230 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             for (int k = 0; k < 6; k++) c2 += r[k] * r[k];
         }
     };
+    // ================================================================== device loop
+    // Problems made of grid blocks only (no priors, no odometry, no host-staged all-reduce): the reduced solve and the
+    // step acceptance run in two one-workgroup kernels, the trust-region state lives on the device, and an iteration
+    // is a fixed sequence of launches with ONE host synchronisation at its end (three
+    // synchronisations and a loop of one-double copies per iteration).
+    // Measured (tools/prof_solve.py, one MI355X): 10 k EUCM images 0.166 vs 0.21 ms per iteration, Mei equal, the
+    // 45-column rig 0.43 vs 0.37 -- there the one-workgroup factorisation of the reduced system costs more than the
+    // host's round trip, so wide systems keep the host loop.  VG_SOLVER_HOST_LOOP / VG_SOLVER_DEVICE_LOOP force a side.
+    static const bool force_host_loop = getenv("VG_SOLVER_HOST_LOOP") != nullptr;      // measurement / A-B hooks
+    static const bool force_device_loop = getenv("VG_SOLVER_DEVICE_LOOP") != nullptr;
+    if (coupled.empty() && p->priors.empty() && !opt.allreduce && !force_host_loop && (G <= 32 || force_device_loop)) {
+        DevBuf<vg::LmState> d_state;
+        DevBuf<double> d_U, d_gvec, d_S, d_xcur, d_glo, d_ghi;
+        DevBuf<int> d_Wd;
+        DevBuf<unsigned char> d_gfrozen;
+        VG_TRY(d_state.alloc(1));
+        VG_TRY(d_U.alloc((size_t)2 * G * G));
+        VG_TRY(d_gvec.alloc((size_t)2 * G));
+        VG_TRY(d_S.alloc((size_t)G * G));
+        VG_TRY(d_xcur.alloc((size_t)G));
+        std::vector<double> glo(G), ghi(G);
+        for (int a2 = 0; a2 < G; a2++) {
+            glo[a2] = lo[(size_t)gcol_param[a2]];
+            ghi[a2] = hi[(size_t)gcol_param[a2]];
+        }
+        VG_TRY(d_glo.upload(glo));
+        VG_TRY(d_ghi.upload(ghi));
+        VG_TRY(d_Wd.upload(Wd));
+        VG_TRY(d_gfrozen.upload(gfrozen));
+        vg::LmState h0;
+        std::memset(&h0, 0, sizeof h0);
+        h0.radius = opt.initial_trust_region_radius;
+        h0.decrease_factor = 2.;
+        h0.mu = 1. / h0.radius;
+        h0.term = VG_TERM_NO_CONVERGENCE;
+        VG_HIP(hipMemcpyAsync(d_state.p, &h0, sizeof h0, hipMemcpyHostToDevice, st));
+        VG_HIP(hipMemsetAsync(d_bad.p, 0, sizeof(int), st));
+        if (!n_poses) VG_HIP(hipMemsetAsync(d_rgram.p, 0, sizeof(double) * h_rgram.size(), st));
+        struct PinState {
+            vg::LmState *p = nullptr;
+            ~PinState()
+            {
+                if (p) (void)hipHostFree(p);
+            }
+        } pin_state;
+        VG_HIP(hipHostMalloc(reinterpret_cast<void **>(&pin_state.p), sizeof(vg::LmState), hipHostMallocDefault));
+
+        vg::LmAcceptArgs aa;
+        aa.st = d_state.p;
+        aa.U = d_U.p;
+        aa.gg = d_gvec.p;
+        aa.sums = d_sums.p;
+        aa.inv = d_inv.p;
+        aa.Wd = d_Wd.p;
+        aa.dg = d_dg.p;
+        aa.gmax_bits = d_gmax.p;
+        aa.bad = d_bad.p;
+        aa.xcur = d_xcur.p;
+        aa.x = d_x.p;
+        aa.gcol_param = d_gcol_param.p;
+        aa.lo = d_glo.p;
+        aa.hi = d_ghi.p;
+        aa.gfrozen = d_gfrozen.p;
+        aa.n_ds = n_ds;
+        aa.Wmax = Wmax;
+        aa.G = G;
+        aa.init = 1;
+        aa.multi_rank = multi_rank ? 1 : 0;
+        size_t accept_lds = sizeof(double) * ((size_t)n_ds * Wmax * Wmax + ((size_t)n_ds * G + 1) / 2 + 1);
+        if (accept_lds > 48 * 1024) accept_lds = 0;  // many datasets: read from global memory
+        aa.lds_doubles = accept_lds / sizeof(double);
+        aa.dmin = opt.min_lm_diagonal;
+        aa.dmax = opt.max_lm_diagonal;
+        aa.ftol = opt.function_tolerance;
+        aa.gtol = opt.gradient_tolerance;
+        aa.ptol = opt.parameter_tolerance;
+        aa.min_rel_decrease = opt.min_relative_decrease;
+        aa.max_radius = opt.max_trust_region_radius;
+        aa.min_radius = opt.min_trust_region_radius;
+        vg::LmSolveArgs ra;
+        ra.st = d_state.p;
+        ra.U = d_U.p;
+        ra.gg = d_gvec.p;
+        ra.rgram = d_rgram.p;
+        ra.lo = d_glo.p;
+        ra.hi = d_ghi.p;
+        ra.gfrozen = d_gfrozen.p;
+        ra.xcur = d_xcur.p;
+        ra.dg = d_dg.p;
+        ra.S = d_S.p;
+        ra.G = G;
+        ra.use_bounds = opt.use_bounds;
+        ra.dmin = opt.min_lm_diagonal;
+        ra.dmax = opt.max_lm_diagonal;
+        const bool s_in_lds = sizeof(double) * (2 * (size_t)G * G + 4 * (size_t)G + 2) <= 150 * 1024;
+        if (s_in_lds) ra.S = nullptr;
+        const size_t solve_lds = sizeof(double) * ((s_in_lds ? 2 : 1) * (size_t)G * G + 4 * (size_t)G + 2);
+        if (solve_lds > 64 * 1024)  // up to 127 global columns: 133 KB of the CU's 160 KB
+            VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(vg::vg_lm_reduced_solve_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_lds));
+
+        DevBuf<double> *cur = gramA, *cand = gramB;
+        vg::SolveDatasetDev *ds_cur = d_dsA.p, *ds_cand = d_dsB.p;
+        auto read_state = [&]() -> int {
+            VG_HIP(hipMemcpyAsync(pin_state.p, d_state.p, sizeof(vg::LmState), hipMemcpyDeviceToHost, st));
+            VG_HIP(hipStreamSynchronize(st));
+            return VG_OK;
+        };
+        VG_HIP(hipMemcpyAsync(d_xc.p, d_x.p, sizeof(double) * (size_t)n_params, hipMemcpyDeviceToDevice, st));
+        VG_TRY(enqueue_evaluate(d_x.p, cur));
+        hipLaunchKernelGGL(vg::vg_lm_accept_kernel, dim3(1), dim3(vg::kLmThreads), accept_lds, st, aa);
+        VG_HIP(hipGetLastError());
+        VG_TRY(read_state());
+        const double initial_cost = 0.5 * pin_state.p->cost2;
+        if (opt.verbose) std::printf("iter      cost      cost_change  |gradient|   |step|    tr_ratio  tr_radius\n%4d  %.6e\n", 0, initial_cost);
+        aa.init = 0;
+        int iter = 0;
+        for (iter = 1; iter <= opt.max_num_iterations; iter++) {
+            vg::SchurArgs sa;
+            sa.ds = ds_cur;
+            sa.inv = d_inv.p;
+            sa.ref_ptr = d_ref_ptr.p;
+            sa.ref_ds = d_ref_ds.p;
+            sa.ref_blk = d_ref_blk.p;
+            sa.pose_frozen = d_pf.p;
+            sa.G = G;
+            sa.n_poses = (int)n_poses;
+            sa.mu = 0.;
+            sa.mu_dev = &d_state.p->mu;
+            sa.dmin = opt.min_lm_diagonal;
+            sa.dmax = opt.max_lm_diagonal;
+            sa.rec = d_rec.p;
+            sa.rows = d_rows.p;
+            sa.bad = d_bad.p;
+            if (n_poses) {
+                hipLaunchKernelGGL(vg::vg_schur_rows_kernel, dim3((unsigned)((n_poses * C + 255) / 256)), dim3(256), 0, st, sa);
+                VG_HIP(hipGetLastError());
+                VG_TRY(launch_dense_gram(st, d_rows.p, n_rows, C, rows_per_group, n_groups, d_rgroups.p));
+                hipLaunchKernelGGL(vg::vg_gram_slab_sum_kernel, dim3(n_slabs), dim3(256), 0, st, (const double *)d_rgroups.p,
+                                   n_groups, C * C, d_rslabs.p);
+                VG_HIP(hipGetLastError());
+                hipLaunchKernelGGL(vg::vg_gram_final_sum_kernel, dim3((C * C + 3) / 4), dim3(256), 0, st,
+                                   (const double *)d_rslabs.p, n_slabs, C * C, d_rgram.p);
+                VG_HIP(hipGetLastError());
+            }
+            VG_TRY(vgc::allreduce_sum(comm, d_rgram.p, h_rgram.size(), st));  // Schur complement of the poses of all ranks
+            hipLaunchKernelGGL(vg::vg_lm_reduced_solve_kernel, dim3(1), dim3(G <= 64 ? vg::kWave : vg::kLmThreads), solve_lds, st, ra);
+            VG_HIP(hipGetLastError());
+            vg::BacksubArgs ba;
+            ba.s = sa;
+            ba.dg = d_dg.p;
+            ba.pose_param = d_pose_param.p;
+            ba.gcol_param = d_gcol_param.p;
+            ba.delta = d_delta.p;
+            ba.scal = d_scal.p;
+            ba.gmax_bits = d_gmax.p;
+            ba.x = d_x.p;
+            ba.xg = d_xg.p;
+            ba.lo = d_lo.p;
+            ba.hi = d_hi.p;
+            ba.x_new = d_xc.p;   // the step is applied where it is computed: no separate launch
+            if (n_poses || G) {
+                const unsigned int bs_grid = n_bs_groups ? n_bs_groups : 1u;
+                if (G < 64) hipLaunchKernelGGL(vg::vg_backsub_kernel<4>, dim3(bs_grid), dim3(vg::kBsThreads), 0, st, ba);
+                else hipLaunchKernelGGL(vg::vg_backsub_kernel<8>, dim3(bs_grid), dim3(vg::kBsThreads), 0, st, ba);
+                VG_HIP(hipGetLastError());
+            }
+            if (n_bs_groups) {
+                hipLaunchKernelGGL(vg::vg_gram_final_sum_kernel, dim3(2), dim3(256), 0, st, (const double *)d_scal.p, n_bs_groups, 5,
+                                   d_scal_sum.p);
+                VG_HIP(hipGetLastError());
+            }
+            VG_TRY(enqueue_evaluate(d_xc.p, cand));
+            hipLaunchKernelGGL(vg::vg_lm_accept_kernel, dim3(1), dim3(vg::kLmThreads), accept_lds, st, aa);
+            VG_HIP(hipGetLastError());
+            VG_TRY(read_state());  // the one synchronisation of the iteration
+            const vg::LmState &S = *pin_state.p;
+            if (opt.verbose)
+                std::printf("%4d  %.6e  %10.3e  %10.3e  %9.3e  %9.3e  %9.3e %s\n", iter, 0.5 * S.cost2, S.cost_change, S.grad_max,
+                            S.step_norm, S.rho, S.radius, S.accepted ? "" : (S.done && S.term <= VG_TERM_CONVERGENCE_PARAMETER ? "(converged)" : "(rejected)"));
+            if (S.accepted) {
+                std::swap(cur, cand);
+                std::swap(ds_cur, ds_cand);
+                std::swap(d_x.p, d_xc.p);
+            }
+            if (S.done) break;
+        }
+        const vg::LmState &S = *pin_state.p;
+        char msg[160] = "";
+        int term = S.done ? S.term : VG_TERM_NO_CONVERGENCE;
+        if (iter > opt.max_num_iterations) {
+            iter = opt.max_num_iterations;
+            std::snprintf(msg, sizeof msg, "maximum number of iterations reached");
+        } else if (term == VG_TERM_CONVERGENCE_GRADIENT)
+            std::snprintf(msg, sizeof msg, "gradient tolerance reached: max norm %.3e <= %.3e", S.grad_max, opt.gradient_tolerance);
+        else if (term == VG_TERM_CONVERGENCE_PARAMETER) std::snprintf(msg, sizeof msg, "parameter tolerance reached: |step| %.3e", S.step_norm);
+        else if (term == VG_TERM_CONVERGENCE_FUNCTION)
+            std::snprintf(msg, sizeof msg, "function tolerance reached: |cost change| / cost = %.3e",
+                          S.cost2 > 0 ? std::fabs(2. * S.cost_change) / (S.cost2 + 2. * S.cost_change) : 0.);
+        else if (term == VG_TERM_RADIUS_TOO_SMALL) std::snprintf(msg, sizeof msg, "trust region radius below %.1e", opt.min_trust_region_radius);
+        if (S.n_bad) {
+            const size_t len = std::strlen(msg);
+            std::snprintf(msg + len, sizeof msg - len, "%s%d pose block(s) not positive definite", len ? "; " : "", S.n_bad);
+        }
+        VG_HIP(hipMemcpyAsync(p->d_params, d_x.p, sizeof(double) * (size_t)n_params, hipMemcpyDeviceToDevice, st));
+        VG_HIP(hipStreamSynchronize(st));
+        p->frames_stale = true;
+        if (sum) {
+            std::memset(sum, 0, sizeof *sum);
+            sum->initial_cost = initial_cost;
+            sum->final_cost = 0.5 * S.cost2;
+            sum->num_iterations = iter;
+            sum->num_successful_steps = S.n_success;
+            sum->termination = term;
+            sum->gradient_max_norm = S.grad_max;
+            sum->final_radius = S.radius;
+            sum->total_seconds = now_s() - t_start;
+            sum->num_global_columns = G;
+            sum->num_pose_blocks = n_poses;
+            std::snprintf(sum->message, sizeof sum->message, "%s", msg);
+        }
+        return VG_OK;
+    }
+
     // values of the global columns at the starting point
     for (int a2 = 0; a2 < G; a2++) VG_HIP(hipMemcpy(&h_xg[a2], p->d_params + gcol_param[a2], sizeof(double), hipMemcpyDeviceToHost));
     std::vector<double> h_xcur(h_xg);  // global values at the CURRENT point (h_xg is refreshed only after the reduced solve)
@@ -745,6 +976,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
         sa.G = G;
         sa.n_poses = (int)n_poses;
         sa.mu = mu;
+        sa.mu_dev = nullptr;
         sa.dmin = opt.min_lm_diagonal;
         sa.dmax = opt.max_lm_diagonal;
         sa.rec = d_rec.p;
@@ -754,8 +986,6 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
         bool coupled_ok = true;
         if (n_poses) {
             VG_HIP(hipMemsetAsync(d_bad.p, 0, sizeof(int), st));
-            hipLaunchKernelGGL(vg::vg_pose_factor_kernel, dim3((unsigned)((n_poses + 63) / 64)), dim3(64), 0, st, sa);
-            VG_HIP(hipGetLastError());
             hipLaunchKernelGGL(vg::vg_schur_rows_kernel, dim3((unsigned)((n_poses * C + 255) / 256)), dim3(256), 0, st, sa);
             VG_HIP(hipGetLastError());
             // sequences coupled by odometry: raw V / g / W^T come back, the host eliminates the block-tridiagonal
@@ -860,6 +1090,9 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             ba.gmax_bits = d_gmax.p;
             ba.x = d_x.p;
             ba.xg = d_xg.p;
+            ba.lo = d_lo.p;
+            ba.hi = d_hi.p;
+            ba.x_new = d_xc.p;   // overwritten by vg_apply_step_kernel below (host-eliminated sequences add their steps first)
             if (n_poses || G) {  // G <= kBsThreads: one workgroup is enough for the global columns alone
                 const unsigned int bs_grid = n_bs_groups ? n_bs_groups : 1u;
                 if (G < 64) hipLaunchKernelGGL(vg::vg_backsub_kernel<4>, dim3(bs_grid), dim3(vg::kBsThreads), 0, st, ba);
