@@ -10,6 +10,7 @@
 
 #include <math.h>
 #include <stddef.h>
+#include <stdlib.h>
 #include <string.h>
 
 #ifdef _OPENMP
@@ -917,6 +918,161 @@ void vgo_odometry_prior_eval(const double zetaPrior[6], const double A[36], cons
         blockdiag6(R20, RM, J2m);
         mat6_mul(A, J2m, J2); /* jac = _A * J2 */
     }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * OdometryCost: differential-drive odometry with wheel radii / track gauge as a third parameter block.
+ * src/calibration/odometry_cost_function.cpp: odom_zeta_i :10-36, zeta_i_jacobian :39-69, tf0n_jac_calc :72-94,
+ * calc_acc :96-144, ctor :147-197, Evaluate :202-266.  Parameter blocks (6, 6, 3) as it is ADDED to the problem
+ * (src/calibration/unified_calibration.cpp:732-735); the class declares one block only.
+ * ---------------------------------------------------------------------------------------- */
+static void compose_(const double a[6], const double b[6], double out[6]) /* transformation.h:80-88 */
+{
+    double q1[4], q2[4], qres[4], rt[3];
+    vgo_quat_from_rotvec(a + 3, q1);
+    vgo_quat_from_rotvec(b + 3, q2);
+    quat_rotate(q1, b, rt);
+    out[0] = rt[0] + a[0]; out[1] = rt[1] + a[1]; out[2] = rt[2] + a[2];
+    quat_mul(q1, q2, qres);
+    vgo_quat_to_rotvec(qres, out + 3);
+}
+
+static void inverse_(const double a[6], double out[6]) /* transformation.h:112-119: t = -(R(-r) t), r = -r */
+{
+    double n[3] = {-a[3], -a[4], -a[5]}, R[9];
+    vgo_rotation_matrix(n, R);
+    for (int i = 0; i < 3; i++) out[i] = (-R[3 * i]) * a[0] + (-R[3 * i + 1]) * a[1] + (-R[3 * i + 2]) * a[2];
+    out[3] = n[0]; out[4] = n[1]; out[5] = n[2];
+}
+
+/* tf0n_jac_calc: the chain 0T1 ... 0Tn of the wheel increments and d(zeta_i)/d(intrinsics) of every step */
+static void odo_chain(int n, const double *deltaQ, const double intr[3], double *tf0 /*[n][6]*/, double *jz /*[n][9]*/)
+{
+    const double r1 = intr[0], r2 = intr[1], g = intr[2];
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < n; i++) {
+        const double dl = deltaQ[2 * i], dr = deltaQ[2 * i + 1];
+        /* odom_zeta_i: v_w = [[r1/2, r2/2], [-(r1/g), r2/g]] * delta; zeta_i = (v, 0, w) */
+        const double v = (r1 / 2) * dl + (r2 / 2) * dr;
+        const double w = (-(r1 / g)) * dl + (r2 / g) * dr;
+        const double step[6] = {v, 0., 0., 0., 0., w};
+        double nxt[6];
+        compose_(acc, step, nxt);
+        memcpy(acc, nxt, sizeof acc);
+        memcpy(tf0 + 6 * i, acc, sizeof acc);
+        double *J = jz + 9 * i; /* zeta_i_jacobian */
+        J[0] = dl / 2; J[1] = dr / 2; J[2] = 0;
+        J[3] = 0; J[4] = 0; J[5] = 0;
+        J[6] = -dl / g; J[7] = dr / g; J[8] = (r1 * dl - r2 * dr) / (g * g);
+    }
+}
+
+void vgo_odometry_cost_init(double errV, double errW, double lambda, int n, const double *deltaQ, const double intr_prior[3],
+                            double zetaPrior[6], double A[36])
+{
+    double *tf0 = (double *)malloc(sizeof(double) * 6 * (size_t)n), *jz = (double *)malloc(sizeof(double) * 9 * (size_t)n);
+    odo_chain(n, deltaQ, intr_prior, tf0, jz);
+    memcpy(zetaPrior, tf0 + 6 * (n - 1), 6 * sizeof(double));
+    free(tf0);
+    free(jz);
+    /* the rest of the constructor (:160-194) repeats OdometryPrior's (calib_cost_functions.cpp:127-167) on this zetaPrior */
+    {
+        const double MIN_SIGMA_V = 0.01, MIN_SIGMA_W = 0.01, MIN_DELTA = 0.01, MIN_L = 0.01;
+        const double nr = norm3(zetaPrior + 3), nt = norm3(zetaPrior);
+        const double delta = nr > MIN_DELTA ? nr : MIN_DELTA, l = nt > MIN_L ? nt : MIN_L;
+        const double s = sin(delta / 2.), c = cos(delta / 2.), l2 = l / 2.;
+        const double dfdu[6] = {c, l2 * s, -s, l2 * c, 0, 1};
+        double Cu0 = errV * errV * l * l, Cu1 = errW * errW * delta * delta;
+        if (Cu0 < MIN_SIGMA_V * MIN_SIGMA_V) Cu0 = MIN_SIGMA_V * MIN_SIGMA_V;
+        if (Cu1 < MIN_SIGMA_W * MIN_SIGMA_W) Cu1 = MIN_SIGMA_W * MIN_SIGMA_W;
+        double Cx[9], CxInv[9], L[9] = {0}, U[9];
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++)
+                Cx[3 * i + j] = dfdu[2 * i] * Cu0 * dfdu[2 * j] + dfdu[2 * i + 1] * Cu1 * dfdu[2 * j + 1] + (i == j ? lambda * lambda : 0.);
+        mat3_inverse(Cx, CxInv);
+        for (int r = 0; r < 3; r++)
+            for (int cc = 0; cc <= r; cc++) {
+                double v = CxInv[3 * r + cc];
+                for (int k = 0; k < cc; k++) v -= L[3 * r + k] * L[3 * cc + k];
+                L[3 * r + cc] = (r == cc) ? sqrt(v) : v / L[3 * cc + cc];
+            }
+        for (int r = 0; r < 3; r++)
+            for (int cc = 0; cc < 3; cc++) U[3 * r + cc] = L[3 * cc + r];
+        for (int i = 0; i < 36; i++) A[i] = 0.;
+        A[0] = U[0]; A[1] = U[1]; A[6] = U[3]; A[7] = U[4];
+        A[5] = U[2]; A[11] = U[5];
+        A[14] = 1. / lambda;
+        A[21] = 1. / lambda; A[28] = 1. / lambda; A[35] = U[8];
+    }
+}
+
+void vgo_odometry_cost_eval(const double A[36], int n, const double *deltaQ, const double xi1[6], const double xi2[6],
+                            const double intr[3], double residual[6], double J1[36], double J2[36], double J3[18])
+{
+    double zeta[6], err[6];
+    inverse_compose(xi1, xi2, zeta);
+    double *tf0 = (double *)malloc(sizeof(double) * 6 * (size_t)n), *jz = (double *)malloc(sizeof(double) * 9 * (size_t)n);
+    odo_chain(n, deltaQ, intr, tf0, jz);
+    const double *zeta_odo = tf0 + 6 * (n - 1);
+    double delta[6];
+    inverse_compose(zeta_odo, zeta, delta); /* zeta_odo.inverseCompose(zeta) */
+    memcpy(err, delta, sizeof err);
+    for (int i = 0; i < 6; i++) {
+        double s = 0.;
+        for (int k = 0; k < 6; k++) s += A[6 * i + k] * err[k];
+        residual[i] = s;
+    }
+    if (J1 || J2) { /* identical to OdometryPrior's two pose blocks (:231-252 == calib_cost_functions.cpp:187-209) */
+        double r_[6];
+        const double zero[6] = {0, 0, 0, 0, 0, 0};
+        vgo_odometry_prior_eval(zero, A, xi1, xi2, r_, J1, J2);
+    }
+    if (J3) {
+        /* calc_acc: ACC = sum_i R(0T(i-1)) * [[1,0,-t_y],[0,1,t_x],[0,0,1]] * jac_zeta_i, t = trans(iTn) */
+        double ACC[9] = {0};
+        for (int i = 0; i < n; i++) {
+            const double zero[6] = {0, 0, 0, 0, 0, 0};
+            const double *tf0j = i > 0 ? tf0 + 6 * (i - 1) : zero;
+            double R0j[9], ti0[6], tin[6];
+            vgo_rotation_matrix(tf0j + 3, R0j);
+            inverse_(tf0 + 6 * i, ti0);
+            compose_(ti0, zeta_odo, tin);
+            const double Jm[9] = {1, 0, -tin[1], 0, 1, tin[0], 0, 0, 1};
+            double T[9], T2[9];
+            mat3_mul(R0j, Jm, T);
+            mat3_mul(T, jz + 9 * i, T2);
+            for (int k = 0; k < 9; k++) ACC[k] = ACC[k] + T2[k];
+        }
+        double acc63[18] = {ACC[0], ACC[1], ACC[2], ACC[3], ACC[4], ACC[5], 0, 0, 0, 0, 0, 0, 0, 0, 0, ACC[6], ACC[7], ACC[8]};
+        /* jac = -_A * delta.screwTransfInv() * [[R31, 0], [0, R31 M(zeta_odo.rot)]] * jac_intrinsic */
+        double n3[3] = {-zeta_odo[3], -zeta_odo[4], -zeta_odo[5]}, R31[9], M[9], RM[9], J3m[36];
+        vgo_rotation_matrix(n3, R31);
+        vgo_inter_omega_rot(zeta_odo + 3, M);
+        mat3_mul(R31, M, RM);
+        blockdiag6(R31, RM, J3m);
+        double nd[3] = {-delta[3], -delta[4], -delta[5]}, R[9], H[9], RH[9], TT[36];
+        vgo_rotation_matrix(nd, R);
+        hat_(delta, H);
+        mat3_mul(R, H, RH);
+        for (int i = 0; i < 36; i++) TT[i] = 0.;
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) {
+                TT[6 * i + j] = R[3 * i + j];
+                TT[6 * i + 3 + j] = -RH[3 * i + j];
+                TT[6 * (3 + i) + 3 + j] = R[3 * i + j];
+            }
+        double T1[36], T2[36];
+        mat6_mul(A, TT, T1);
+        mat6_mul(T1, J3m, T2);
+        for (int i = 0; i < 6; i++)
+            for (int j = 0; j < 3; j++) {
+                double s = 0.;
+                for (int k = 0; k < 6; k++) s += T2[6 * i + k] * acc63[3 * k + j];
+                J3[3 * i + j] = -s;
+            }
+    }
+    free(tf0);
+    free(jz);
 }
 
 int vgo_max_threads(void)

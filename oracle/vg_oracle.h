@@ -108,6 +108,14 @@ void vgo_odometry_prior_init(double errV, double errW, double lambda, const doub
 void vgo_odometry_prior_eval(const double zetaPrior[6], const double A[36], const double xi1[6], const double xi2[6],
                              double residual[6], double J1[36], double J2[36]);
 
+/* OdometryCost (src/calibration/odometry_cost_function.cpp): constructor (:147-197) -> zetaPrior[6], A[36]; Evaluate
+ * (:202-266) with parameter blocks (xi1[6], xi2[6], intrinsics[3] = wheel radii left / right, track gauge) ->
+ * residual[6], J1 / J2 [36], J3 [6 x 3], row-major, any of them NULL.  deltaQ: n wheel-increment pairs. */
+void vgo_odometry_cost_init(double errV, double errW, double lambda, int n, const double *deltaQ, const double intr_prior[3],
+                            double zetaPrior[6], double A[36]);
+void vgo_odometry_cost_eval(const double A[36], int n, const double *deltaQ, const double xi1[6], const double xi2[6],
+                            const double intr[3], double residual[6], double J1[36], double J2[36], double J3[18]);
+
 int vgo_max_threads(void);
 
 #ifdef __cplusplus

@@ -79,6 +79,10 @@ def lib():
         L.vgo_odometry_prior_init.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_double, _dp, _dp, _dp, _dp]
         L.vgo_odometry_prior_eval.restype = None
         L.vgo_odometry_prior_eval.argtypes = [_dp, _dp, _dp, _dp, _dp, _dp, _dp]
+        L.vgo_odometry_cost_init.restype = None
+        L.vgo_odometry_cost_init.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int, _dp, _dp, _dp, _dp]
+        L.vgo_odometry_cost_eval.restype = None
+        L.vgo_odometry_cost_eval.argtypes = [_dp, ctypes.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
         _lib = L
     return _lib
 
@@ -201,6 +205,25 @@ class OdometryPrior:
         r, J1, J2 = np.empty(6), np.empty((6, 6)), np.empty((6, 6))
         lib().vgo_odometry_prior_eval(_ptr(self.zeta), _ptr(self.A), _ptr(a), _ptr(b), _ptr(r), _ptr(J1), _ptr(J2))
         return r, J1, J2
+
+
+class OdometryCost:
+    """OdometryCost (src/calibration/odometry_cost_function.cpp), parameter blocks (xi1[6], xi2[6], intrinsics[3])"""
+
+    def __init__(self, errV, errW, lam, delta_q, intr_prior):
+        self.dq = _c(delta_q).reshape(-1, 2)
+        self.zeta = np.empty(6)
+        self.A = np.empty((6, 6))
+        ip = _c(intr_prior)
+        lib().vgo_odometry_cost_init(ctypes.c_double(errV), ctypes.c_double(errW), ctypes.c_double(lam), self.dq.shape[0],
+                                     _ptr(self.dq), _ptr(ip), _ptr(self.zeta), _ptr(self.A))
+
+    def evaluate(self, xi1, xi2, intr):
+        a, b, c = _c(xi1), _c(xi2), _c(intr)
+        r, J1, J2, J3 = np.empty(6), np.empty((6, 6)), np.empty((6, 6)), np.empty((6, 3))
+        lib().vgo_odometry_cost_eval(_ptr(self.A), self.dq.shape[0], _ptr(self.dq), _ptr(a), _ptr(b), _ptr(c), _ptr(r),
+                                     _ptr(J1), _ptr(J2), _ptr(J3))
+        return r, J1, J2, J3
 
 
 def compose(a, b, inverse=False):

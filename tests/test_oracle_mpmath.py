@@ -163,6 +163,10 @@ class Transf:  # include/geometry/transformation.h, data = [t(3), r(3)] (:46)
                 S[3 + i][3 + j] = R[i][j]
         return S
 
+    def inverse(self):  # :112-119
+        R = self.rot_mat_inv()
+        return Transf([-sum(R[i][k] * self.t[k] for k in range(3)) for i in range(3)], [-a for a in self.r])
+
     def array(self):
         return self.t + self.r
 
@@ -456,3 +460,88 @@ def test_odometry_prior_against_50_digits():
         close(r, res, "odometry residual", floor_rel=1e-6)
         close(j1, J1, "odometry J1")
         close(j2, J2, "odometry J2")
+
+
+def odometry_A(zp, errV, errW, lam):
+    """the weighting matrix both odometry blocks build from their zetaPrior (calib_cost_functions.cpp:127-167,
+    odometry_cost_function.cpp:160-194)"""
+    delta = max(norm(zp.r), mpf("0.01"))
+    l = max(norm(zp.t), mpf("0.01"))
+    s, c = mp.sin(delta / 2), mp.cos(delta / 2)
+    dfdu = [[c, l / 2 * s], [-s, l / 2 * c], [mpf(0), mpf(1)]]
+    eV, eW, la = mpf(errV), mpf(errW), mpf(lam)
+    Cu = [[max(eV * eV * l * l, mpf("0.01") ** 2), mpf(0)], [mpf(0), max(eW * eW * delta * delta, mpf("0.01") ** 2)]]
+    Cx = matmul(matmul(dfdu, Cu), transpose(dfdu))
+    for i in range(3):
+        Cx[i][i] += la * la
+    U = cholesky_upper(inv3(Cx))
+    A = [[mpf(0)] * 6 for _ in range(6)]
+    for i in range(2):
+        A[i][0], A[i][1], A[i][5] = U[i][0], U[i][1], U[i][2]
+    A[2][2] = A[3][3] = A[4][4] = 1 / la
+    A[5][5] = U[2][2]
+    return A
+
+
+def test_odometry_cost_against_50_digits():
+    """OdometryCost, src/calibration/odometry_cost_function.cpp: chain of wheel increments :72-94 (odom_zeta_i :10-36,
+    zeta_i_jacobian :39-69), calc_acc :96-144, ctor :147-197, Evaluate :202-266 with blocks (6, 6, 3)"""
+    for trial in range(4):
+        n = int(RNG.integers(1, 7))
+        dq = RNG.uniform(0.05, 0.6, (n, 2)) * RNG.choice([1.0, 1.0, -1.0], (n, 1))
+        intr0 = np.array([0.11, 0.105, 0.52]) * (1 + 0.02 * RNG.standard_normal(3))
+        intr = intr0 * (1 + 0.01 * RNG.standard_normal(3))
+        errV, errW, lam = (float(v) for v in RNG.uniform(0.01, 0.2, 3))
+
+        def chain(p):
+            r1, r2, g = V(p)
+            acc, tfs, jzs = Transf(), [], []
+            for dl, dr in dq:
+                dl, dr = mpf(float(dl)), mpf(float(dr))
+                v = (r1 / 2) * dl + (r2 / 2) * dr
+                w = -(r1 / g) * dl + (r2 / g) * dr
+                acc = acc.compose(Transf([v, mpf(0), mpf(0)], [mpf(0), mpf(0), w]))
+                tfs.append(acc)
+                jzs.append([[dl / 2, dr / 2, mpf(0)], [mpf(0)] * 3, [-dl / g, dr / g, (r1 * dl - r2 * dr) / (g * g)]])
+            return tfs, jzs
+
+        zp = chain(intr0)[0][-1]
+        A = odometry_A(zp, errV, errW, lam)
+        blk = vgo.OdometryCost(errV, errW, lam, dq, intr0)
+        close(blk.zeta, zp.array(), "zetaPrior of the wheel chain", floor_rel=1e-6)
+        close(blk.A, A, "A", floor_rel=1e-6)
+        base = np.array([0.4, -0.3, 0.0, 0.0, 0.0, 0.7])
+        x1 = base + 0.01 * RNG.standard_normal(6)
+        x2 = vgo.compose(base, to_np(zp.array())) + 0.01 * RNG.standard_normal(6)
+        X1, X2 = Transf.from_data(x1), Transf.from_data(x2)
+        zeta = X1.inverse_compose(X2)
+        tfs, jzs = chain(intr)
+        zo = tfs[-1]
+        delta = zo.inverse_compose(zeta)
+        res = matvec(A, delta.array())
+
+        def jblock(X):
+            Ri = X.rot_mat_inv()
+            RM = matmul(Ri, inter_omega_rot(X.r))
+            J = [[mpf(0)] * 6 for _ in range(6)]
+            for i in range(3):
+                for j in range(3):
+                    J[i][j], J[3 + i][3 + j] = Ri[i][j], RM[i][j]
+            return J
+
+        J1 = [[-a for a in row] for row in matmul(matmul(A, zeta.screw_transf_inv()), jblock(X1))]
+        J2 = matmul(A, jblock(X2))
+        ACC = [[mpf(0)] * 3 for _ in range(3)]
+        for i in range(n):
+            t0j = tfs[i - 1] if i > 0 else Transf()
+            tin = tfs[i].inverse().compose(zo)
+            Jm = [[1, 0, -tin.t[1]], [0, 1, tin.t[0]], [0, 0, 1]]
+            T = matmul(matmul(t0j.rot_mat(), Jm), jzs[i])
+            ACC = [[ACC[a][b] + T[a][b] for b in range(3)] for a in range(3)]
+        acc63 = [ACC[0], ACC[1], [mpf(0)] * 3, [mpf(0)] * 3, [mpf(0)] * 3, ACC[2]]
+        J3 = [[-a for a in row] for row in matmul(matmul(matmul(A, delta.screw_transf_inv()), jblock(zo)), acc63)]
+        r, j1, j2, j3 = blk.evaluate(x1, x2, intr)
+        close(r, res, "odometry-cost residual", floor_rel=1e-6)
+        close(j1, J1, "odometry-cost J1")
+        close(j2, J2, "odometry-cost J2")
+        close(j3, J3, "odometry-cost J3 (intrinsics)")

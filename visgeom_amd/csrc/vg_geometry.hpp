@@ -305,9 +305,16 @@ VG_HD void build_frame_single_direct(const double *xi, double *frame)
     double racc[3] = {r[0], r[1], r[2]};
     RotTrig gacc = g;
     if (!(g.th < 1e-5) && g.th < 1.00000001e-5) {
-        const Quat q = quat_from_rotvec(r, g);   // identity * q == q, component by component
-        quat_to_rotvec(q, racc);
-        gacc.th = norm3(racc);                   // sin / cos of it: those of th to 1e-16 (only used if still >= 1e-5)
+        // Quaternion(rot) (quaternion.h:41-48), identity * q == q component by component, toRotationVector (:86-91):
+        // here |q.xyz| = sin(th / 2) ~ 5e-6 is always below its 1e-5 threshold, so the atan2 branch cannot occur
+        // (written out instead of calling quat_to_rotvec: its unreachable branch cost the kernel 3 % in registers)
+        const double x = r[0] / g.th * g.sh, y = r[1] / g.th * g.sh, z = r[2] / g.th * g.sh;
+        if (sqrt(x * x + y * y + z * z) < 1e-5) {
+            racc[0] = x * 2.;
+            racc[1] = y * 2.;
+            racc[2] = z * 2.;
+            gacc.th = norm3(racc);  // sin / cos of it: those of th to 1e-16 (only used if still >= 1e-5)
+        }
     }
     double R[9], Rb[9], M[9], R12[9], M12[9];
     rotation_matrix(racc, 1., gacc, R);  // R13 = R(xiAcc.rot)
