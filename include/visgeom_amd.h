@@ -164,12 +164,30 @@ int vg_problem_add_odometry_prior(vg_problem *p, int transform_id, int64_t index
  * residual[6], J1[36], J2[36] (row-major; either Jacobian may be NULL). */
 int vg_odometry_prior_evaluate(double err_v, double err_w, double lambda, const double *xi1_odom, const double *xi2_odom,
                                const double *xi1, const double *xi2, double *residual, double *J1, double *J2);
+/* A free-standing global parameter block (1..16 doubles) at the end of the parameter vector -- the
+ * [radius_left, radius_right, track_gauge] of data type "odometry_intrinsic" (unified_calibration.cpp:680-683). */
+int vg_problem_add_parameter_block(vg_problem *p, int size, const double *values, int constant, int *block_id);
+int64_t vg_problem_parameter_block_offset(const vg_problem *p, int block_id);
+/* OdometryCost (include/calibration/odometry_cost_function.h:33-57, src/calibration/odometry_cost_function.cpp:147-266;
+ * parseData :661-742): six residuals between elements `index` and `index + 1` of a SEQUENCE transform and the three
+ * odometry intrinsics of a differential drive, r = A (zeta_odo(intrinsics)^-1 o (xi1^-1 o xi2)) with zeta_odo the
+ * chain of the interval's n_steps wheel increments delta_q [n_steps][2] = (left, right).  Parameter blocks (6, 6, 3),
+ * as the reference ADDS the block to its problem (:732-735; the class itself declares one block).  The
+ * weighting A is fixed from the block's values at the time of the call.  Like OdometryPrior these blocks are
+ * evaluated on the host and make the pose system of the sequence block tridiagonal (single rank). */
+int vg_problem_add_odometry_cost(vg_problem *p, int transform_id, int64_t index, double err_v, double err_w, double lambda,
+                                 int n_steps, const double *delta_q, int param_block_id);
+/* Host-only evaluation of one OdometryCost block: constructor arguments + the three parameter blocks ->
+ * zeta_prior[6] (NULL ok), residual[6], J1[36], J2[36], J3[18] (6 x 3), row-major, any Jacobian may be NULL. */
+int vg_odometry_cost_evaluate(double err_v, double err_w, double lambda, int n_steps, const double *delta_q, const double *intr_prior,
+                              const double *xi1, const double *xi2, const double *intr, double *zeta_prior, double *residual,
+                              double *J1, double *J2, double *J3);
 /* SetParameterBlockConstant on ONE element of a sequence ("anchor": true, :803-806). */
 int vg_problem_set_pose_constant(vg_problem *p, int transform_id, int64_t index);
 /* freezes the layout, uploads everything, allocates per-block frames. */
 int vg_problem_finalize(vg_problem *p);
 
-/* ---- parameter vector: [camera 0 | camera 1 | ... | transform 0 (count x 6) | transform 1 ...] ---- */
+/* ---- parameter vector: [camera 0 | camera 1 | ... | transform 0 (count x 6) | transform 1 ... | parameter blocks] ---- */
 int64_t vg_problem_num_parameters(const vg_problem *p);
 int64_t vg_problem_camera_offset(const vg_problem *p, int camera_id);
 int64_t vg_problem_transform_offset(const vg_problem *p, int transform_id, int64_t index);

@@ -231,3 +231,35 @@ def test_bench_starts_its_own_ranks(monkeypatch):
     assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert cmd[-4:] == ["--gpus", "4", "--steps", "7"] and cmd[-5].endswith("bench.py")
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_odometry_cost_host_block_matches_oracle(lib):
+    """vg_odometry_cost_evaluate (host arithmetic, no GPU): OdometryCost with parameter blocks (xi1[6], xi2[6],
+    [radius_left, radius_right, track_gauge]) (odometry_cost_function.cpp:147-266) against the C restatement, which
+    tests/test_oracle_mpmath.py holds to 1e-12 of a 50-digit evaluation of the same formulas."""
+    import numpy as np
+
+    from oracle import vgo
+
+    rng = np.random.default_rng(23)
+    dp = ctypes.POINTER(ctypes.c_double)
+    P = lambda a: a.ctypes.data_as(dp)
+    for errV, errW, lam, n_steps, turn in [(0.05, 0.02, 0.3, 1, 0.2), (0.0, 0.0, 1.0, 7, 0.0), (0.3, 0.3, 0.02, 25, 1.0)]:
+        prior = np.array([0.05, 0.052, 0.31])
+        dq = np.ascontiguousarray(0.4 + 0.1 * rng.standard_normal((n_steps, 2)) + turn * np.array([-0.1, 0.1]))
+        blk = vgo.OdometryCost(errV, errW, lam, dq, prior)
+        x1 = rng.standard_normal(6) * 0.5
+        x2 = vgo.compose(x1, blk.zeta) + 0.03 * rng.standard_normal(6)
+        intr = prior * (1 + 0.05 * rng.standard_normal(3))
+        z, r, J1, J2, J3 = np.empty(6), np.empty(6), np.empty((6, 6)), np.empty((6, 6)), np.empty((6, 3))
+        assert lib.vg_odometry_cost_evaluate(errV, errW, lam, n_steps, P(dq), P(prior), P(x1), P(x2), P(intr), P(z), P(r), P(J1), P(J2), P(J3)) == 0
+        ro, J1o, J2o, J3o = blk.evaluate(x1, x2, intr)
+        assert np.max(np.abs(z - blk.zeta)) <= 1e-14 * max(1.0, np.max(np.abs(blk.zeta)))
+        assert np.max(np.abs(r - ro)) <= 1e-12 * max(1.0, np.max(np.abs(ro)))
+        for J, Jo in ((J1, J1o), (J2, J2o), (J3, J3o)):
+            assert np.max(np.abs(J - Jo)) <= 1e-12 * max(1.0, np.max(np.abs(Jo)))
+        r2 = np.empty(6)
+        assert lib.vg_odometry_cost_evaluate(errV, errW, lam, n_steps, P(dq), P(prior), P(x1), P(x2), P(intr), None, P(r2), None, None, None) == 0
+        assert np.array_equal(r, r2)
+    assert lib.vg_odometry_cost_evaluate(0.1, 0.1, 0.0, 1, P(dq), P(prior), P(x1), P(x2), P(intr), None, P(r), None, None, None) != 0
+    assert lib.vg_odometry_cost_evaluate(0.1, 0.1, 1.0, 0, P(dq), P(prior), P(x1), P(x2), P(intr), None, P(r), None, None, None) != 0

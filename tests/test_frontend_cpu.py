@@ -78,7 +78,7 @@ def test_parse_errors_mirror_the_reference(tmp_path, what, msg):
                                          "value": r["transformations"][0]["value"]})
             r["data"][0]["transform_chain"].append({"name": "other", "direct": True})
         elif what == "unknown_type":
-            r["data"][0]["type"] = "odometry_intrinsic"
+            r["data"][0]["type"] = "stereo_pairs"
         elif what == "images_without_corners":
             r["data"][0].update(type="images", object={"cols": 12, "rows": 8, "size": 0.1})
         elif what == "bad_literal":
@@ -234,3 +234,26 @@ def test_json_parser_survives_mutated_input(tmp_path):
         finally:
             c.close()
     assert ok + bad == len(variants) and bad > len(variants) // 2
+
+
+def test_odometry_intrinsic_entry_parses_and_initialises_the_sequence(tmp_path):
+    """parse side of "odometry_intrinsic" (unified_calibration.cpp:660-742), no GPU: the wheel geometry lands in
+    intrinsicMap[transform], the sequence is xi_0 = 0, xi_i+1 = xi_i o zetaPrior_i with zetaPrior_i the chained wheel
+    increments under the prior geometry (checked against the oracle's OdometryCost constructor)."""
+    import numpy as np
+
+    from oracle import vgo
+
+    n = 6
+    d = S.make_wheeled(n)
+    path = S.write_wheeled_json(str(tmp_path), d)
+    c = GenericCameraCalibration()
+    c.addResiduals(path)
+    assert np.array_equal(c.intrinsics("xiOdomBase"), d["init_wheels"])
+    seq = c.transform("xiOdomBase")
+    assert seq.shape == (n, 6) and np.array_equal(seq[0], np.zeros(6))
+    xi = np.zeros(6)
+    for i in range(n - 1):
+        xi = vgo.compose(xi, vgo.OdometryCost(0.05, 0.05, 0.05, d["delta_q"][i], d["init_wheels"]).zeta)
+        assert np.max(np.abs(seq[i + 1] - xi)) < 1e-14
+    c.close()

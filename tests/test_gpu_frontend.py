@@ -277,3 +277,49 @@ def test_do_not_solve_global_keeps_the_dataset_out_of_the_problem(gpu, tmp_path)
     sig0, _ = c.writeImageResidual(0, tmp_path / "image_error_0.txt", n_images=15)
     assert np.all(sig0 < 1e-6)
     c.close()
+
+
+def test_wheeled_base_with_odometry_intrinsic_entry(gpu, tmp_path):
+    """the "odometry_intrinsic" data type end to end (unified_calibration.cpp:660-742): wheel increments read from the
+    data file, the sequence initialised by chaining them under the prior wheel geometry and anchored at element 0,
+    one OdometryCost (xi_i, xi_i+1, [radius_left, radius_right, track_gauge]) per interval; the wheel geometry is
+    calibrated together with the camera and the hand-eye transform.  Through the class mirror and the calib CLI."""
+    import json
+
+    from visgeom_amd import _build, synthetic as S
+    from visgeom_amd.calibration import GenericCameraCalibration
+
+    n = 16
+    d = S.make_wheeled(n, sigma=0.1)
+    path = S.write_wheeled_json(str(tmp_path), d)
+    c = GenericCameraCalibration()
+    c.addResiduals(path)
+    assert np.array_equal(c.intrinsics("xiOdomBase"), d["init_wheels"])            # intrinsicMap[transformName], :677-680
+    report = c.compute(max_num_iterations=200)
+    print("wheeled", c.summary["termination"], c.summary["num_iterations"], "%.4e -> %.4e" % (c.summary["initial_cost"], c.summary["final_cost"]),
+          "wheels", c.intrinsics("xiOdomBase"))
+    assert "Sequence : xiOdomBase" in report and "xiOdomBase : " in report.split("Local extrinsic")[0]
+    assert c.summary["num_global_columns"] == 21 and c.summary["num_pose_blocks"] == n
+    assert np.array_equal(c.transform("xiOdomBase")[0], np.zeros(6))                # anchor
+    assert rel(c.intrinsics("xiOdomBase"), d["gt_wheels"]) < 2e-2
+    assert np.max(np.abs(c.transform("xiOdomBase") - d["gt_base"])) < 1e-2
+    assert 0.3 < c.summary["final_cost"] / (0.5 * 0.01 * 2 * 96 * n) < 1.5
+    c.close()
+    r = subprocess.run([_build.CLI, path], capture_output=True, text=True, cwd=str(tmp_path), timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "Sequence : xiOdomBase" in r.stdout and "xiBaseCam" in r.stdout
+
+    # error behaviour of the entry (:662-670, :706-709)
+    root = json.load(open(path))
+    bad = dict(root, data=[dict(root["data"][0], transform="xiBaseCam"), root["data"][1]])
+    json.dump(bad, open(tmp_path / "bad_global.json", "w"))
+    c = GenericCameraCalibration()
+    with pytest.raises(Exception, match="is global. Odometry must be a sequence"):
+        c.addResiduals(str(tmp_path / "bad_global.json"))
+    c.close()
+    bad = dict(root, data=[root["data"][0], root["data"][0], root["data"][1]])
+    json.dump(bad, open(tmp_path / "bad_twice.json", "w"))
+    c = GenericCameraCalibration()
+    with pytest.raises(Exception, match="has already been initialized"):
+        c.addResiduals(str(tmp_path / "bad_twice.json"))
+    c.close()

@@ -640,3 +640,139 @@ def test_argument_errors_of_the_block_level_entries(vg):
         p.solve(allreduce=lambda buf: None, max_num_iterations=2)
     assert "all-reduce" in str(e.value)
     p.close()
+
+
+def _wheeled_reference(d, n, errV, errW, lam, x0):
+    """scipy TRF on the oracle for the wheeled-base problem; x = [intrinsics 6 | xiBaseCam 6 | xiOdomBoard 6 |
+    xiOdomBase n x 6 | wheels 3] (the product's layout: cameras, transforms, parameter blocks), element 0 constant."""
+    from scipy.optimize import least_squares
+
+    N = d["board"].shape[0]
+    W = 18 + 6 * n
+    blocks = [vgo.OdometryCost(errV, errW, lam, d["delta_q"][i], d["init_wheels"]) for i in range(n - 1)]
+    free = np.ones(x0.size, dtype=bool)
+    free[18:24] = False
+
+    def full(z):
+        x = x0.copy()
+        x[free] = z
+        return x
+
+    def fun(z):
+        x = full(z)
+        r, _, _ = vgo.eval_dataset(0, [1, 1, 0], d["board"], d["corners"], x, 0, [6, 18, 12], [0, 6, 0], np.arange(n), want_jac=False)
+        ro = [b.evaluate(x[18 + 6 * i:24 + 6 * i], x[24 + 6 * i:30 + 6 * i], x[W:W + 3])[0] for i, b in enumerate(blocks)]
+        return np.concatenate([r.ravel()] + ro)
+
+    def jac(z):
+        x = full(z)
+        _, ji, jm = vgo.eval_dataset(0, [1, 1, 0], d["board"], d["corners"], x, 0, [6, 18, 12], [0, 6, 0], np.arange(n), want_jac=True)
+        J = np.zeros((2 * N * n + 6 * (n - 1), x.size))
+        for b in range(n):
+            rows = slice(b * 2 * N, (b + 1) * 2 * N)
+            J[rows, 0:6] = ji[b]
+            J[rows, 6:12] = jm[0][b]
+            J[rows, 18 + 6 * b:24 + 6 * b] = jm[1][b]
+            J[rows, 12:18] = jm[2][b]
+        for i, blk in enumerate(blocks):
+            _, J1, J2, J3 = blk.evaluate(x[18 + 6 * i:24 + 6 * i], x[24 + 6 * i:30 + 6 * i], x[W:W + 3])
+            rows = slice(2 * N * n + 6 * i, 2 * N * n + 6 * i + 6)
+            J[rows, 18 + 6 * i:24 + 6 * i] = J1
+            J[rows, 24 + 6 * i:30 + 6 * i] = J2
+            J[rows, W:W + 3] = J3
+        return J[:, free]
+
+    ref = least_squares(fun, x0[free], jac=jac, method="trf", x_scale="jac", xtol=1e-15, ftol=1e-15, gtol=1e-15, max_nfev=500)
+    return ref, full, fun, jac, free
+
+
+def _wheeled_x0(d, n):
+    seq = [np.zeros(6)]
+    for i in range(n - 1):   # "init": true of the odometry_intrinsic entry: chain the priors (unified_calibration.cpp:724-730)
+        seq.append(vgo.compose(seq[-1], vgo.OdometryCost(0.05, 0.05, 0.05, d["delta_q"][i], d["init_wheels"]).zeta))
+    return np.concatenate([d["init_intrinsics"], d["init_xi_base_cam"], d["init_xi_odom_board"], np.concatenate(seq), d["init_wheels"]])
+
+
+@pytest.mark.parametrize("lam", [0.05, 1.0])
+def test_odometry_cost_matches_scipy_on_the_oracle(vg, lam):
+    """data type "odometry_intrinsic" (unified_calibration.cpp:660-742): OdometryCost blocks (6, 6, 3) couple consecutive
+    elements of the sequence AND a shared parameter block [radius_left, radius_right, track_gauge]: three more global
+    columns, a pose-global coupling J_pose^T J_3 on top of the block-tridiagonal pose system."""
+    from visgeom_amd import synthetic as S
+
+    n = 12
+    d = S.make_wheeled(n, sigma=0.1)
+    errV, errW = 0.05, 0.05
+    x0 = _wheeled_x0(d, n)
+    ref, full, fun, jac, free = _wheeled_reference(d, n, errV, errW, lam, x0)
+
+    p = vg.CalibrationProblem(0)
+    cam = p.add_camera("eucm", d["init_intrinsics"])
+    bc = p.add_transform(True, d["init_xi_base_cam"])
+    ob = p.add_transform(True, d["init_xi_odom_board"])
+    seq = p.add_transform(False, x0[18:18 + 6 * n].reshape(n, 6))
+    wheels = p.add_parameter_block(d["init_wheels"])
+    p.add_dataset(cam, [(bc, 1), (seq, 1), (ob, 0)], d["board"], d["corners"])
+    for i in range(n - 1):
+        p.add_odometry_cost(seq, i, errV, errW, lam, d["delta_q"][i], wheels)
+    p.set_pose_constant(seq, 0)
+    p.finalize()
+    W = 18 + 6 * n
+    assert p.parameter_block_offset(wheels) == W
+    summ = p.solve(max_num_iterations=300, use_bounds=0)
+    x = p.get_parameters()
+    print("odometry cost lam=%g" % lam, summ["termination"], summ["num_iterations"],
+          "cost gpu %.10e scipy %.10e (initial %.4e)" % (summ["final_cost"], ref.cost, summ["initial_cost"]), "wheels", x[W:], full(ref.x)[W:])
+    assert summ["num_global_columns"] == 21
+    assert np.array_equal(x[18:24], x0[18:24])                      # the anchor did not move
+    assert abs(summ["initial_cost"] - 0.5 * np.sum(fun(x0[free]) ** 2)) <= 1e-10 * summ["initial_cost"]
+    assert abs(summ["final_cost"] - 0.5 * np.sum(fun(x[free]) ** 2)) <= 1e-10 * summ["final_cost"]
+    # the reference's odometry Jacobians are first-order approximations, so the comparison is solver-to-solver as in
+    # the OdometryPrior case: gradient (by the reference's J) reduced, same cost, same optimum to solver tolerance
+    g = jac(x[free]).T @ fun(x[free])
+    g0 = jac(x0[free]).T @ fun(x0[free])
+    assert np.max(np.abs(g)) <= 1e-5 * np.max(np.abs(g0))
+    assert abs(summ["final_cost"] - ref.cost) <= 1e-5 * ref.cost
+    # Planar motion leaves one gauge freedom: lifting the camera on the base by dz (xiBaseCam t_z, index 8) and the board in
+    # the odometry frame by the same dz (xiOdomBoard t_z, index 14) changes no image.  Each solver stops somewhere else
+    # along it, so those two are compared through their difference.
+    xr = full(ref.x)
+    keep = np.ones(W, dtype=bool)
+    keep[[8, 14]] = False
+    keep[:6] = False
+    assert rel(x[:6], xr[:6]) < 1e-4
+    assert np.max(np.abs(x[:W][keep] - xr[:W][keep])) < 1e-3
+    assert abs((x[8] - x[14]) - (xr[8] - xr[14])) < 1e-3
+    assert rel(x[W:], xr[W:]) < 1e-3
+    # calibration sanity: wheel geometry and the observable part of the hand-eye transform recovered
+    assert rel(x[W:], d["gt_wheels"]) < 2e-2
+    obs = [6, 7, 9, 10, 11]
+    assert np.max(np.abs(x[obs] - np.concatenate([d["gt_xi_base_cam"], []])[[0, 1, 3, 4, 5]])) < 1e-2
+    p.close()
+
+
+def test_constant_wheel_geometry_reduces_to_fixed_priors(vg):
+    """A constant parameter block: its three global columns are frozen, the OdometryCost blocks act as odometry priors
+    computed from the (fixed) wheel geometry."""
+    from visgeom_amd import synthetic as S
+
+    n = 8
+    d = S.make_wheeled(n, sigma=0.1)
+    x0 = _wheeled_x0(d, n)
+    p = vg.CalibrationProblem(0)
+    cam = p.add_camera("eucm", d["init_intrinsics"])
+    bc = p.add_transform(True, d["init_xi_base_cam"])
+    ob = p.add_transform(True, d["init_xi_odom_board"])
+    seq = p.add_transform(False, x0[18:18 + 6 * n].reshape(n, 6))
+    wheels = p.add_parameter_block(d["init_wheels"], constant=True)
+    p.add_dataset(cam, [(bc, 1), (seq, 1), (ob, 0)], d["board"], d["corners"])
+    for i in range(n - 1):
+        p.add_odometry_cost(seq, i, 0.05, 0.05, 0.5, d["delta_q"][i], wheels)
+    p.set_pose_constant(seq, 0)
+    p.finalize()
+    summ = p.solve(max_num_iterations=200, use_bounds=0)
+    x = p.get_parameters()
+    W = 18 + 6 * n
+    assert np.array_equal(x[W:], d["init_wheels"])
+    assert summ["final_cost"] < 1e-3 * summ["initial_cost"] and summ["termination"].startswith("CONVERGENCE")
+    p.close()

@@ -83,6 +83,12 @@ SIGNATURES = {
     "vg_problem_add_transformation_prior": (ctypes.c_int, [_vp, ctypes.c_int, _dp]),
     "vg_problem_add_odometry_prior": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int64, ctypes.c_double, ctypes.c_double,
                                                      ctypes.c_double, _dp, _dp]),
+    "vg_problem_add_parameter_block": (ctypes.c_int, [_vp, ctypes.c_int, _dp, ctypes.c_int, _ip]),
+    "vg_problem_parameter_block_offset": (ctypes.c_int64, [_vp, ctypes.c_int]),
+    "vg_problem_add_odometry_cost": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int64, ctypes.c_double, ctypes.c_double,
+                                                    ctypes.c_double, ctypes.c_int, _dp, ctypes.c_int]),
+    "vg_odometry_cost_evaluate": (ctypes.c_int, [ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int, _dp, _dp, _dp,
+                                                 _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
     "vg_odometry_prior_evaluate": (ctypes.c_int, [ctypes.c_double, ctypes.c_double, ctypes.c_double, _dp, _dp, _dp, _dp, _dp,
                                                   _dp, _dp]),
     "vg_problem_set_pose_constant": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int64]),

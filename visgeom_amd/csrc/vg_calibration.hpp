@@ -7,8 +7,11 @@
 // Differences from the reference, all stated in DESIGN.md section 8:
 //   * "images" datasets need pre-extracted corners ("corners_file", same layout as ir_data's "data_file"): the
 //     corner detector (OpenCV) is out of scope.  "ir_data" is read exactly as the reference reads it.
-//   * odometry_intrinsic entries are rejected (OdometryCost is declared with one parameter block but added with three,
-//     broken as shipped); transformation_prior is accepted on global transforms; odometry is accepted.
+//   * odometry_intrinsic (:660-742) is accepted with the parameter blocks the reference ADDS the cost with (xi_i, xi_i+1,
+//     [radius_left, radius_right, track_gauge]); the reference declares OdometryCost with a single block of 6 and its
+//     report indexes cameraMap with the transform's name (broken as shipped).  Here the wheel geometry lives in
+//     intrinsicMap[transform] as in the reference and the report prints its three values.
+//   * transformation_prior is accepted on global transforms; odometry is accepted.
 //   * the per-image refinement of estimateInitialGrid runs as n INDEPENDENT problems in one launch (vg_refine_poses:
 //     own trust region per image, SoftLOneLoss(25)), the global-transform refinement as one batched problem with
 //     SoftLOneLoss(1) per block -- the reference's semantics (:1137-1155, :358-429), not its one-Ceres-solve-per-image loop.
@@ -155,6 +158,14 @@ struct vg_calibration {
         bool anchor;
     };
     std::vector<Odometry> odometry;
+    struct OdometryIntrinsic {  // data type "odometry_intrinsic": wheel increments + wheel geometry to calibrate
+        std::string transform;
+        double errV, errW, lambda;
+        std::vector<std::vector<double>> deltaQ;  // one [n][2] list of increments per interval
+        std::vector<double> prior;                // the geometry the blocks were constructed with
+        bool anchor;
+    };
+    std::vector<OdometryIntrinsic> odometryIntrinsic;
     std::string log;  // what the reference prints to stdout while parsing / solving
 
     vgcal::Array6d &getTransformData(const std::string &name, int idx)  // unified_calibration.h:161-165
@@ -581,6 +592,53 @@ inline void parse_data(vg_calibration *c, const vgjson::Value &root, const std::
             }
             init_transforms(c, data, di.at("init").as_string());
             // addGridResidualBlocks (:514-630) happens when the GPU problem is assembled, in compute()
+        } else if (type == "odometry_intrinsic") {  // :660-742
+            vg_calibration::OdometryIntrinsic od;
+            od.transform = di.at("transform").as_string();
+            if (c->transformInfoMap.find(od.transform) == c->transformInfoMap.end())
+                throw Error{VG_ERR_INVALID_ARGUMENT, od.transform + " has not been declared"};
+            if (c->transformInfoMap[od.transform].global)
+                throw Error{VG_ERR_INVALID_ARGUMENT, od.transform + " is global. Odometry must be a sequence"};
+            if (c->cameraModelMap.find(od.transform) != c->cameraModelMap.end())  // the reference would overwrite the camera's entry
+                throw Error{VG_ERR_INVALID_ARGUMENT, od.transform + " names a camera and an odometry transform"};
+            od.errV = di.at("err_v").as_number();
+            od.errW = di.at("err_w").as_number();
+            od.lambda = di.at("lambda").as_number();
+            od.prior = {di.at("radius_left").as_number(), di.at("radius_right").as_number(), di.at("track_gauge").as_number()};
+            c->intrinsicMap[od.transform] = od.prior;
+            std::string file = di.at("data_file").as_string();
+            if (!file.empty() && file[0] != '/') file = base_dir + file;
+            const vgjson::Value dataFile = vgjson::parse_file(file);  // the odometry increment measurements
+            for (auto &dataPoint : dataFile.arr) {
+                od.deltaQ.emplace_back();
+                for (auto &x : dataPoint.arr) {
+                    const std::vector<double> pt = x.as_vector();
+                    if (pt.size() < 2) throw Error{VG_ERR_INVALID_ARGUMENT, "a wheel increment needs two values"};
+                    od.deltaQ.back().push_back(pt[0]);
+                    od.deltaQ.back().push_back(pt[1]);
+                }
+                if (od.deltaQ.back().empty()) throw Error{VG_ERR_INVALID_ARGUMENT, "an odometry interval without wheel increments"};
+            }
+            const bool init = di.at("init").as_bool();
+            auto &seq = c->sequenceTransformMap[od.transform];
+            if (init) {  // use the odometry as initial values: xi_0 = 0, xi_i+1 = xi_i o zetaPrior_i (:695-730)
+                c->log += od.transform + "\n";
+                if (!seq.empty()) throw Error{VG_ERR_INVALID_ARGUMENT, od.transform + " has already been initialized"};
+                c->transformInfoMap[od.transform].initialized = true;
+                seq.push_back(Array6d{0, 0, 0, 0, 0, 0});
+                c->sequenceInitMap[od.transform].push_back(true);
+                for (auto &dq : od.deltaQ) {
+                    std::vector<Array6d> tf0;
+                    std::vector<std::array<double, 9>> jz;
+                    vgodo::wheel_chain(dq, od.prior.data(), tf0, jz);
+                    seq.push_back(compose(seq.back(), tf0.back()));
+                    c->sequenceInitMap[od.transform].push_back(true);
+                }
+            } else if (seq.size() < od.deltaQ.size() + 1) {  // the reference indexes elements i, i + 1 unchecked (:733-734)
+                throw Error{VG_ERR_INVALID_ARGUMENT, od.transform + " has fewer elements than the odometry intervals need"};
+            }
+            od.anchor = di.at("anchor").as_bool();
+            c->odometryIntrinsic.push_back(od);
         } else if (type == "odometry") {  // :743-807
             vg_calibration::Odometry od;
             od.transform = di.at("transform").as_string();
@@ -679,9 +737,15 @@ int vg_calibration_compute(vg_calibration *c, const vg_solve_options *options, v
         return code;
     };
     std::map<std::string, int> camId, tfId;
-    for (auto &x : c->intrinsicMap)
+    std::map<std::string, int> wheelId;  // intrinsicMap also holds the wheel geometry of odometry_intrinsic entries
+    for (auto &x : c->intrinsicMap) {
+        if (c->cameraModelMap.find(x.first) == c->cameraModelMap.end()) {
+            if ((rc = vg_problem_add_parameter_block(p, (int)x.second.size(), x.second.data(), 0, &wheelId[x.first])) != VG_OK) return bail(rc);
+            continue;
+        }
         if ((rc = vg_problem_add_camera(p, c->cameraModelMap[x.first], x.second.data(), c->cameraConstantMap[x.first], &camId[x.first])) != VG_OK)
             return bail(rc);
+    }
     for (auto &x : c->transformInfoMap) {
         const std::string &name = x.first;
         if (x.second.global) {
@@ -718,6 +782,13 @@ int vg_calibration_compute(vg_calibration *c, const vg_solve_options *options, v
                 return bail(rc);
         if (od.anchor && (rc = vg_problem_set_pose_constant(p, tfId[od.transform], 0)) != VG_OK) return bail(rc);
     }
+    for (auto &od : c->odometryIntrinsic) {  // one OdometryCost per interval (:719-737), optional anchor (:738-741)
+        for (size_t i = 0; i < od.deltaQ.size(); i++)
+            if ((rc = vg_problem_add_odometry_cost(p, tfId[od.transform], (int64_t)i, od.errV, od.errW, od.lambda, (int)(od.deltaQ[i].size() / 2),
+                                                   od.deltaQ[i].data(), wheelId[od.transform])) != VG_OK)
+                return bail(rc);
+        if (od.anchor && (rc = vg_problem_set_pose_constant(p, tfId[od.transform], 0)) != VG_OK) return bail(rc);
+    }
     for (auto &pr : c->transformationPriors)
         if ((rc = vg_problem_add_transformation_prior(p, tfId[pr.first], pr.second.data())) != VG_OK) return bail(rc);
     if ((rc = vg_problem_finalize(p)) != VG_OK) return bail(rc);
@@ -726,7 +797,8 @@ int vg_calibration_compute(vg_calibration *c, const vg_solve_options *options, v
     std::vector<double> x((size_t)vg_problem_num_parameters(p));
     if ((rc = vg_problem_get_parameters(p, x.data())) != VG_OK) return bail(rc);
     for (auto &kv : c->intrinsicMap) {
-        const int64_t off = vg_problem_camera_offset(p, camId[kv.first]);
+        const int64_t off = wheelId.count(kv.first) ? vg_problem_parameter_block_offset(p, wheelId[kv.first])
+                                                    : vg_problem_camera_offset(p, camId[kv.first]);
         for (size_t k = 0; k < kv.second.size(); k++) kv.second[k] = x[(size_t)off + k];
     }
     for (auto &kv : c->transformInfoMap) {

@@ -427,6 +427,56 @@ int vg_problem_add_odometry_prior(vg_problem *p, int transform_id, int64_t index
     return VG_OK;
 }
 
+int vg_problem_add_parameter_block(vg_problem *p, int size, const double *values, int constant, int *block_id)
+{
+    if (!p || !values) return fail(VG_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (p->finalized) return fail(VG_ERR_STATE, "problem already finalized");
+    if (size < 1 || size > 16) return fail(VG_ERR_INVALID_ARGUMENT, "parameter block size must be in [1, 16]");
+    vgi::ParamBlock b;
+    b.size = size;
+    b.constant = constant != 0;
+    b.init.assign(values, values + size);
+    p->pblocks.push_back(b);
+    if (block_id) *block_id = (int)p->pblocks.size() - 1;
+    return VG_OK;
+}
+
+int64_t vg_problem_parameter_block_offset(const vg_problem *p, int block_id)
+{
+    if (!p || !p->finalized || block_id < 0 || block_id >= (int)p->pblocks.size()) return -1;
+    return p->pblocks[block_id].offset;
+}
+
+int vg_problem_add_odometry_cost(vg_problem *p, int transform_id, int64_t index, double err_v, double err_w, double lambda,
+                                 int n_steps, const double *delta_q, int param_block_id)
+{
+    if (!p || !delta_q) return fail(VG_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (p->finalized) return fail(VG_ERR_STATE, "problem already finalized");
+    if (transform_id < 0 || transform_id >= (int)p->tfs.size()) return fail(VG_ERR_INVALID_ARGUMENT, "transform id out of range");
+    const Transform &t = p->tfs[transform_id];
+    if (t.global) return fail(VG_ERR_INVALID_ARGUMENT, "Odometry must be a sequence");  // :667-670
+    if (index < 0 || index + 1 >= t.count) return fail(VG_ERR_INVALID_ARGUMENT, "odometry index outside the sequence");
+    if (!(lambda > 0.)) return fail(VG_ERR_INVALID_ARGUMENT, "lambda must be positive");
+    if (n_steps < 1) return fail(VG_ERR_INVALID_ARGUMENT, "an odometry interval needs at least one wheel increment");
+    if (param_block_id < 0 || param_block_id >= (int)p->pblocks.size() || p->pblocks[param_block_id].size != 3)
+        return fail(VG_ERR_INVALID_ARGUMENT, "the odometry intrinsics must be a parameter block of size 3");
+    p->odoms.push_back(vgodo::make_cost_block(transform_id, index, err_v, err_w, lambda, delta_q, n_steps,
+                                              p->pblocks[param_block_id].init.data(), param_block_id));
+    return VG_OK;
+}
+
+int vg_odometry_cost_evaluate(double err_v, double err_w, double lambda, int n_steps, const double *delta_q, const double *intr_prior,
+                              const double *xi1, const double *xi2, const double *intr, double *zeta_prior, double *residual,
+                              double *J1, double *J2, double *J3)
+{
+    if (!delta_q || !intr_prior || !xi1 || !xi2 || !intr || !residual) return fail(VG_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!(lambda > 0.) || n_steps < 1) return fail(VG_ERR_INVALID_ARGUMENT, "lambda must be positive, n_steps >= 1");
+    const vgodo::Block b = vgodo::make_cost_block(0, 0, err_v, err_w, lambda, delta_q, n_steps, intr_prior, 0);
+    if (zeta_prior) std::memcpy(zeta_prior, b.zeta, sizeof b.zeta);
+    vgodo::evaluate_cost(b, xi1, xi2, intr, residual, J1, J2, J3);
+    return VG_OK;
+}
+
 int vg_odometry_prior_evaluate(double err_v, double err_w, double lambda, const double *xi1_odom, const double *xi2_odom,
                                const double *xi1, const double *xi2, double *residual, double *J1, double *J2)
 {
@@ -456,11 +506,13 @@ int vg_problem_finalize(vg_problem *p)
     int64_t off = 0;
     for (auto &c : p->cams) { c.offset = off; off += c.K; }
     for (auto &t : p->tfs) { t.offset = off; off += 6 * t.count; }
+    for (auto &b : p->pblocks) { b.offset = off; off += b.size; }
     p->n_params = off;
     std::vector<double> h((size_t)off, 0.);
     for (auto &c : p->cams) std::memcpy(h.data() + c.offset, c.init.data(), sizeof(double) * c.K);
     for (auto &t : p->tfs)
         if (t.count) std::memcpy(h.data() + t.offset, t.init.data(), sizeof(double) * 6 * (size_t)t.count);
+    for (auto &b : p->pblocks) std::memcpy(h.data() + b.offset, b.init.data(), sizeof(double) * (size_t)b.size);
     VG_HIP(hipMalloc(&p->d_params, sizeof(double) * (size_t)(off > 0 ? off : 1)));
     if (off) VG_HIP(hipMemcpy(p->d_params, h.data(), sizeof(double) * (size_t)off, hipMemcpyHostToDevice));
 

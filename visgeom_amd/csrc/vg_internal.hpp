@@ -40,6 +40,14 @@ struct Transform {
     std::vector<double> init;
 };
 
+// a free-standing global parameter block (the wheel radii / track gauge of OdometryCost, unified_calibration.cpp:680-683)
+struct ParamBlock {
+    int size = 0;
+    bool constant = false;
+    int64_t offset = -1;
+    std::vector<double> init;
+};
+
 struct Dataset {
     int camera = -1, L = 0, N = 0;
     int tids[vg::kMaxChain] = {0};
@@ -77,6 +85,7 @@ struct vg_problem {
     std::vector<vgi::Camera> cams;
     std::vector<vgi::Transform> tfs;
     std::vector<vgi::Dataset> dss;
+    std::vector<vgi::ParamBlock> pblocks;
     std::vector<vgi::Prior> priors;
     std::vector<vgodo::Block> odoms;                       // OdometryPrior blocks (consecutive elements of a sequence)
     std::vector<std::pair<int, int64_t>> const_poses;     // (sequence transform, index) held constant ("anchor")

@@ -132,19 +132,24 @@ inline void prior_residual(const vgi::Prior &pr, const double *xi6, double *r)
 struct CoupledSeq {
     int tf = -1;
     int64_t pb = 0, n = 0, param_off = 0;   // first pose block, number of elements, first parameter of the range
-    std::vector<vgodo::Block> blocks;       // sorted by element index
+    std::vector<vgodo::Block> blocks;       // sorted by element index; OdometryCost blocks carry pblock >= 0
+    std::vector<int> pb_goff;               // global column of every parameter block (shared by all sequences)
     std::vector<std::pair<int64_t, vgi::Prior>> unary;  // TransformationPrior blocks on single elements of the range
     std::vector<unsigned char> frozen;      // per element
     std::vector<double> x, xc;              // current / candidate values [n][6]
     std::vector<double> Cf, Bs;             // per element: Cholesky factor C_i (lower, 6x6 row-major), B_i = L_{i+1,i}
     std::vector<double> Y, g, Dd;           // rows [6n][C], full gradient [6n], clamped undamped diagonal [6n]
 
-    double cost2(const std::vector<double> &xv) const
+    // xg: values of the global columns at the same point (the odometry intrinsics of OdometryCost blocks live there)
+    double cost2(const std::vector<double> &xv, const double *xg) const
     {
         double c = 0.;
         for (const auto &b : blocks) {
             double r[6];
-            vgodo::evaluate(b, &xv[(size_t)b.i * 6], &xv[(size_t)(b.i + 1) * 6], r, nullptr, nullptr);
+            if (b.pblock >= 0)
+                vgodo::evaluate_cost(b, &xv[(size_t)b.i * 6], &xv[(size_t)(b.i + 1) * 6], xg + pb_goff[(size_t)b.pblock], r, nullptr, nullptr, nullptr);
+            else
+                vgodo::evaluate(b, &xv[(size_t)b.i * 6], &xv[(size_t)(b.i + 1) * 6], r, nullptr, nullptr);
             for (int k = 0; k < 6; k++) c += r[k] * r[k];
         }
         for (const auto &u : unary) {
@@ -174,9 +179,32 @@ struct CoupledSeq {
 
     // rec: [n][kPoseRec] raw V (packed lower) | g | diag ;  raw: [6n][C] raw W^T | g columns.  Returns false when a
     // diagonal block is not positive definite.
-    bool eliminate(const double *rec, const double *raw, int G, double mu, double dmin, double dmax)
+    // OdometryCost blocks: what they add to the GLOBAL part of the normal equations (J3^T J3, J3^T r); their pose and
+    // pose-global parts are handled by eliminate()
+    void add_global_terms(const std::vector<double> &xv, const double *xg, int G, std::vector<double> &Uo, std::vector<double> &go) const
+    {
+        for (const auto &b : blocks) {
+            if (b.pblock < 0) continue;
+            const int g0 = pb_goff[(size_t)b.pblock];
+            double r[6], J3[18];
+            vgodo::evaluate_cost(b, &xv[(size_t)b.i * 6], &xv[(size_t)(b.i + 1) * 6], xg + g0, r, nullptr, nullptr, J3);
+            for (int a2 = 0; a2 < 3; a2++) {
+                for (int b2 = 0; b2 < 3; b2++) {
+                    double h = 0.;
+                    for (int k = 0; k < 6; k++) h += J3[3 * k + a2] * J3[3 * k + b2];
+                    Uo[(size_t)(g0 + a2) * G + g0 + b2] += h;
+                }
+                double gs = 0.;
+                for (int k = 0; k < 6; k++) gs += J3[3 * k + a2] * r[k];
+                go[(size_t)(g0 + a2)] += gs;
+            }
+        }
+    }
+
+    bool eliminate(const double *rec, const double *raw, int G, double mu, double dmin, double dmax, const double *xg)
     {
         const int C = G + 1;
+        std::vector<double> Wodo;  // [6n][G] pose-global coupling of the OdometryCost blocks (J_pose^T J3), if any
         std::vector<double> H((size_t)n * 36, 0.), E((size_t)n * 36, 0.);  // diagonal blocks, E_i = H_{i,i+1}
         g.assign((size_t)n * 6, 0.);
         for (int64_t i = 0; i < n; i++) {
@@ -187,7 +215,24 @@ struct CoupledSeq {
         }
         for (const auto &b : blocks) {
             double r[6], J1[36], J2[36];
-            vgodo::evaluate(b, &x[(size_t)b.i * 6], &x[(size_t)(b.i + 1) * 6], r, J1, J2);
+            if (b.pblock >= 0) {
+                double J3[18];
+                const int g0 = pb_goff[(size_t)b.pblock];
+                vgodo::evaluate_cost(b, &x[(size_t)b.i * 6], &x[(size_t)(b.i + 1) * 6], xg + g0, r, J1, J2, J3);
+                if (Wodo.empty()) Wodo.assign((size_t)n * 6 * G, 0.);
+                for (int a2 = 0; a2 < 6; a2++)
+                    for (int c3 = 0; c3 < 3; c3++) {
+                        double s1 = 0., s2 = 0.;
+                        for (int k = 0; k < 6; k++) {
+                            s1 += J1[6 * k + a2] * J3[3 * k + c3];
+                            s2 += J2[6 * k + a2] * J3[3 * k + c3];
+                        }
+                        Wodo[((size_t)b.i * 6 + a2) * G + g0 + c3] += s1;
+                        Wodo[((size_t)(b.i + 1) * 6 + a2) * G + g0 + c3] += s2;
+                    }
+            } else {
+                vgodo::evaluate(b, &x[(size_t)b.i * 6], &x[(size_t)(b.i + 1) * 6], r, J1, J2);
+            }
             double *H1 = &H[(size_t)b.i * 36], *H2 = &H[(size_t)(b.i + 1) * 36], *Ei = &E[(size_t)b.i * 36];
             for (int a2 = 0; a2 < 6; a2++) {
                 for (int b2 = 0; b2 < 6; b2++) {
@@ -226,7 +271,8 @@ struct CoupledSeq {
         std::vector<double> R((size_t)n * 6 * C);  // right-hand sides [W^T | g] with the odometry gradient in the last column
         for (int64_t i = 0; i < n; i++) {
             for (int k = 0; k < 6; k++) {
-                for (int c = 0; c < G; c++) R[((size_t)i * 6 + k) * C + c] = raw[((size_t)i * 6 + k) * C + c];
+                for (int c = 0; c < G; c++)
+                    R[((size_t)i * 6 + k) * C + c] = raw[((size_t)i * 6 + k) * C + c] + (Wodo.empty() ? 0. : Wodo[((size_t)i * 6 + k) * G + c]);
                 R[((size_t)i * 6 + k) * C + G] = g[(size_t)i * 6 + k];
             }
             if (frozen[(size_t)i]) {  // constant element: unit block, no coupling, zero right-hand side
@@ -387,6 +433,8 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
     for (size_t c = 0; c < p->cams.size(); c++) { cam_goff[c] = G; G += p->cams[c].K; }
     for (size_t t = 0; t < p->tfs.size(); t++)
         if (p->tfs[t].global) { tf_goff[t] = G; G += 6; }
+    std::vector<int> pb_goff(p->pblocks.size());
+    for (size_t b = 0; b < p->pblocks.size(); b++) { pb_goff[b] = G; G += p->pblocks[b].size; }
     if (G > 127) return fail(VG_ERR_INVALID_ARGUMENT, "more than 127 global columns are not supported");
     int64_t n_poses = 0;
     for (size_t t = 0; t < p->tfs.size(); t++)
@@ -403,6 +451,11 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             gcol_param[cam_goff[c] + k] = p->cams[c].offset + k;
             if (opt.use_bounds && !p->cams[c].constant)
                 vg_intrinsic_bounds(p->cams[c].model, k, &lo[p->cams[c].offset + k], &hi[p->cams[c].offset + k]);
+        }
+    for (size_t b = 0; b < p->pblocks.size(); b++)
+        for (int k = 0; k < p->pblocks[b].size; k++) {
+            gfrozen[pb_goff[b] + k] = p->pblocks[b].constant;
+            gcol_param[pb_goff[b] + k] = p->pblocks[b].offset + k;
         }
     for (size_t t = 0; t < p->tfs.size(); t++) {
         const vgi::Transform &tf = p->tfs[t];
@@ -459,6 +512,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
     }
     for (auto &c2 : coupled) {
         std::sort(c2.blocks.begin(), c2.blocks.end(), [](const vgodo::Block &a2, const vgodo::Block &b2) { return a2.i < b2.i; });
+        c2.pb_goff = pb_goff;
         for (int64_t i = 0; i < c2.n; i++) pose_frozen[(size_t)(c2.pb + i)] = 2;
         c2.x.resize((size_t)c2.n * 6);
         c2.xc.resize((size_t)c2.n * 6);
@@ -953,7 +1007,8 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
     }
     for (auto &c2 : coupled) {
         VG_HIP(hipMemcpy(c2.x.data(), d_x.p + c2.param_off, sizeof(double) * c2.x.size(), hipMemcpyDeviceToHost));
-        cost2 += c2.cost2(c2.x);
+        cost2 += c2.cost2(c2.x, h_xg.data());
+        c2.add_global_terms(c2.x, h_xg.data(), G, U, gg);
     }
     double radius = opt.initial_trust_region_radius, decrease_factor = 2.;
     int iter = 0, n_success = 0, term = VG_TERM_NO_CONVERGENCE;
@@ -997,7 +1052,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
                 VG_HIP(hipMemcpyAsync(hraw.data(), d_rows.p + (size_t)c2.pb * 6 * C, sizeof(double) * hraw.size(),
                                       hipMemcpyDeviceToHost, st));
                 VG_HIP(hipStreamSynchronize(st));
-                if (!c2.eliminate(hrec.data(), hraw.data(), G, mu, opt.min_lm_diagonal, opt.max_lm_diagonal)) {
+                if (!c2.eliminate(hrec.data(), hraw.data(), G, mu, opt.min_lm_diagonal, opt.max_lm_diagonal, h_xcur.data())) {
                     coupled_ok = false;
                     std::fill(c2.Y.begin(), c2.Y.end(), 0.);
                     c2.Y.resize((size_t)c2.n * 6 * C, 0.);
@@ -1136,9 +1191,15 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             for (int a2 = 0; a2 < G; a2++) xg2 += h_xg[a2] * h_xg[a2];
             double gdp = sc[0] + host_scal[0], ddp = sc[1] + host_scal[1], dp2 = sc[2] + host_scal[2],
                    gp2 = sc[3] + host_scal[3], xp2 = sc[4], gmax_p = ps[0] > host_scal[4] ? ps[0] : host_scal[4];
+            // global values of the candidate: clamp(x + dg), as vg_apply_step_kernel does
+            std::vector<double> xg_c(G);
+            for (int a2 = 0; a2 < G; a2++) {
+                const double v = h_xg[a2] + dg[a2], l2 = lo[(size_t)gcol_param[a2]], h2 = hi[(size_t)gcol_param[a2]];
+                xg_c[a2] = v < l2 ? l2 : (v > h2 ? h2 : v);
+            }
             for (auto &c2 : coupled) {
                 VG_HIP(hipMemcpy(c2.xc.data(), d_xc.p + c2.param_off, sizeof(double) * c2.xc.size(), hipMemcpyDeviceToHost));
-                cost2_c += c2.cost2(c2.xc);
+                cost2_c += c2.cost2(c2.xc, xg_c.data());
             }
             {
                 std::vector<double> pack(Uc);
@@ -1164,14 +1225,8 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
                 // pose part of the gradient max-norm is replaced by its (summable) 2-norm, an upper bound:
                 // the gradient test can only fire later than Ceres' max-norm test, never earlier.
                 if (multi_rank) gmax_p = std::sqrt(gp2);
-                if (!p->priors.empty()) {  // global values of the candidate: clamp(x + dg), as vg_apply_step_kernel does
-                    std::vector<double> xg_c(G);
-                    for (int a2 = 0; a2 < G; a2++) {
-                        const double v = h_xg[a2] + dg[a2], l2 = lo[(size_t)gcol_param[a2]], h2 = hi[(size_t)gcol_param[a2]];
-                        xg_c[a2] = v < l2 ? l2 : (v > h2 ? h2 : v);
-                    }
-                    add_priors(xg_c, Uc, ggc, cost2_c);
-                }
+                if (!p->priors.empty()) add_priors(xg_c, Uc, ggc, cost2_c);
+                for (auto &c2 : coupled) c2.add_global_terms(c2.xc, xg_c.data(), G, Uc, ggc);
             }
             double gdg = 0., ddg = 0., dg2 = 0., gmax_g = 0.;
             for (int a2 = 0; a2 < G; a2++) {

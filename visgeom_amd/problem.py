@@ -198,6 +198,22 @@ class CalibrationProblem:
         a, b = _c(xi1), _c(xi2)
         capi.check(self._lib.vg_problem_add_odometry_prior(self._h, transform, index, err_v, err_w, lam, _ptr(a), _ptr(b)))
 
+    def add_parameter_block(self, values, constant=False):
+        """a free-standing global parameter block (e.g. the odometry intrinsics); returns its id"""
+        v = _c(values)
+        bid = ctypes.c_int(-1)
+        capi.check(self._lib.vg_problem_add_parameter_block(self._h, v.size, _ptr(v), int(constant), ctypes.byref(bid)))
+        return bid.value
+
+    def parameter_block_offset(self, block):
+        return self._lib.vg_problem_parameter_block_offset(self._h, block)
+
+    def add_odometry_cost(self, transform, index, err_v, err_w, lam, delta_q, block):
+        """OdometryCost block (odometry_cost_function.h:33-57) between elements index and index + 1 of a sequence and
+        the 3-vector parameter block of the odometry intrinsics; delta_q [n, 2] wheel increments of the interval"""
+        dq = _c(delta_q).reshape(-1, 2)
+        capi.check(self._lib.vg_problem_add_odometry_cost(self._h, transform, index, err_v, err_w, lam, dq.shape[0], _ptr(dq), block))
+
     def set_pose_constant(self, transform, index):
         capi.check(self._lib.vg_problem_set_pose_constant(self._h, transform, index))
 

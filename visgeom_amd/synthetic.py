@@ -295,6 +295,102 @@ def make_handeye(n_frames, config_index=6, sigma=0.1, odo_sigma=0.002):
             "gt_base": base, "odometry": odo, "seed": seed}
 
 
+GT_WHEELS = np.array([0.05, 0.05, 0.30])        # [radius_left, radius_right, track_gauge], metres
+INIT_WHEELS = np.array([0.052, 0.0485, 0.315])
+
+
+def wheel_step(intr, dq):
+    """One wheel increment [d_left, d_right] (radians) -> the base motion [v, 0, 0, 0, 0, w] of
+    odometry_cost_function.cpp:10-36: v = (r1 dl + r2 dr) / 2, w = (r2 dr - r1 dl) / g."""
+    r1, r2, g = intr
+    return np.array([(r1 * dq[0] + r2 * dq[1]) / 2, 0, 0, 0, 0, (r2 * dq[1] - r1 * dq[0]) / g])
+
+
+def make_wheeled(n_frames, steps=5, config_index=7, sigma=0.1, q_sigma=2e-3):
+    """Differential-drive set for the odometry_intrinsic path (unified_calibration.cpp:660-742): an EUCM camera
+    looking forward from a wheeled base that weaves in front of a fixed board; between consecutive frames the base
+    integrates `steps` wheel increments [d_left, d_right] (radians).  Same camera chain as make_handeye
+    [xiBaseCam INVERSE, xiOdomBase INVERSE, xiOdomBoard DIRECT]; xiOdomBase_0 = identity.  The measured increments
+    carry q_sigma of noise; GT_WHEELS generated the motion, INIT_WHEELS is where a calibration would start."""
+    seed = BASE_SEED + config_index
+    board = board_points()
+    gt = GT_EUCM_CAM1.copy()
+    centre = np.array([board[:, 0].max() / 2, board[:, 1].max() / 2, 0.0])
+    # camera z = base x (forward), camera x = -base y, camera y = -base z, plus a small mounting error
+    R_bc = np.array([[0.0, 0, 1], [-1, 0, 0], [0, -1, 0]]) @ rodrigues(np.array([0.03, -0.02, 0.015]))
+    T_bc = np.eye(4)
+    T_bc[:3, :3] = R_bc
+    T_bc[:3, 3] = [0.10, 0.02, 0.30]
+    T_cb0 = _se3(np.array([0, 0, 0.9, 0.10, -0.15, 0.05]))
+    T_cb0[:3, 3] -= T_cb0[:3, :3] @ centre
+    T_oboard = T_bc @ T_cb0
+    k = np.arange((n_frames - 1) * steps, dtype=np.uint64)
+    zero = np.zeros_like(k)
+    # slow weave: a common forward/backward term and a differential term, both smooth in time, plus jitter
+    t = np.arange((n_frames - 1) * steps) / max(1, (n_frames - 1) * steps)
+    common = 0.35 * np.sin(2 * np.pi * 2 * t) + 0.1 * (uniform(seed, zero, k + np.uint64(PERTURB_OFFSET + 8192)) - 0.5)
+    diff = 0.18 * np.cos(2 * np.pi * 3 * t) + 0.1 * (uniform(seed, zero + np.uint64(1), k + np.uint64(PERTURB_OFFSET + 8192)) - 0.5)
+    dq_gt = np.stack([common - diff, common + diff], -1).reshape(n_frames - 1, steps, 2)
+    T = np.eye(4)
+    base = [np.zeros(6)]
+    for i in range(n_frames - 1):
+        for s_ in range(steps):
+            T = T @ _se3(wheel_step(GT_WHEELS, dq_gt[i, s_]))
+        base.append(_xi_of(T))
+    base = np.stack(base)
+    cam_board = np.stack([np.linalg.inv(T_bc) @ np.linalg.inv(_se3(b)) @ T_oboard for b in base])
+    X = np.einsum("nij,kj->nki", cam_board[:, :3, :3], board) + cam_board[:, None, :3, 3]
+    uv, ok = project("eucm", gt, X)
+    if not _accept(uv, ok).all():
+        raise RuntimeError("the board leaves the image of the wheeled base")
+    na, nb = normal_pair(seed, np.repeat(np.arange(n_frames - 1, dtype=np.uint64), steps),
+                         np.tile(np.arange(steps, dtype=np.uint64), n_frames - 1) + np.uint64(PERTURB_OFFSET + 12288))
+    dq = dq_gt + q_sigma * np.stack([na, nb], -1).reshape(n_frames - 1, steps, 2)
+    xi_bc = _xi_of(T_bc)
+    return {"board": board, "corners": uv + _noise(seed, n_frames, board.shape[0], sigma), "gt_intrinsics": gt,
+            "init_intrinsics": INIT["eucm"].copy(), "gt_xi_base_cam": xi_bc, "gt_xi_odom_board": _xi_of(T_oboard),
+            "init_xi_base_cam": xi_bc + _perturb(seed, 1, 6, salt=11)[0],
+            "init_xi_odom_board": _xi_of(T_oboard) + _perturb(seed, 1, 6, salt=12)[0],
+            "gt_base": base, "delta_q": dq, "gt_delta_q": dq_gt, "gt_wheels": GT_WHEELS.copy(),
+            "init_wheels": INIT_WHEELS.copy(), "seed": seed}
+
+
+def write_wheeled_json(directory, d, name="wheeled", err_v=0.05, err_w=0.05, lam=0.05, anchor=True, init=True):
+    """A calibration file using the "odometry_intrinsic" data type (unified_calibration.cpp:660-742) for a set made
+    by make_wheeled: wheel increments in <name>_wheels.json (a list of intervals, each a list of [d_left, d_right]),
+    the sequence xiOdomBase initialised by chaining the increments under the prior wheel geometry ("init": true)."""
+    import json
+    import os
+
+    board = d["board"]
+    n = d["corners"].shape[0]
+    corners_file, wheels_file = name + "_corners.json", name + "_wheels.json"
+    with open(os.path.join(directory, corners_file), "w") as f:
+        json.dump([[{"camera": "cam", "points": d["corners"][i].tolist()}] for i in range(n)], f)
+    with open(os.path.join(directory, wheels_file), "w") as f:
+        json.dump(d["delta_q"].tolist(), f)
+    odo = {"type": "odometry_intrinsic", "transform": "xiOdomBase", "err_v": err_v, "err_w": err_w, "lambda": lam,
+           "radius_left": float(d["init_wheels"][0]), "radius_right": float(d["init_wheels"][1]),
+           "track_gauge": float(d["init_wheels"][2]), "init": bool(init), "anchor": bool(anchor), "data_file": wheels_file}
+    grid = {"type": "ir_data", "camera": "cam", "parameters": [], "init": "none",
+            "transform_chain": [{"name": "xiBaseCam", "direct": False}, {"name": "xiOdomBase", "direct": False},
+                                {"name": "xiOdomBoard", "direct": True}],
+            "image_width": IMAGE_W, "image_height": IMAGE_H, "data_file": corners_file,
+            "object": {"points": board.tolist(), "corner_ul": 0, "corner_ur": BOARD_COLS - 1,
+                       "corner_bl": BOARD_COLS * (BOARD_ROWS - 1), "corner_br": BOARD_COLS * BOARD_ROWS - 1}}
+    root = {"transformations": [{"name": "xiBaseCam", "global": True, "prior": True, "constant": False,
+                                 "value": d["init_xi_base_cam"].tolist()},
+                                {"name": "xiOdomBoard", "global": True, "prior": True, "constant": False,
+                                 "value": d["init_xi_odom_board"].tolist()},
+                                {"name": "xiOdomBase", "global": False, "prior": False, "constant": False}],
+            "cameras": [{"name": "cam", "type": "eucm", "constant": False, "value": d["init_intrinsics"].tolist()}],
+            "data": [odo, grid]}
+    path = os.path.join(directory, name + ".json")
+    with open(path, "w") as f:
+        json.dump(root, f, indent=1)
+    return path
+
+
 def write_calibration_json(directory, d, model, name="calib", camera="cam", sequence="xiCamBoard", prior=False,
                            init=True, flags=(), as_images=False, skip=()):
     """Config 1: write <name>.json (+ <name>_corners.json) in the reference's calibration schema (README.md:36-223,
