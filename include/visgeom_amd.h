@@ -341,7 +341,9 @@ typedef struct vg_solve_summary {
     double initial_cost, final_cost; /* 1/2 sum r^2, as Ceres reports it */
     int num_iterations, num_successful_steps, termination;
     double gradient_max_norm, final_radius;
-    double total_seconds, evaluate_seconds, schur_seconds, host_seconds;
+    double total_seconds, evaluate_seconds, schur_seconds, host_seconds; /* host-driven loop: time in evaluations / pose
+                                    elimination / host algebra; device-resident loop: evaluate_seconds = all iterations,
+                                    host_seconds = set-up (tables, buffers), schur_seconds = 0 */
     int num_global_columns;     /* G */
     int64_t num_pose_blocks;
     char message[160];
@@ -351,6 +353,10 @@ void vg_solve_options_init(vg_solve_options *o); /* the defaults listed above */
 /* Limits: at most 127 global columns (sum of the cameras' K + 6 per global transform: e.g. eight Mei cameras and
  * seven global transforms); any number of pose blocks below 2^28.  Beyond that VG_ERR_INVALID_ARGUMENT. */
 int vg_problem_solve(vg_problem *p, const vg_solve_options *options, vg_solve_summary *summary);
+/* A solve works in one device block and one pinned host block (index tables, Gram sets, Schur rows ...) which the library
+ * keeps for the next solve of the process instead of returning them (allocation was a third of a 10 k-image solve).
+ * This frees them; safe at any time between solves. */
+void vg_release_cached_memory(void);
 
 /* The per-image pose refinement of estimateInitialGrid (src/calibration/unified_calibration.cpp:1137-1155) for n
  * images at once: n INDEPENDENT problems -- one GenericProjectionJac block with chain {DIRECT} each, intrinsics

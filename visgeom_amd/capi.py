@@ -125,6 +125,7 @@ SIGNATURES = {
     "vg_comm_allreduce_sum": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, _vp]),
     "vg_comm_destroy": (None, [_vp]),
     "vg_solve_options_init": (None, [ctypes.POINTER(SolveOptions)]),
+    "vg_release_cached_memory": (None, []),
     "vg_problem_solve": (ctypes.c_int, [_vp, ctypes.POINTER(SolveOptions), ctypes.POINTER(SolveSummary)]),
     "vg_refine_poses": (ctypes.c_int, [ctypes.c_int, _vp, ctypes.c_int, _dp, ctypes.c_int, _dp, ctypes.c_int64, _dp, _dp,
                                        ctypes.POINTER(SolveOptions), _i32p, _dp, _i32p]),

@@ -187,6 +187,8 @@ void fill_gram_args(const vg_problem *p, const Dataset &d, vg::GramArgs &a, doub
     a.L = d.L;
     a.W = cam.K + 6 * d.L + 1;
     a.frame_stride_d = d.frame_stride;
+    a.gate = p->gram_gate;
+    a.gate_expect = p->gram_gate_expect;
 }
 
 template <int MODEL>

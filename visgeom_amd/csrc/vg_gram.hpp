@@ -40,7 +40,16 @@ struct GramArgs {
     int L;
     int W;
     int frame_stride_d;
+    // speculative launches of the LM loop (vg_solver_impl.hpp): the kernel returns at once unless *gate == gate_expect.
+    // NULL = always run.
+    const int *gate;
+    int gate_expect;
 };
+
+__device__ __forceinline__ bool gate_closed(const int *gate, int expect)
+{
+    return gate != nullptr && *reinterpret_cast<const volatile int *>(gate) != expect;
+}
 
 // D(16x16) += A(16x4) * B(4x16); lane l supplies A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15].
 __device__ __forceinline__ f64x4 mfma_f64_16x16x4(double a, double b, f64x4 c)
@@ -120,6 +129,7 @@ __global__ __launch_bounds__(kGramMaxWavesPerBlock *kWave) void vg_gram_fused_ke
     constexpr int K = CameraTraits<MODEL>::K;
     using d2 = HIP_vector_type<double, 2>;
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    if (gate_closed(a.gate, a.gate_expect)) return;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned int bA = 2 * (blockIdx.x * (blockDim.x >> 6) + wave);  // wave-uniform

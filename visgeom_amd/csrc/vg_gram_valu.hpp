@@ -190,6 +190,7 @@ __global__ __launch_bounds__(kValuThreads, 2) void vg_gram_valu_kernel(GramValuA
     using d2 = HIP_vector_type<double, 2>;
     __shared__ __attribute__((aligned(16))) double lds[kValuImagesPerBlock * FS + (kValuThreads / kWave) * E];
     double *fr_lds = lds, *red = lds + kValuImagesPerBlock * FS;
+    if (gate_closed(a.g.gate, a.g.gate_expect)) return;
 
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
     const int sl = lane & (kValuLanesPerImage - 1);
@@ -370,6 +371,32 @@ __global__ __launch_bounds__(256) void vg_gram_partials_sum_kernel(const double 
         out[r * W + c] = t;
         out[c * W + r] = t;
     }
+}
+
+// Sum of n_items row-major blocks of `entries` doubles: out[e] = sum_i in[i * entries + e], one workgroup per entry, every
+// lane's (strided) loads in flight together, fixed order.  One launch where slab + final sum were two: a few hundred small
+// blocks (the Gram of the pose rows per row group) are latency, not bandwidth.
+__global__ __launch_bounds__(256) void vg_gram_strided_sum_kernel(const double *__restrict__ in, unsigned int n_items, int entries,
+                                                                   double *__restrict__ out)
+{
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+    const int e = blockIdx.x;
+    double s = 0.;
+    for (unsigned int i0 = 0; i0 < n_items; i0 += 8 * 256) {
+        double v[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const unsigned int i = i0 + q * 256 + tid;
+            v[q] = i < n_items ? in[(size_t)i * entries + e] : 0.;
+        }
+        s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, kWave);
+    __shared__ double red[4];
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    if (tid == 0) out[e] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 }  // namespace vg

@@ -99,6 +99,8 @@ struct vg_problem {
     bool frames_stale = true;
     // test / measurement hook (vg_problem_force_prepared_frames): every kernel reads the reference-order frames of the
     // chain-prep launch instead of walking single-member chains itself
+    const int *gram_gate = nullptr;  // set by the solver around speculative launches (GramArgs::gate)
+    int gram_gate_expect = 0;
     bool force_prepared_frames = false;
 };
 

@@ -68,6 +68,8 @@ struct SchurArgs {
     double *rec;           // [n_poses][kPoseRec]
     double *rows;          // [n_poses * 6][G + 1]
     int *bad;              // number of poses whose damped block was not positive definite
+    const int *gate;       // speculative launches of the device loop: run only if *gate == gate_expect (NULL: always)
+    int gate_expect;
 };
 
 // The elimination of pose i: V_i, g_i gathered from the Gram blocks of every dataset that references the pose, damping,
@@ -143,6 +145,7 @@ __global__ __launch_bounds__(256) void vg_schur_rows_kernel(SchurArgs a)
 {
     const int C = a.G + 1;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gate_closed(a.gate, a.gate_expect)) return;
     if (t >= (long long)a.n_poses * C) return;
     const int i = (int)(t / C), gcol = (int)(t - (long long)i * C);
     PoseFactor f;
@@ -230,6 +233,7 @@ __global__ __launch_bounds__(kBsThreads) void vg_backsub_kernel(BacksubArgs b)
 {
     const SchurArgs &a = b.s;
     const int t = blockIdx.x * kBsThreads + threadIdx.x;
+    if (gate_closed(a.gate, a.gate_expect)) return;
     if (t < a.G) {
         const long long gp = b.gcol_param[t];
         b.delta[gp] = b.dg[t];

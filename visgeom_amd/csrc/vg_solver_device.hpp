@@ -18,6 +18,8 @@ struct LmState {
     double grad_max, step_norm, rho, cost_change, model_change;
     int ucur;                          // which of the two U / g slots belongs to the current point
     int step_ok, accepted, done, term, iter, n_success, n_bad;
+    int gate;                          // ucur while the solve runs, -1 once done: what speculatively queued launches test
+    double cost2_init;                 // twice the cost at the starting point
 };
 
 struct LmSolveArgs {
@@ -31,6 +33,7 @@ struct LmSolveArgs {
     double *dg;                        // [G] out: global step
     double *S;                         // [G*G] global scratch for the damped reduced matrix, or NULL: it fits the LDS too
     int G, use_bounds;
+    int gate_expect;                   // run only if st->gate == gate_expect (-1: no test)
     double dmin, dmax;
 };
 
@@ -57,7 +60,7 @@ __global__ __launch_bounds__(kLmThreads) void vg_lm_reduced_solve_kernel(LmSolve
     const int G = a.G, C = G + 1, tid = threadIdx.x;
     const int kT = blockDim.x;
     LmState *st = a.st;
-    if (st->done) return;
+    if (st->done || (a.gate_expect >= 0 && st->gate != a.gate_expect)) return;
     double *A = sm, *rhs = A + (size_t)G * G, *b = rhs + G, *x = b + G, *heldf = x + G, *flags = heldf + G;
     double *S = a.S ? a.S : flags + 2;  // the damped matrix survives the active-set passes: LDS when both fit
     const double mu = st->mu;
@@ -150,6 +153,12 @@ struct LmAcceptArgs {
     const double *lo, *hi;
     const unsigned char *gfrozen;
     int n_ds, Wmax, G, init, multi_rank;
+    const double *scal_partials;       // [n_scal][5] per-workgroup partials of the back-substitution's scalar sums, or NULL:
+    unsigned int n_scal;               //   they were summed (and all-reduced) into sums[n_ds * Wmax^2 ..] by the caller
+    int gate_expect;                   // run only if st->gate == gate_expect (-1: no test)
+    LmState *host_state;               // pinned host memory (device-visible): the state after this call, for the host's
+                                       //   decisions -- written by the kernel itself: a copy command between two kernels of
+                                       //   a stream costs two engine hand-overs (~20 us), a store costs nothing
     size_t lds_doubles;                // dynamic LDS given to the launch, in doubles
     double dmin, dmax, ftol, gtol, ptol, min_rel_decrease, max_radius, min_radius;
 };
@@ -158,7 +167,7 @@ __global__ __launch_bounds__(kLmThreads) void vg_lm_accept_kernel(LmAcceptArgs a
 {
     const int G = a.G, tid = threadIdx.x;
     LmState *st = a.st;
-    if (st->done) return;
+    if (st->done || (a.gate_expect >= 0 && st->gate != a.gate_expect)) return;
     const int slot = a.init ? st->ucur : 1 - st->ucur;  // where the freshly evaluated point's blocks go
     double *Uc = a.U + (size_t)slot * G * G, *gc = a.gg + (size_t)slot * G;
     const size_t WW = (size_t)a.Wmax * a.Wmax;
@@ -211,17 +220,40 @@ __global__ __launch_bounds__(kLmThreads) void vg_lm_accept_kernel(LmAcceptArgs a
             s_fz[k] = a.gfrozen[k];
         }
     }
+    // the five scalar sums of the step: summed here (fixed order) unless the caller already did (several ranks)
+    __shared__ double s_sc[5], s_red[5][kLmThreads / kWave];
+    if (a.scal_partials && !a.init) {
+        double acc[5] = {0., 0., 0., 0., 0.};
+        for (unsigned int i = tid; i < a.n_scal; i += kLmThreads)
+#pragma unroll
+            for (int q = 0; q < 5; q++) acc[q] += a.scal_partials[(size_t)i * 5 + q];
+#pragma unroll
+        for (int q = 0; q < 5; q++) {
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) acc[q] += __shfl_xor(acc[q], off, kWave);
+            if ((tid & (kWave - 1)) == 0) s_red[q][tid >> 6] = acc[q];
+        }
+    }
+    __syncthreads();
+    if (tid < 5 && a.scal_partials && !a.init) {
+        double t = 0.;
+        for (int w = 0; w < kLmThreads / kWave; w++) t += s_red[tid][w];
+        s_sc[tid] = t;
+    }
     __syncthreads();
     if (tid != 0) return;
     double cost2_c = 0.;
     for (int d = 0; d < a.n_ds; d++) cost2_c += a.sums[d * WW + (size_t)a.Wd[d] * a.Wd[d] - 1];
     if (a.init) {
         st->cost2 = cost2_c;
+        st->cost2_init = cost2_c;
         st->mu = 1. / st->radius;
+        st->gate = st->ucur;
+        if (a.host_state) *a.host_state = *st;
         return;
     }
     st->cost2_c = cost2_c;
-    const double *sc = a.sums + (size_t)a.n_ds * WW;
+    const double *sc = a.scal_partials ? s_sc : a.sums + (size_t)a.n_ds * WW;
     const int n_bad = *a.bad;
     *a.bad = 0;
     double gmax_p = __longlong_as_double((long long)*a.gmax_bits);
@@ -268,7 +300,11 @@ __global__ __launch_bounds__(kLmThreads) void vg_lm_accept_kernel(LmAcceptArgs a
     st->cost_change = cost_change;
     st->model_change = model_change;
     st->accepted = 0;
-    if (st->done) return;
+    if (st->done) {
+        st->gate = -1;
+        if (a.host_state) *a.host_state = *st;
+        return;
+    }
     const bool success = step_ok && isfinite(cost2_c) && rho > a.min_rel_decrease;
     if (success) {
         st->n_success++;
@@ -294,6 +330,8 @@ __global__ __launch_bounds__(kLmThreads) void vg_lm_accept_kernel(LmAcceptArgs a
         }
     }
     st->mu = 1. / st->radius;
+    st->gate = st->done ? -1 : st->ucur;
+    if (a.host_state) *a.host_state = *st;
 }
 
 }  // namespace vg

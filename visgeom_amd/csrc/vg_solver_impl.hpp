@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <vector>
 
 #include "vg_internal.hpp"
@@ -52,20 +53,142 @@ bool chol_solve(int n, const double *A, const double *b, double *x)
     return true;
 }
 
+// ---- memory of one solve -----------------------------------------------------------------------------------
+// A solve needs ~40 device buffers, a dozen small uploads and a few pinned read-back buffers.  One hipMalloc /
+// hipMemcpy / hipHostMalloc each made the set-up 0.45 ms of a 1.4 ms solve (10 k EUCM images), so they come out of ONE
+// device allocation and ONE pinned allocation per solve: region U holds the uploads (staged at the same offsets of the
+// pinned block, ONE asynchronous copy at flush()), the rest is bump-allocated scratch.  Both blocks are kept for the
+// next solve of the process (vg_release_cached_memory frees them); anything that does not fit falls back to its own
+// allocation.
+struct SolveArena {
+    char *dev = nullptr, *pin = nullptr;
+    size_t dev_cap = 0, pin_cap = 0;
+    size_t up_cap = 0, up_used = 0;   // [0, up_cap) of both blocks: uploads
+    size_t dev_used = 0, pin_used = 0;  // bump pointers behind the upload region
+    int device = -1;
+    bool flushed = false;
+    static size_t align(size_t n) { return (n + 255) & ~(size_t)255; }
+    void *dev_alloc(size_t bytes)
+    {
+        const size_t o = align(dev_used);
+        if (!dev || o + bytes > dev_cap) return nullptr;
+        dev_used = o + bytes;
+        return dev + o;
+    }
+    void *pin_alloc(size_t bytes)
+    {
+        const size_t o = align(pin_used);
+        if (!pin || o + bytes > pin_cap) return nullptr;
+        pin_used = o + bytes;
+        return pin + o;
+    }
+    // device address of an upload of `bytes`, its bytes staged for flush(); NULL when the region is full / already flushed
+    void *upload(const void *src, size_t bytes)
+    {
+        const size_t o = align(up_used);
+        if (!dev || !pin || flushed || o + bytes > up_cap) return nullptr;
+        std::memcpy(pin + o, src, bytes);
+        up_used = o + bytes;
+        return dev + o;
+    }
+    int flush(hipStream_t st)
+    {
+        if (!flushed && up_used) VG_HIP(hipMemcpyAsync(dev, pin, up_used, hipMemcpyHostToDevice, st));
+        flushed = true;
+        return VG_OK;
+    }
+};
+
+struct ArenaCache {
+    std::mutex m;
+    char *dev = nullptr, *pin = nullptr;
+    size_t dev_cap = 0, pin_cap = 0;
+    int device = -1;
+    void drop()
+    {
+        if (dev) {
+            (void)hipSetDevice(device);
+            (void)hipFree(dev);
+        }
+        if (pin) (void)hipHostFree(pin);
+        dev = pin = nullptr;
+        dev_cap = pin_cap = 0;
+    }
+};
+ArenaCache g_arena_cache;
+thread_local SolveArena *t_arena = nullptr;
+
+// takes the cached blocks when they are large enough, allocates otherwise; the destructor hands the blocks back
+struct ArenaScope {
+    SolveArena a;
+    ArenaScope(int device, size_t dev_need, size_t pin_need, size_t up_cap)
+    {
+        {
+            std::lock_guard<std::mutex> lk(g_arena_cache.m);
+            if (g_arena_cache.dev && g_arena_cache.device == device && g_arena_cache.dev_cap >= dev_need && g_arena_cache.pin_cap >= pin_need) {
+                a.dev = g_arena_cache.dev;
+                a.pin = g_arena_cache.pin;
+                a.dev_cap = g_arena_cache.dev_cap;
+                a.pin_cap = g_arena_cache.pin_cap;
+                g_arena_cache.dev = g_arena_cache.pin = nullptr;
+                g_arena_cache.dev_cap = g_arena_cache.pin_cap = 0;
+            }
+        }
+        if (!a.dev) {
+            if (hipMalloc(reinterpret_cast<void **>(&a.dev), dev_need) != hipSuccess) a.dev = nullptr;
+            if (a.dev && hipHostMalloc(reinterpret_cast<void **>(&a.pin), pin_need, hipHostMallocDefault) != hipSuccess) {
+                (void)hipFree(a.dev);
+                a.dev = a.pin = nullptr;
+            }
+            (void)hipGetLastError();  // a failed block only means: every buffer takes its own allocation
+            a.dev_cap = a.dev ? dev_need : 0;
+            a.pin_cap = a.pin ? pin_need : 0;
+        }
+        a.device = device;
+        a.up_cap = up_cap < a.dev_cap && up_cap < a.pin_cap ? up_cap : 0;
+        a.dev_used = a.pin_used = a.up_cap;
+        t_arena = &a;
+    }
+    ~ArenaScope()
+    {
+        t_arena = nullptr;
+        if (!a.dev) return;
+        std::lock_guard<std::mutex> lk(g_arena_cache.m);
+        if (a.dev_cap >= g_arena_cache.dev_cap) {  // keep the larger one
+            g_arena_cache.drop();
+            g_arena_cache.dev = a.dev;
+            g_arena_cache.pin = a.pin;
+            g_arena_cache.dev_cap = a.dev_cap;
+            g_arena_cache.pin_cap = a.pin_cap;
+            g_arena_cache.device = a.device;
+        } else {
+            (void)hipFree(a.dev);
+            (void)hipHostFree(a.pin);
+        }
+    }
+    ArenaScope(const ArenaScope &) = delete;
+    ArenaScope &operator=(const ArenaScope &) = delete;
+};
+
 template <typename T>
 struct DevBuf {
     T *p = nullptr;
+    bool owned = false;
     ~DevBuf()
     {
-        if (p) (void)hipFree(p);
+        if (p && owned) (void)hipFree(p);
     }
     int alloc(size_t n)
     {
-        VG_HIP(hipMalloc(&p, sizeof(T) * (n ? n : 1)));
+        const size_t bytes = sizeof(T) * (n ? n : 1);
+        if (t_arena && (p = static_cast<T *>(t_arena->dev_alloc(bytes))) != nullptr) return VG_OK;
+        VG_HIP(hipMalloc(&p, bytes));
+        owned = true;
         return VG_OK;
     }
     int upload(const std::vector<T> &h)
     {
+        if (t_arena && !h.empty() && (p = static_cast<T *>(t_arena->upload(h.data(), sizeof(T) * h.size()))) != nullptr) return VG_OK;
         int rc = alloc(h.size());
         if (rc != VG_OK) return rc;
         if (!h.empty()) VG_HIP(hipMemcpy(p, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice));
@@ -77,14 +200,18 @@ struct DevBuf {
 struct PinnedBuf {
     double *p = nullptr;
     size_t n = 0;
+    bool owned = false;
     ~PinnedBuf()
     {
-        if (p) (void)hipHostFree(p);
+        if (p && owned) (void)hipHostFree(p);
     }
     int alloc(size_t count)
     {
         n = count;
-        VG_HIP(hipHostMalloc(reinterpret_cast<void **>(&p), sizeof(double) * (count ? count : 1), hipHostMallocDefault));
+        const size_t bytes = sizeof(double) * (count ? count : 1);
+        if (t_arena && (p = static_cast<double *>(t_arena->pin_alloc(bytes))) != nullptr) return VG_OK;
+        VG_HIP(hipHostMalloc(reinterpret_cast<void **>(&p), bytes, hipHostMallocDefault));
+        owned = true;
         return VG_OK;
     }
 };
@@ -385,6 +512,12 @@ struct CoupledSeq {
 
 extern "C" {
 
+void vg_release_cached_memory(void)
+{
+    std::lock_guard<std::mutex> lk(g_arena_cache.m);
+    g_arena_cache.drop();
+}
+
 void vg_solve_options_init(vg_solve_options *o)
 {
     if (!o) return;
@@ -423,6 +556,14 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
     hipStream_t st = p->stream;
     const double t_start = now_s();
     double t_eval = 0., t_schur = 0., t_host = 0.;
+    static const bool trace_setup = getenv("VG_SOLVER_TIMING") != nullptr;  // measurement hook: where the set-up time goes
+    double t_mark = t_start;
+    auto mark = [&](const char *what) {
+        if (!trace_setup) return;
+        const double t = now_s();
+        std::fprintf(stderr, "[vg_problem_solve] %-28s %8.1f us\n", what, (t - t_mark) * 1e6);
+        t_mark = t;
+    };
 
     // ---------------------------------------------------------------- column / pose bookkeeping
     const int n_ds = (int)p->dss.size();
@@ -571,12 +712,27 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
                 }
     }
 
+    mark("host index tables");
     // ---------------------------------------------------------------- device state
     const int C = G + 1;
     const unsigned int n_rows = (unsigned int)(6 * n_poses);
     const unsigned int rows_per_group = 96;  // 16 poses per wave: enough waves to fill the chip at 5 k poses
     const unsigned int n_groups = n_rows ? (n_rows + rows_per_group - 1) / rows_per_group : 0;
     const unsigned int n_slabs = (n_groups + vg::kSlab - 1) / vg::kSlab;
+    // one device block + one pinned block for the whole solve (SolveArena); sizes: the buffers below, generously rounded
+    size_t up_need = 64 * 1024 + (size_t)n_ds * 1024;
+    up_need += sizeof(int) * (inv.size() + ref_ptr.size() + ref_ds.size() + ref_blk.size()) + (size_t)n_poses * (1 + sizeof(long long));
+    up_need += sizeof(double) * 2 * (size_t)n_params + sizeof(long long) * (size_t)G + 16 * 256;
+    size_t dev_need = up_need + (4u << 20);
+    for (int d = 0; d < n_ds; d++) {
+        const size_t ww = (size_t)Wd[d] * Wd[d];
+        dev_need += 2 * sizeof(double) * ((size_t)p->dss[d].n_blocks * ww + 32) + sizeof(double) * ((size_t)p->dss[d].n_blocks / vg::kSlab + 2) * ww;
+    }
+    dev_need += sizeof(double) * (3 * (size_t)n_params + (size_t)n_poses * vg::kPoseRec + (size_t)n_rows * C + ((size_t)n_groups + n_slabs + 8) * C * C +
+                                  (size_t)n_poses + 8 * (size_t)C * C);
+    const size_t pin_need = up_need + (1u << 20) + sizeof(double) * ((size_t)n_ds * Wmax * Wmax + 4 * (size_t)C * C);
+    VG_HIP(hipSetDevice(p->device));
+    ArenaScope arena_scope(p->device, dev_need, pin_need, up_need);
     std::vector<DevBuf<double>> gramA_v((size_t)(n_ds ? n_ds : 1)), gramB_v((size_t)(n_ds ? n_ds : 1));  // sized once, never resized
     DevBuf<double> *const gramA = gramA_v.data(), *const gramB = gramB_v.data();
     DevBuf<double> d_sums, d_x, d_xc, d_delta, d_lo, d_hi, d_rec, d_rows, d_rgroups, d_rslabs, d_rgram, d_dg, d_scal;
@@ -593,6 +749,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
         hdsB[d] = {gramB[d].p, Wd[d], pose_off[d]};
     }
 #define VG_TRY(e) do { if ((rc = (e)) != VG_OK) return rc; } while (0)
+    mark("Gram set allocation");
     VG_TRY(d_dsA.upload(hdsA));
     VG_TRY(d_dsB.upload(hdsB));
     VG_TRY(d_inv.upload(inv));
@@ -604,6 +761,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
     VG_TRY(d_gcol_param.upload(gcol_param));
     VG_TRY(d_lo.upload(lo));
     VG_TRY(d_hi.upload(hi));
+    mark("uploads");
     VG_TRY(d_sums.alloc((size_t)n_ds * Wmax * Wmax + 5));
     VG_TRY(d_x.alloc((size_t)n_params));
     VG_TRY(d_xc.alloc((size_t)n_params));
@@ -643,6 +801,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
     VG_TRY(pin_rgram.alloc(h_rgram.size()));
     VG_TRY(pin_small.alloc((size_t)2 * G + 2));
 
+    mark("scratch + pinned allocation");
     // several datasets: their fixed-order sums run as ONE slab launch and ONE final launch (descriptor tables for
     // the two alternating Gram sets); a single dataset keeps the plain kernels
     std::vector<DevBuf<double>> sum_partials(n_ds);
@@ -801,14 +960,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
         VG_HIP(hipMemcpyAsync(d_state.p, &h0, sizeof h0, hipMemcpyHostToDevice, st));
         VG_HIP(hipMemsetAsync(d_bad.p, 0, sizeof(int), st));
         if (!n_poses) VG_HIP(hipMemsetAsync(d_rgram.p, 0, sizeof(double) * h_rgram.size(), st));
-        struct PinState {
-            vg::LmState *p = nullptr;
-            ~PinState()
-            {
-                if (p) (void)hipHostFree(p);
-            }
-        } pin_state;
-        VG_HIP(hipHostMalloc(reinterpret_cast<void **>(&pin_state.p), sizeof(vg::LmState), hipHostMallocDefault));
+        vg::LmState final_state;
 
         vg::LmAcceptArgs aa;
         aa.st = d_state.p;
@@ -831,6 +983,8 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
         aa.G = G;
         aa.init = 1;
         aa.multi_rank = multi_rank ? 1 : 0;
+        aa.scal_partials = (n_bs_groups && !multi_rank) ? d_scal.p : nullptr;
+        aa.n_scal = n_bs_groups;
         size_t accept_lds = sizeof(double) * ((size_t)n_ds * Wmax * Wmax + ((size_t)n_ds * G + 1) / 2 + 1);
         if (accept_lds > 48 * 1024) accept_lds = 0;  // many datasets: read from global memory
         aa.lds_doubles = accept_lds / sizeof(double);
@@ -864,25 +1018,53 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(vg::vg_lm_reduced_solve_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_lds));
 
-        DevBuf<double> *cur = gramA, *cand = gramB;
-        vg::SolveDatasetDev *ds_cur = d_dsA.p, *ds_cand = d_dsB.p;
-        auto read_state = [&]() -> int {
-            VG_HIP(hipMemcpyAsync(pin_state.p, d_state.p, sizeof(vg::LmState), hipMemcpyDeviceToHost, st));
-            VG_HIP(hipStreamSynchronize(st));
+        aa.gate_expect = -1;
+        ra.gate_expect = -1;
+        // An iteration is a fixed sequence of launches whose buffers depend only on the PARITY of the number of accepted
+        // steps so far (which Gram set / parameter buffer is "current"); the device keeps that parity in LmState::gate.
+        // So the host queues iteration k + 1 for the parity an acceptance of step k would give BEFORE it knows the
+        // outcome of step k -- every kernel of a queued iteration returns at once if the gate says otherwise (a
+        // rejected step: the same parity is queued again; convergence: gate = -1) -- and only then waits for the state
+        // of iteration k.  The GPU always has the next iteration in its queue: no launch latency, no idle time behind
+        // the host's read-back.  Robust (SoftLOne) evaluations re-weight the Gram set in place with an ungated kernel
+        // and RCCL calls cannot be skipped on one rank only, so those solves queue one iteration at a time.
+        // MEASURED (tools/exp/solve_probe.py, 10 k images, state published by the accept kernel itself): EUCM 0.112 vs
+        // 0.116 ms per iteration, Mei 0.145 vs 0.148 -- the iteration is bound by its eight dependent launches on the
+        // GPU, not by the host's read-back.  3 % is not worth a second code path by default: VG_SOLVER_SPECULATE=1.
+        const bool speculate = opt.soft_l1_scale <= 0. && !multi_rank && getenv("VG_SOLVER_SPECULATE") != nullptr;
+        DevBuf<double> *gset[2] = {gramA, gramB};
+        vg::SolveDatasetDev *dset[2] = {d_dsA.p, d_dsB.p};
+        double *xbuf[2] = {d_x.p, d_xc.p};
+        constexpr int kSlots = 4;
+        struct Slots {
+            vg::LmState *p = nullptr;
+            bool owned = false;
+            hipEvent_t ev[kSlots] = {};
+            ~Slots()
+            {
+                if (p && owned) (void)hipHostFree(p);
+                for (auto e : ev)
+                    if (e) (void)hipEventDestroy(e);
+            }
+        } slots;
+        if (t_arena) slots.p = static_cast<vg::LmState *>(t_arena->pin_alloc(sizeof(vg::LmState) * kSlots));
+        if (!slots.p) {
+            VG_HIP(hipHostMalloc(reinterpret_cast<void **>(&slots.p), sizeof(vg::LmState) * kSlots, hipHostMallocDefault));
+            slots.owned = true;
+        }
+        for (auto &e : slots.ev) VG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        int n_queued = 0;
+        // the accept kernel writes its state into pinned slot `slot` itself; the event tells the host when
+        auto next_slot = [&]() { return n_queued++ % kSlots; };
+        auto queue_state = [&](int slot) -> int {
+            VG_HIP(hipEventRecord(slots.ev[slot], st));
             return VG_OK;
         };
-        VG_HIP(hipMemcpyAsync(d_xc.p, d_x.p, sizeof(double) * (size_t)n_params, hipMemcpyDeviceToDevice, st));
-        VG_TRY(enqueue_evaluate(d_x.p, cur));
-        hipLaunchKernelGGL(vg::vg_lm_accept_kernel, dim3(1), dim3(vg::kLmThreads), accept_lds, st, aa);
-        VG_HIP(hipGetLastError());
-        VG_TRY(read_state());
-        const double initial_cost = 0.5 * pin_state.p->cost2;
-        if (opt.verbose) std::printf("iter      cost      cost_change  |gradient|   |step|    tr_ratio  tr_radius\n%4d  %.6e\n", 0, initial_cost);
-        aa.init = 0;
-        int iter = 0;
-        for (iter = 1; iter <= opt.max_num_iterations; iter++) {
+        // queue one LM iteration for parity `par` (current point = set / buffer `par`, candidate = the other one)
+        auto queue_iteration = [&](int par, bool gated, int &slot) -> int {
+            const int *gate = gated ? &d_state.p->gate : nullptr;
             vg::SchurArgs sa;
-            sa.ds = ds_cur;
+            sa.ds = dset[par];
             sa.inv = d_inv.p;
             sa.ref_ptr = d_ref_ptr.p;
             sa.ref_ds = d_ref_ds.p;
@@ -897,19 +1079,20 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             sa.rec = d_rec.p;
             sa.rows = d_rows.p;
             sa.bad = d_bad.p;
+            sa.gate = gate;
+            sa.gate_expect = par;
             if (n_poses) {
                 hipLaunchKernelGGL(vg::vg_schur_rows_kernel, dim3((unsigned)((n_poses * C + 255) / 256)), dim3(256), 0, st, sa);
                 VG_HIP(hipGetLastError());
                 VG_TRY(launch_dense_gram(st, d_rows.p, n_rows, C, rows_per_group, n_groups, d_rgroups.p));
-                hipLaunchKernelGGL(vg::vg_gram_slab_sum_kernel, dim3(n_slabs), dim3(256), 0, st, (const double *)d_rgroups.p,
-                                   n_groups, C * C, d_rslabs.p);
-                VG_HIP(hipGetLastError());
-                hipLaunchKernelGGL(vg::vg_gram_final_sum_kernel, dim3((C * C + 3) / 4), dim3(256), 0, st,
-                                   (const double *)d_rslabs.p, n_slabs, C * C, d_rgram.p);
+                hipLaunchKernelGGL(vg::vg_gram_strided_sum_kernel, dim3(C * C), dim3(256), 0, st, (const double *)d_rgroups.p, n_groups,
+                                   C * C, d_rgram.p);
                 VG_HIP(hipGetLastError());
             }
             VG_TRY(vgc::allreduce_sum(comm, d_rgram.p, h_rgram.size(), st));  // Schur complement of the poses of all ranks
-            hipLaunchKernelGGL(vg::vg_lm_reduced_solve_kernel, dim3(1), dim3(G <= 64 ? vg::kWave : vg::kLmThreads), solve_lds, st, ra);
+            vg::LmSolveArgs r2 = ra;
+            r2.gate_expect = gated ? par : -1;
+            hipLaunchKernelGGL(vg::vg_lm_reduced_solve_kernel, dim3(1), dim3(G <= 64 ? vg::kWave : vg::kLmThreads), solve_lds, st, r2);
             VG_HIP(hipGetLastError());
             vg::BacksubArgs ba;
             ba.s = sa;
@@ -919,38 +1102,80 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             ba.delta = d_delta.p;
             ba.scal = d_scal.p;
             ba.gmax_bits = d_gmax.p;
-            ba.x = d_x.p;
+            ba.x = xbuf[par];
             ba.xg = d_xg.p;
             ba.lo = d_lo.p;
             ba.hi = d_hi.p;
-            ba.x_new = d_xc.p;   // the step is applied where it is computed: no separate launch
+            ba.x_new = xbuf[1 - par];   // the step is applied where it is computed: no separate launch
             if (n_poses || G) {
                 const unsigned int bs_grid = n_bs_groups ? n_bs_groups : 1u;
                 if (G < 64) hipLaunchKernelGGL(vg::vg_backsub_kernel<4>, dim3(bs_grid), dim3(vg::kBsThreads), 0, st, ba);
                 else hipLaunchKernelGGL(vg::vg_backsub_kernel<8>, dim3(bs_grid), dim3(vg::kBsThreads), 0, st, ba);
                 VG_HIP(hipGetLastError());
             }
-            if (n_bs_groups) {
+            if (n_bs_groups && multi_rank) {  // part of the evaluation's packed all-reduce; one rank: the accept kernel sums them
                 hipLaunchKernelGGL(vg::vg_gram_final_sum_kernel, dim3(2), dim3(256), 0, st, (const double *)d_scal.p, n_bs_groups, 5,
                                    d_scal_sum.p);
                 VG_HIP(hipGetLastError());
             }
-            VG_TRY(enqueue_evaluate(d_xc.p, cand));
-            hipLaunchKernelGGL(vg::vg_lm_accept_kernel, dim3(1), dim3(vg::kLmThreads), accept_lds, st, aa);
+            p->gram_gate = gate;
+            p->gram_gate_expect = par;
+            const int re = enqueue_evaluate(xbuf[1 - par], gset[1 - par]);
+            p->gram_gate = nullptr;
+            if (re != VG_OK) return re;
+            vg::LmAcceptArgs a2 = aa;
+            a2.gate_expect = gated ? par : -1;
+            slot = next_slot();
+            a2.host_state = slots.p + slot;
+            hipLaunchKernelGGL(vg::vg_lm_accept_kernel, dim3(1), dim3(vg::kLmThreads), accept_lds, st, a2);
             VG_HIP(hipGetLastError());
-            VG_TRY(read_state());  // the one synchronisation of the iteration
-            const vg::LmState &S = *pin_state.p;
-            if (opt.verbose)
+            return queue_state(slot);
+        };
+        auto wait_state = [&](int slot) -> int {
+            VG_HIP(hipEventSynchronize(slots.ev[slot]));
+            return VG_OK;
+        };
+        if (t_arena) VG_TRY(t_arena->flush(st));  // every table of the set-up in one asynchronous copy
+        mark("device-loop state");
+        const double t_loop = now_s();  // everything before: allocation and upload of the problem's solver state
+        VG_HIP(hipMemcpyAsync(d_xc.p, d_x.p, sizeof(double) * (size_t)n_params, hipMemcpyDeviceToDevice, st));
+        VG_TRY(enqueue_evaluate(xbuf[0], gset[0]));
+        int parity = 0, pending = next_slot(), iter = 0;
+        aa.host_state = slots.p + pending;
+        hipLaunchKernelGGL(vg::vg_lm_accept_kernel, dim3(1), dim3(vg::kLmThreads), accept_lds, st, aa);
+        VG_HIP(hipGetLastError());
+        aa.init = 0;
+        if (opt.max_num_iterations >= 1) VG_TRY(queue_iteration(parity, speculate, pending));
+        else VG_TRY(queue_state(pending));
+        const vg::LmState *Sp = slots.p + pending;
+        bool printed_header = false;
+        for (iter = 1; iter <= opt.max_num_iterations; iter++) {
+            int spec = -1;
+            if (speculate && iter < opt.max_num_iterations) VG_TRY(queue_iteration(parity ^ 1, true, spec));
+            VG_TRY(wait_state(pending));  // the one wait of the iteration; the GPU already holds the next one
+            Sp = slots.p + pending;
+            const vg::LmState &S = *Sp;
+            if (opt.verbose) {
+                if (!printed_header)
+                    std::printf("iter      cost      cost_change  |gradient|   |step|    tr_ratio  tr_radius\n%4d  %.6e\n", 0, 0.5 * S.cost2_init);
+                printed_header = true;
                 std::printf("%4d  %.6e  %10.3e  %10.3e  %9.3e  %9.3e  %9.3e %s\n", iter, 0.5 * S.cost2, S.cost_change, S.grad_max,
                             S.step_norm, S.rho, S.radius, S.accepted ? "" : (S.done && S.term <= VG_TERM_CONVERGENCE_PARAMETER ? "(converged)" : "(rejected)"));
-            if (S.accepted) {
-                std::swap(cur, cand);
-                std::swap(ds_cur, ds_cand);
-                std::swap(d_x.p, d_xc.p);
             }
-            if (S.done) break;
+            if (S.accepted) parity ^= 1;
+            if (S.done || iter == opt.max_num_iterations) {
+                if (!S.done) iter++;  // ran out of iterations
+                break;
+            }
+            if (S.accepted && spec >= 0) pending = spec;                       // the queued iteration is the real one
+            else VG_TRY(queue_iteration(parity, speculate, pending));          // rejected: what was queued has skipped itself
         }
-        const vg::LmState &S = *pin_state.p;
+        VG_TRY(wait_state(pending));
+        d_x.p = xbuf[parity];       // DevBuf handles: keep ownership of both buffers, current one in d_x
+        d_xc.p = xbuf[1 - parity];
+        const double initial_cost = 0.5 * Sp->cost2_init;
+        final_state = *Sp;
+        const vg::LmState &S = final_state;
         char msg[160] = "";
         int term = S.done ? S.term : VG_TERM_NO_CONVERGENCE;
         if (iter > opt.max_num_iterations) {
@@ -980,6 +1205,8 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             sum->gradient_max_norm = S.grad_max;
             sum->final_radius = S.radius;
             sum->total_seconds = now_s() - t_start;
+            sum->host_seconds = t_loop - t_start;            // set-up: buffers, index tables, uploads
+            sum->evaluate_seconds = now_s() - t_loop;        // the iterations (device resident)
             sum->num_global_columns = G;
             sum->num_pose_blocks = n_poses;
             std::snprintf(sum->message, sizeof sum->message, "%s", msg);
@@ -987,6 +1214,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
         return VG_OK;
     }
 
+    if (t_arena) VG_TRY(t_arena->flush(st));
     // values of the global columns at the starting point
     for (int a2 = 0; a2 < G; a2++) VG_HIP(hipMemcpy(&h_xg[a2], p->d_params + gcol_param[a2], sizeof(double), hipMemcpyDeviceToHost));
     std::vector<double> h_xcur(h_xg);  // global values at the CURRENT point (h_xg is refreshed only after the reduced solve)
@@ -1032,6 +1260,8 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
         sa.n_poses = (int)n_poses;
         sa.mu = mu;
         sa.mu_dev = nullptr;
+        sa.gate = nullptr;
+        sa.gate_expect = 0;
         sa.dmin = opt.min_lm_diagonal;
         sa.dmax = opt.max_lm_diagonal;
         sa.rec = d_rec.p;
