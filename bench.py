@@ -163,9 +163,31 @@ def main():
     if dist is not None and backend == "nccl":
         from visgeom_amd import distributed as vdist_
 
-        comm = vdist_.make_comm(local_rank)
-        if rank == 0:
-            print("[bench] native RCCL communicator: world size %d" % comm.n_ranks, file=sys.stderr)
+        # created in a helper thread with a deadline and agreed on by all ranks: if the native communicator cannot be
+        # set up on this node, every rank falls back to torch.distributed for the small sums instead of hanging the bench
+        import threading
+
+        box = {}
+
+        def _make():
+            try:
+                box["comm"] = vdist_.make_comm(local_rank)
+            except Exception as e:  # noqa: BLE001
+                box["error"] = repr(e)
+
+        th = threading.Thread(target=_make, daemon=True)
+        th.start()
+        th.join(float(os.environ.get("VG_BENCH_COMM_TIMEOUT", "120")))
+        ok = torch.tensor([1 if "comm" in box else 0], device="cuda:%d" % local_rank, dtype=torch.int32)
+        if not th.is_alive():  # a rank still inside ncclCommInitRank cannot take part in another collective
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 1 and "comm" in box:
+            comm = box["comm"]
+            if rank == 0:
+                print("[bench] native RCCL communicator: world size %d" % comm.n_ranks, file=sys.stderr)
+        else:
+            print("[bench] rank %d: native RCCL communicator unavailable (%s): sums go through torch.distributed" %
+                  (rank, box.get("error", "timeout")), file=sys.stderr)
 
     def sum_over_ranks_(t):
         if comm is not None:

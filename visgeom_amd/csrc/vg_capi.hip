@@ -250,7 +250,8 @@ template <int MODEL>
 int launch_gram_valu(hipStream_t stream, const vg::GramValuArgs &a, int L, bool inline_chain)
 {
     // corners per lane and chunk: small boards (at most one corner per lane of the half-wave) do not pay for three
-    return a.g.N <= (unsigned)vg::kValuLanesPerImage ? launch_gram_valu_ch<MODEL, 1>(stream, a, L, inline_chain)
+    static const bool force_ch1 = getenv("VG_GRAM_CH1") != nullptr;  // measurement hook
+    return (force_ch1 || a.g.N <= (unsigned)vg::kValuLanesPerImage) ? launch_gram_valu_ch<MODEL, 1>(stream, a, L, inline_chain)
                                                      : launch_gram_valu_ch<MODEL, 3>(stream, a, L, inline_chain);
 }
 
