@@ -421,8 +421,8 @@ def main():
 
     # ---- BASELINE.json config 4, the north-star multi-GPU case: Mei (K = 10), 10 000 images x 96 corners IN TOTAL,
     # images sharded over the ranks (strong scaling).  One LM-style iteration = chain prep + fused evaluate + Gram of
-    # this rank's images + fixed-order sum + ONE packed all-reduce of [H (W x W, holds J^T J, J^T r and the cost) |
-    # n_failed] on the device buffer.  Time = max over ranks between fences.
+    # this rank's images + fixed-order sum + ONE all-reduce of H (W x W: J^T J, J^T r, the cost and with it the
+    # number of failed corners) on the device buffer.  Time = max over ranks between fences.
     sharded = None
     try:
         from visgeom_amd import distributed as vdist
@@ -437,12 +437,13 @@ def main():
         pm.finalize()
         gm, _ = pm.alloc_gram(dsm)
         Wm = pm.gram_width(dsm)
-        pack = torch.zeros(Wm * Wm + 1, dtype=torch.float64, device="cuda")  # [H | n_failed]
+        # [H]: J^T J, J^T r and r^T r; a failed projection adds 2e30 to r^T r (two residuals of 1e15), so the number of
+        # failed corners of ALL ranks is read off the reduced r^T r -- it travels in the same W*W doubles
+        pack = torch.zeros(Wm * Wm, dtype=torch.float64, device="cuda")
 
         def it_sharded():
             pm.prepare()
-            pm.gram_fused_sum(dsm, gm, pack)           # writes the first W*W doubles
-            pack[Wm * Wm:].copy_(torch.floor(pack[Wm * Wm - 1:Wm * Wm] / 2e30 + 0.5))  # failed corners: 2e30 of r^T r each
+            pm.gram_fused_sum(dsm, gm, pack)
             sum_over_ranks_(pack)
 
         ms = min(wall_ms(it_sharded, a.steps) for _ in range(3))
@@ -453,7 +454,10 @@ def main():
                                  ("one vg_comm_allreduce_sum per iteration, %d doubles, in place on the device buffer" % pack.numel()
                                   if comm is not None else "torch.distributed " + backend),
                    "ms_per_iter": ms, "evals_per_s": n_total * N / (ms * 1e-3), "gram_width": Wm,
-                   "cost": float(pack[Wm * Wm - 1].item()) * 0.5, "n_failed": float(pack[Wm * Wm].item())}
+                   "fused_gram_flops_per_obs": 2 * Wm * (Wm + 1) + EVAL_FLOPS["mei"],
+                   "fused_gram_TFLOPs_incl_sum_and_collective": (2 * Wm * (Wm + 1) + EVAL_FLOPS["mei"]) * n_total * N / (ms * 1e-3) / 1e12,
+                   "cost": float(pack[Wm * Wm - 1].item()) * 0.5,
+                   "n_failed": float(torch.floor(pack[Wm * Wm - 1] / 2e30 + 0.5).item())}
         pm.close()
     except Exception as e:  # never take the headline down
         sharded = {"error": repr(e)}

@@ -66,9 +66,12 @@ def build(vg, model, n_images, chain_kind, n_points=None):
     return p, ds, status, board, corners, K, bases, strides
 
 
-CASES = [("eucm", 40, "D", None),      # W = 13, one MFMA tile           (config 2 / headline shape)
+# single-member chains (W <= 17) run on the vector-pipe kernel (vg_gram_valu.hpp: one chunk of 3 corners per lane for W <= 13,
+# chunks of 2 + 1 for Mei's 17), longer chains on the matrix-core kernel; test_matrix_core_kernels_for_narrow_blocks
+# repeats the narrow cases with the matrix-core kernel forced
+CASES = [("eucm", 40, "D", None),      # W = 13                          (config 2 / headline shape)
          ("ucm", 17, "D", None),       # W = 12
-         ("mei", 23, "D", None),       # W = 17, two tiles               (config 4 shape)
+         ("mei", 23, "D", None),       # W = 17                          (config 4 shape)
          ("eucm", 19, "ID", None),     # W = 19, stereo cam-2 shape      (config 3)
          ("mei", 9, "IDDID", None),    # W = 41, three tiles, chain of 5
          ("eucm", 11, "D", 7),         # odd N < wave: image rows end mid-MFMA group
@@ -177,3 +180,17 @@ def test_full_size_10k_gram_properties(vg):
     Gref = oracle_grams("eucm", [0], d["board"], d["corners"][sub], pv, 0, [6], [6], sub)
     assert_gram_parity(gram.cpu().numpy()[sub], Gref, "10k subset")
     p.close()
+
+
+def test_matrix_core_kernels_for_narrow_blocks():
+    """VG_GRAM_FORCE_MFMA=1 (read once per process) sends the single-member chains to vg_gram_fused_kernel as well --
+    one 16 x 16 tile for W <= 16, the RCOL variant (16 Jacobian columns in the tile, residual column on the lanes) for
+    Mei's W = 17: the same cases, the same bars, in a process of their own."""
+    import os
+    import subprocess
+    import sys
+
+    env = dict(os.environ, VG_GRAM_FORCE_MFMA="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k",
+                        "test_gram_fused_two_pass_and_sum or failed_projections"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

@@ -249,10 +249,12 @@ int launch_gram_valu_ch(hipStream_t stream, const vg::GramValuArgs &a, int L, bo
 template <int MODEL>
 int launch_gram_valu(hipStream_t stream, const vg::GramValuArgs &a, int L, bool inline_chain)
 {
-    // corners per lane and chunk: small boards (at most one corner per lane of the half-wave) do not pay for three
+    // corners per lane in a full chunk: three for the 13-wide blocks (an 8 x 12 board is one chunk), two for wider ones
+    // (register file); boards of at most one corner per lane of the half-wave do not pay for more than one
     static const bool force_ch1 = getenv("VG_GRAM_CH1") != nullptr;  // measurement hook
+    constexpr int kMain = vg::CameraTraits<MODEL>::K + 7 <= 13 ? 3 : 2;
     return (force_ch1 || a.g.N <= (unsigned)vg::kValuLanesPerImage) ? launch_gram_valu_ch<MODEL, 1>(stream, a, L, inline_chain)
-                                                     : launch_gram_valu_ch<MODEL, 3>(stream, a, L, inline_chain);
+                                                                     : launch_gram_valu_ch<MODEL, kMain>(stream, a, L, inline_chain);
 }
 
 }  // namespace

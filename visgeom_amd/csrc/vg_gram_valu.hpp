@@ -1,5 +1,6 @@
-// vg_gram_valu.hpp -- fused evaluate + Gram for NARROW row blocks (W = K + 6L + 1 <= 13: EUCM / UCM mono, the headline
-// workload), entirely on the FP64 vector pipe: "J^T J / J^T r block reductions with wavefront shuffles".
+// vg_gram_valu.hpp -- fused evaluate + Gram for the row blocks of chains with at most ONE member (W = K + 6L + 1 <= 17:
+// EUCM / UCM / Mei mono -- the headline workload and config 4), entirely on the FP64 vector pipe: "J^T J / J^T r block
+// reductions with wavefront shuffles".
 //
 // Why not the matrix cores here: on gfx950 v_mfma_f64_16x16x4_f64 runs at the FP64 VECTOR rate and shares its datapath
 // (profiles/r01d_fp64_pipes_probe.txt), so its only merit is the built-in cross-lane sum -- and a 16 x 16 tile spends
@@ -11,7 +12,9 @@
 // instead of 5 x 91, all through DPP / swizzle (no LDS memory, no barrier).  The order of every sum is fixed.
 //
 // Work split: one 32-lane half-wave per image (an 8 x 12 board is 3 corners per lane, no idle lanes), 8 images per
-// 256-thread workgroup.  Chains of ONE member used DIRECT are walked in-kernel (thread f of the workgroup derives the
+// 256-thread workgroup.  A lane keeps the rows of the corners of one CHUNK in registers: 3 corners for W <= 13 (the board is
+// one chunk, one pass of the halving tree), 2 for Mei's W = 17 (a chunk of 64 corners and one of 32: two passes; measured
+// 37.8 us for 10 k images against 55.8 us for chain-prep + the matrix-core kernel).  Chains of ONE member used DIRECT are walked in-kernel (thread f of the workgroup derives the
 // frame of image f), so the normal-equation build needs no chain-prep launch.  Optionally the workgroup also leaves the
 // sum of its 8 images (all entries, fixed order) in `partials`, transposed [entry][workgroup], for the one final-sum
 // launch that replaces the slab + final pair.
@@ -24,7 +27,7 @@ namespace vg {
 constexpr int kValuThreads = 256;
 constexpr int kValuLanesPerImage = 32;
 constexpr int kValuImagesPerBlock = kValuThreads / kValuLanesPerImage;
-constexpr int kValuMaxW = 13;
+constexpr int kValuMaxW = 17;
 
 struct GramValuArgs {
     GramArgs g;                  // frames (prepared route), board, obs, intr, gram, n_blocks, N, (L, W, stride: template)
@@ -177,17 +180,102 @@ __device__ __forceinline__ void valu_tree_all(const Rows &R, double (&t)[N], std
     ((t[I] = R.template tree<5, I>()), ...);
 }
 
-// CH = corners per lane and chunk: 3 covers an 8 x 12 board in one chunk (one pass of the halving tree per image);
-// boards of at most 32 points use CH = 1.
+// What a lane needs of the CC corners it owns in one chunk: requested from HBM ahead of use.
+template <int CC>
+struct ValuChunkIn {
+    using d2 = HIP_vector_type<double, 2>;
+    double gb[CC][3];
+    d2 ob[CC];
+    bool ragged[CC];
+    __device__ __forceinline__ void load(const GramArgs &g, unsigned int b, unsigned int b0, bool bvalid, int sl, unsigned int c0)
+    {
+#pragma unroll
+        for (int j = 0; j < CC; j++) {
+            const unsigned int c = c0 + sl + kValuLanesPerImage * j;
+            ragged[j] = !(bvalid && c < g.N);
+            const unsigned int cc = c < g.N ? c : g.N - 1;
+            const unsigned int bb = bvalid ? b : b0;
+            gb[j][0] = g.board[3 * cc];
+            gb[j][1] = g.board[3 * cc + 1];
+            gb[j][2] = g.board[3 * cc + 2];
+            ob[j] = reinterpret_cast<const d2 *>(g.obs)[(size_t)bb * g.N + cc];
+        }
+    }
+};
+
+// One chunk of 32 CC corners of the lane's image: evaluate the lane's CC corners, then products and the sum over the 32
+// lanes in one depth-first pass; the lane's share of the image's Gram sum is added to out[].
+template <int MODEL, int L, int CC, int kOut>
+__device__ __forceinline__ void valu_chunk(const double *__restrict__ intr, const double *fr, const ValuChunkIn<CC> &in,
+                                           int sl, double (&out)[kOut])
+{
+    using Rows = ValuRows<MODEL, L, CC>;
+    constexpr int K = Rows::K, W = Rows::W;
+    Rows R;
+#pragma unroll
+    for (int s = 0; s < 5; s++) R.bit[s] = (sl >> (4 - s)) & 1;
+    // ---- phase 1: the CC corners of this lane, independent of each other (the compiler interleaves their sqrt /
+    // reciprocal chains); no accumulator is live yet
+#pragma unroll
+    for (int j = 0; j < CC; j++) {
+        const double g0 = in.gb[j][0], g1 = in.gb[j][1], g2 = in.gb[j][2];
+        const double X0 = (fr[0] * g0 + fr[1] * g1 + fr[2] * g2) + fr[9];
+        const double X1 = (fr[3] * g0 + fr[4] * g1 + fr[5] * g2) + fr[10];
+        const double X2 = (fr[6] * g0 + fr[7] * g1 + fr[8] * g2) + fr[11];
+        CornerEval<K> e;
+        eval_corner_fast<MODEL>(intr, X0, X1, X2, e);
+#pragma unroll
+        for (int i = 0; i < K; i++) {
+            R.rw[j][0][i] = e.Ju[i];
+            R.rw[j][1][i] = e.Jv[i];
+        }
+        if constexpr (L == 1) {
+            double rows[12];
+            pose_rows_fast(e.P, X0, X1, X2, fr + 12, rows);
+#pragma unroll
+            for (int q = 0; q < 6; q++) {
+                R.rw[j][0][K + q] = rows[q];
+                R.rw[j][1][K + q] = rows[6 + q];
+            }
+        }
+        // residual column; a failed projection contributes the in-band 1e15 (calib_cost_functions.cpp:66-70)
+        R.rw[j][0][W - 1] = e.ok ? e.u - in.ob[j].x : kDoubleBig;
+        R.rw[j][1][W - 1] = e.ok ? e.v - in.ob[j].y : kDoubleBig;
+    }
+    bool any_ragged = false;
+#pragma unroll
+    for (int j = 0; j < CC; j++) any_ragged |= in.ragged[j];
+    if (__builtin_amdgcn_ballot_w64(any_ragged)) {  // ragged last chunk / missing image: a scalar branch no wave takes on full boards
+        // the zero comes out of an asm statement so that the selects below cannot be speculated out of this block
+        // (the compiler otherwise turns it into 2 W CC v_cndmask on the hot path)
+        double zero = 0.;
+        asm volatile("; ragged chunk" : "+v"(zero));
+#pragma unroll
+        for (int j = 0; j < CC; j++)
+#pragma unroll
+            for (int i = 0; i < W; i++) {
+                R.rw[j][0][i] = in.ragged[j] ? zero : R.rw[j][0][i];
+                R.rw[j][1][i] = in.ragged[j] ? zero : R.rw[j][1][i];
+            }
+    }
+    // ---- phase 2: products and the sum over the 32 lanes of the image in one depth-first pass
+    double t[kOut];
+    valu_tree_all(R, t, std::make_integer_sequence<int, kOut>{});
+#pragma unroll
+    for (int k = 0; k < kOut; k++) out[k] += t[k];
+}
+
+// CH = corners per lane in a full chunk (32 CH corners of the image): 3 covers an 8 x 12 board in one chunk for the 13-wide
+// blocks (one pass of the halving tree per image); the 17-wide block of Mei keeps two corners' rows in registers, so its
+// 8 x 12 board is one chunk of 64 corners and one of 32.  Whatever does not fill a full chunk runs in CH = 1 chunks.
 template <int MODEL, int L, bool INLINE, int CH>
 __global__ __launch_bounds__(kValuThreads, 2) void vg_gram_valu_kernel(GramValuArgs a)
 {
     static_assert(L == 0 || L == 1, "narrow row blocks only");
     using Rows = ValuRows<MODEL, L, CH>;
-    constexpr int K = Rows::K, W = Rows::W, E = Rows::E, FS = frame_stride(L);
-    static_assert(W <= kValuMaxW, "the upper triangle must fit the register file");
+    constexpr int W = Rows::W, E = Rows::E, FS = frame_stride(L);
+    static_assert(W <= kValuMaxW && (W <= 13 || CH <= 2), "the rows of a chunk must fit the register file");
     constexpr int kOut = halved(E, 5);
-    using d2 = HIP_vector_type<double, 2>;
     __shared__ __attribute__((aligned(16))) double lds[kValuImagesPerBlock * FS + (kValuThreads / kWave) * E];
     double *fr_lds = lds, *red = lds + kValuImagesPerBlock * FS;
     if (gate_closed(a.g.gate, a.g.gate_expect)) return;
@@ -199,24 +287,13 @@ __global__ __launch_bounds__(kValuThreads, 2) void vg_gram_valu_kernel(GramValuA
     const bool bvalid = b < a.g.n_blocks;
 
     // the first chunk's board points and observations are requested BEFORE the chain walk, so their HBM latency
-    // overlaps it (a wave has one chunk per image on an 8 x 12 board: nothing else could hide that latency)
-    double gb[CH][3];
-    d2 ob[CH];
-    bool ragged[CH];
-    auto load_chunk = [&](unsigned int c0) {
-#pragma unroll
-        for (int j = 0; j < CH; j++) {
-            const unsigned int c = c0 + sl + kValuLanesPerImage * j;
-            ragged[j] = !(bvalid && c < a.g.N);
-            const unsigned int cc = c < a.g.N ? c : a.g.N - 1;
-            const unsigned int bb = bvalid ? b : b0;
-            gb[j][0] = a.g.board[3 * cc];
-            gb[j][1] = a.g.board[3 * cc + 1];
-            gb[j][2] = a.g.board[3 * cc + 2];
-            ob[j] = reinterpret_cast<const d2 *>(a.g.obs)[(size_t)bb * a.g.N + cc];
-        }
-    };
-    load_chunk(0);
+    // overlaps it (a wave has one full chunk per image on an 8 x 12 board: nothing else could hide that latency)
+    constexpr unsigned int kFull = kValuLanesPerImage * CH;
+    const unsigned int n_full = a.g.N / kFull;
+    ValuChunkIn<CH> in_full;
+    ValuChunkIn<1> in_one;
+    if (n_full) in_full.load(a.g, b, b0, bvalid, sl, 0);
+    else in_one.load(a.g, b, b0, bvalid, sl, 0);
 
     // every half-wave derives / fetches the frame of ITS image: no workgroup barrier in front of the arithmetic, the
     // waves of a workgroup drift apart and cover each other's latencies (with one walker per workgroup three waves
@@ -234,68 +311,33 @@ __global__ __launch_bounds__(kValuThreads, 2) void vg_gram_valu_kernel(GramValuA
     wave_lds_fence();
     const double *fr = fr_mine;
 
-    Rows R;
-#pragma unroll
-    for (int s = 0; s < 5; s++) R.bit[s] = (sl >> (4 - s)) & 1;
     double out[kOut];
 #pragma unroll
     for (int k = 0; k < kOut; k++) out[k] = 0.;
 
-    for (unsigned int c0 = 0;;) {
-        // ---- phase 1: the CH corners of this lane, independent of each other (the compiler interleaves their
-        // sqrt / reciprocal chains); no accumulator is live yet
-#pragma unroll
-        for (int j = 0; j < CH; j++) {
-            const double g0 = gb[j][0], g1 = gb[j][1], g2 = gb[j][2];
-            const double X0 = (fr[0] * g0 + fr[1] * g1 + fr[2] * g2) + fr[9];
-            const double X1 = (fr[3] * g0 + fr[4] * g1 + fr[5] * g2) + fr[10];
-            const double X2 = (fr[6] * g0 + fr[7] * g1 + fr[8] * g2) + fr[11];
-            CornerEval<K> e;
-            eval_corner_fast<MODEL>(a.g.intr, X0, X1, X2, e);
-#pragma unroll
-            for (int i = 0; i < K; i++) {
-                R.rw[j][0][i] = e.Ju[i];
-                R.rw[j][1][i] = e.Jv[i];
+    unsigned int c0 = 0;
+    for (unsigned int m = 0; m < n_full; m++) {
+        valu_chunk<MODEL, L, CH, kOut>(a.g.intr, fr, in_full, sl, out);
+        c0 += kFull;
+        if (m + 1 < n_full) in_full.load(a.g, b, b0, bvalid, sl, c0);
+    }
+    if constexpr (CH > 1) {
+        if (c0 < a.g.N) {
+            if (n_full) in_one.load(a.g, b, b0, bvalid, sl, c0);
+            for (;;) {
+                valu_chunk<MODEL, L, 1, kOut>(a.g.intr, fr, in_one, sl, out);
+                c0 += kValuLanesPerImage;
+                if (c0 >= a.g.N) break;
+                in_one.load(a.g, b, b0, bvalid, sl, c0);
             }
-            if constexpr (L == 1) {
-                double rows[12];
-                pose_rows_fast(e.P, X0, X1, X2, fr + 12, rows);
-#pragma unroll
-                for (int q = 0; q < 6; q++) {
-                    R.rw[j][0][K + q] = rows[q];
-                    R.rw[j][1][K + q] = rows[6 + q];
-                }
-            }
-            // residual column; a failed projection contributes the in-band 1e15 (calib_cost_functions.cpp:66-70)
-            R.rw[j][0][W - 1] = e.ok ? e.u - ob[j].x : kDoubleBig;
-            R.rw[j][1][W - 1] = e.ok ? e.v - ob[j].y : kDoubleBig;
         }
-        bool any_ragged = false;
-#pragma unroll
-        for (int j = 0; j < CH; j++) any_ragged |= ragged[j];
-        if (__builtin_amdgcn_ballot_w64(any_ragged)) {  // ragged last chunk / missing image: a scalar branch no wave takes on full boards
-            // the zero comes out of an asm statement so that the selects below cannot be speculated out of this block
-            // (the compiler otherwise turns it into 2 W CH v_cndmask on the hot path)
-            double zero = 0.;
-            asm volatile("; ragged chunk" : "+v"(zero));
-#pragma unroll
-            for (int j = 0; j < CH; j++)
-#pragma unroll
-                for (int i = 0; i < W; i++) {
-                    R.rw[j][0][i] = ragged[j] ? zero : R.rw[j][0][i];
-                    R.rw[j][1][i] = ragged[j] ? zero : R.rw[j][1][i];
-                }
+    } else {
+        // CH == 1: the ragged remainder is one more chunk of the same kind
+        if (c0 < a.g.N) {
+            if (n_full) in_full.load(a.g, b, b0, bvalid, sl, c0);
+            else in_full = in_one;
+            valu_chunk<MODEL, L, 1, kOut>(a.g.intr, fr, in_full, sl, out);
         }
-        // ---- phase 2: products and the sum over the 32 lanes of the image in one depth-first pass
-        {
-            double t[kOut];
-            valu_tree_all(R, t, std::make_integer_sequence<int, kOut>{});
-#pragma unroll
-            for (int k = 0; k < kOut; k++) out[k] += t[k];
-        }
-        c0 += kValuLanesPerImage * CH;
-        if (c0 >= a.g.N) break;
-        load_chunk(c0);
     }
 
     // which entries this lane ended up with: [base, base + real)
