@@ -221,7 +221,7 @@ int launch_gram_fused(hipStream_t stream, const vg::GramArgs &a)
 bool gram_uses_valu(const vg_problem *p, const Dataset &d)
 {
     static const bool force_mfma = getenv("VG_GRAM_FORCE_MFMA") != nullptr;  // measurement hook (A/B of the two kernels)
-    return !force_mfma && d.L <= 1 && p->cams[d.camera].K + 6 * d.L + 1 <= vg::kValuMaxW;
+    return !force_mfma && d.L <= 2 && p->cams[d.camera].K + 6 * d.L + 1 <= vg::kValuMaxW;
 }
 
 bool gram_inline_chain(const vg_problem *p, const Dataset &d)
@@ -229,32 +229,39 @@ bool gram_inline_chain(const vg_problem *p, const Dataset &d)
     return !p->force_prepared_frames && gram_uses_valu(p, d) && d.L == 1 && d.status[0] == VG_TRANSFORM_DIRECT;
 }
 
-template <int MODEL, int CH>
-int launch_gram_valu_ch(hipStream_t stream, const vg::GramValuArgs &a, int L, bool inline_chain)
+template <int MODEL, int L, int CH>
+int launch_gram_valu_lch(hipStream_t stream, const vg::GramValuArgs &a, bool inline_chain)
 {
-    constexpr int K = vg::CameraTraits<MODEL>::K;
     const dim3 grid(a.n_wg), blk(vg::kValuThreads);
-    if (L == 0) {
-        hipLaunchKernelGGL((vg::vg_gram_valu_kernel<MODEL, 0, false, CH>), grid, blk, 0, stream, a);
-    } else if constexpr (K + 7 <= vg::kValuMaxW) {
+    if constexpr (L == 1) {
         if (inline_chain) hipLaunchKernelGGL((vg::vg_gram_valu_kernel<MODEL, 1, true, CH>), grid, blk, 0, stream, a);
         else hipLaunchKernelGGL((vg::vg_gram_valu_kernel<MODEL, 1, false, CH>), grid, blk, 0, stream, a);
     } else {
-        return fail(VG_ERR_STATE, "row block too wide for the vector-pipe Gram kernel");
+        hipLaunchKernelGGL((vg::vg_gram_valu_kernel<MODEL, L, false, CH>), grid, blk, 0, stream, a);
     }
     VG_HIP(hipGetLastError());
     return VG_OK;
 }
 
+// corners per lane in a full chunk, by the width of the row block (register file): three up to 13 columns (an 8 x 12 board
+// is one chunk), two up to 19, one beyond; boards of at most one corner per lane of the half-wave never need more than one
+template <int MODEL, int L>
+int launch_gram_valu_l(hipStream_t stream, const vg::GramValuArgs &a, bool inline_chain)
+{
+    static const bool force_ch1 = getenv("VG_GRAM_CH1") != nullptr;  // measurement hook
+    constexpr int W = vg::CameraTraits<MODEL>::K + 6 * L + 1;
+    constexpr int kMain = W <= 13 ? 3 : (W <= 19 ? 2 : 1);
+    if constexpr (kMain > 1)
+        if (!force_ch1 && a.g.N > (unsigned)vg::kValuLanesPerImage) return launch_gram_valu_lch<MODEL, L, kMain>(stream, a, inline_chain);
+    return launch_gram_valu_lch<MODEL, L, 1>(stream, a, inline_chain);
+}
+
 template <int MODEL>
 int launch_gram_valu(hipStream_t stream, const vg::GramValuArgs &a, int L, bool inline_chain)
 {
-    // corners per lane in a full chunk: three for the 13-wide blocks (an 8 x 12 board is one chunk), two for wider ones
-    // (register file); boards of at most one corner per lane of the half-wave do not pay for more than one
-    static const bool force_ch1 = getenv("VG_GRAM_CH1") != nullptr;  // measurement hook
-    constexpr int kMain = vg::CameraTraits<MODEL>::K + 7 <= 13 ? 3 : 2;
-    return (force_ch1 || a.g.N <= (unsigned)vg::kValuLanesPerImage) ? launch_gram_valu_ch<MODEL, 1>(stream, a, L, inline_chain)
-                                                                     : launch_gram_valu_ch<MODEL, kMain>(stream, a, L, inline_chain);
+    if (L == 0) return launch_gram_valu_l<MODEL, 0>(stream, a, false);
+    if (L == 1) return launch_gram_valu_l<MODEL, 1>(stream, a, inline_chain);
+    return launch_gram_valu_l<MODEL, 2>(stream, a, false);
 }
 
 }  // namespace

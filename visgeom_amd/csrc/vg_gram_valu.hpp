@@ -1,5 +1,6 @@
-// vg_gram_valu.hpp -- fused evaluate + Gram for the row blocks of chains with at most ONE member (W = K + 6L + 1 <= 17:
-// EUCM / UCM / Mei mono -- the headline workload and config 4), entirely on the FP64 vector pipe: "J^T J / J^T r block
+// vg_gram_valu.hpp -- fused evaluate + Gram for the row blocks of chains with at most TWO members (W = K + 6L + 1 <= 23:
+// EUCM / UCM / Mei mono -- the headline workload and config 4 -- and the second camera of a stereo pair or rig), entirely
+// on the FP64 vector pipe: "J^T J / J^T r block
 // reductions with wavefront shuffles".
 //
 // Why not the matrix cores here: on gfx950 v_mfma_f64_16x16x4_f64 runs at the FP64 VECTOR rate and shares its datapath
@@ -27,7 +28,7 @@ namespace vg {
 constexpr int kValuThreads = 256;
 constexpr int kValuLanesPerImage = 32;
 constexpr int kValuImagesPerBlock = kValuThreads / kValuLanesPerImage;
-constexpr int kValuMaxW = 17;
+constexpr int kValuMaxW = 23;
 
 struct GramValuArgs {
     GramArgs g;                  // frames (prepared route), board, obs, intr, gram, n_blocks, N, (L, W, stride: template)
@@ -229,13 +230,14 @@ __device__ __forceinline__ void valu_chunk(const double *__restrict__ intr, cons
             R.rw[j][0][i] = e.Ju[i];
             R.rw[j][1][i] = e.Jv[i];
         }
-        if constexpr (L == 1) {
+#pragma unroll
+        for (int l = 0; l < L; l++) {
             double rows[12];
-            pose_rows_fast(e.P, X0, X1, X2, fr + 12, rows);
+            pose_rows_fast(e.P, X0, X1, X2, fr + 12 + 21 * l, rows);
 #pragma unroll
             for (int q = 0; q < 6; q++) {
-                R.rw[j][0][K + q] = rows[q];
-                R.rw[j][1][K + q] = rows[6 + q];
+                R.rw[j][0][K + 6 * l + q] = rows[q];
+                R.rw[j][1][K + 6 * l + q] = rows[6 + q];
             }
         }
         // residual column; a failed projection contributes the in-band 1e15 (calib_cost_functions.cpp:66-70)
@@ -271,10 +273,10 @@ __device__ __forceinline__ void valu_chunk(const double *__restrict__ intr, cons
 template <int MODEL, int L, bool INLINE, int CH>
 __global__ __launch_bounds__(kValuThreads, 2) void vg_gram_valu_kernel(GramValuArgs a)
 {
-    static_assert(L == 0 || L == 1, "narrow row blocks only");
+    static_assert(L >= 0 && L <= 2 && (!INLINE || L == 1), "chains of at most two members; the in-kernel walk is the single DIRECT member's");
     using Rows = ValuRows<MODEL, L, CH>;
     constexpr int W = Rows::W, E = Rows::E, FS = frame_stride(L);
-    static_assert(W <= kValuMaxW && (W <= 13 || CH <= 2), "the rows of a chunk must fit the register file");
+    static_assert(W <= kValuMaxW && (W <= 13 || CH <= 2) && (W <= 19 || CH == 1), "the rows of a chunk must fit the register file");
     constexpr int kOut = halved(E, 5);
     __shared__ __attribute__((aligned(16))) double lds[kValuImagesPerBlock * FS + (kValuThreads / kWave) * E];
     double *fr_lds = lds, *red = lds + kValuImagesPerBlock * FS;
