@@ -443,4 +443,40 @@ __global__ __launch_bounds__(256) void vg_gram_strided_sum_kernel(const double *
     if (tid == 0) out[e] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// The same sum for WIDE blocks (hundreds to thousands of entries: the Gram of the pose rows of a rig): a workgroup owns 16
+// consecutive entries, 16 lanes per entry walk the items, every load of a 16-lane group is one 128-byte segment; the 16
+// partial sums of an entry are added in a fixed order.
+__global__ __launch_bounds__(256) void vg_gram_strided_sum_tiled_kernel(const double *__restrict__ in, unsigned int n_items, int entries,
+                                                                         double *__restrict__ out)
+{
+    const int tid = threadIdx.x, el = tid & 15, il = tid >> 4;
+    const int e = blockIdx.x * 16 + el;
+    const bool live = e < entries;
+    double s = 0.;
+    for (unsigned int i0 = 0; i0 < n_items; i0 += 4 * 16) {
+        double v[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const unsigned int i = i0 + q * 16 + il;
+            v[q] = (live && i < n_items) ? in[(size_t)i * entries + e] : 0.;
+        }
+        s += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+    __shared__ double red[16][17];
+    red[il][el] = s;
+    __syncthreads();
+    if (tid < 16 && blockIdx.x * 16 + tid < entries) {
+        double t = 0.;
+#pragma unroll
+        for (int q = 0; q < 16; q++) t += red[q][tid];
+        out[blockIdx.x * 16 + tid] = t;
+    }
+}
+
+inline void launch_strided_sum(hipStream_t st, const double *in, unsigned int n_items, int entries, double *out)
+{
+    if (entries <= 256) hipLaunchKernelGGL(vg_gram_strided_sum_kernel, dim3(entries), dim3(256), 0, st, in, n_items, entries, out);
+    else hipLaunchKernelGGL(vg_gram_strided_sum_tiled_kernel, dim3((entries + 15) / 16), dim3(256), 0, st, in, n_items, entries, out);
+}
+
 }  // namespace vg

@@ -735,7 +735,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
     ArenaScope arena_scope(p->device, dev_need, pin_need, up_need);
     std::vector<DevBuf<double>> gramA_v((size_t)(n_ds ? n_ds : 1)), gramB_v((size_t)(n_ds ? n_ds : 1));  // sized once, never resized
     DevBuf<double> *const gramA = gramA_v.data(), *const gramB = gramB_v.data();
-    DevBuf<double> d_sums, d_x, d_xc, d_delta, d_lo, d_hi, d_rec, d_rows, d_rgroups, d_rslabs, d_rgram, d_dg, d_scal;
+    DevBuf<double> d_sums, d_x, d_xc, d_delta, d_lo, d_hi, d_rec, d_rows, d_rgroups, d_rgram, d_dg, d_scal;
     DevBuf<vg::SolveDatasetDev> d_dsA, d_dsB;
     DevBuf<int> d_inv, d_ref_ptr, d_ref_ds, d_ref_blk, d_bad;
     DevBuf<unsigned char> d_pf;
@@ -769,7 +769,6 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
     VG_TRY(d_rec.alloc((size_t)n_poses * vg::kPoseRec));
     VG_TRY(d_rows.alloc((size_t)n_rows * C));
     VG_TRY(d_rgroups.alloc((size_t)n_groups * C * C));
-    VG_TRY(d_rslabs.alloc((size_t)n_slabs * C * C));
     VG_TRY(d_rgram.alloc((size_t)C * C));
     VG_TRY(d_dg.alloc((size_t)(G ? G : 1)));
     const unsigned int n_bs_groups = (unsigned int)((n_poses + vg::kBsPosesPerBlock - 1) / vg::kBsPosesPerBlock);
@@ -1085,8 +1084,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
                 hipLaunchKernelGGL(vg::vg_schur_rows_kernel, dim3((unsigned)((n_poses * C + 255) / 256)), dim3(256), 0, st, sa);
                 VG_HIP(hipGetLastError());
                 VG_TRY(launch_dense_gram(st, d_rows.p, n_rows, C, rows_per_group, n_groups, d_rgroups.p));
-                hipLaunchKernelGGL(vg::vg_gram_strided_sum_kernel, dim3(C * C), dim3(256), 0, st, (const double *)d_rgroups.p, n_groups,
-                                   C * C, d_rgram.p);
+                vg::launch_strided_sum(st, d_rgroups.p, n_groups, C * C, d_rgram.p);
                 VG_HIP(hipGetLastError());
             }
             VG_TRY(vgc::allreduce_sum(comm, d_rgram.p, h_rgram.size(), st));  // Schur complement of the poses of all ranks
@@ -1292,11 +1290,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
                 VG_HIP(hipStreamSynchronize(st));  // c2.Y may be rewritten before an async copy from pageable memory ends
             }
             VG_TRY(launch_dense_gram(st, d_rows.p, n_rows, C, rows_per_group, n_groups, d_rgroups.p));
-            hipLaunchKernelGGL(vg::vg_gram_slab_sum_kernel, dim3(n_slabs), dim3(256), 0, st, (const double *)d_rgroups.p,
-                               n_groups, C * C, d_rslabs.p);
-            VG_HIP(hipGetLastError());
-            hipLaunchKernelGGL(vg::vg_gram_final_sum_kernel, dim3((C * C + 3) / 4), dim3(256), 0, st,
-                               (const double *)d_rslabs.p, n_slabs, C * C, d_rgram.p);
+            vg::launch_strided_sum(st, d_rgroups.p, n_groups, C * C, d_rgram.p);
             VG_HIP(hipGetLastError());
         } else if (comm && comm->n_ranks > 1) {
             VG_HIP(hipMemsetAsync(d_rgram.p, 0, sizeof(double) * h_rgram.size(), st));  // a rank without poses still joins the sum
