@@ -61,11 +61,15 @@ __global__ __launch_bounds__(64) void vg_chain_prep_multi_kernel(const double *_
     if (t >= total_blocks) return;
     int d = 0;
     while (d + 1 < n_dsets && t >= dsets[d + 1].first) d++;
-    const PrepDataset D = dsets[d];
-    const long long b = t - D.first;
-    const long long si = D.seq_index ? (long long)D.seq_index[b] : b;
-    build_frame(D.chain.L, D.chain.status, [&](int l) { return params + D.chain.base[l] + D.chain.stride[l] * si; },
-                D.frames + b * D.frame_stride_d);
+    // the descriptor is read in place: a private copy of its arrays would be indexed dynamically by the chain loop and land
+    // in scratch memory (152 bytes per lane, and 13.9 us for the four datasets of a rig where one dataset takes 6.9)
+    const PrepDataset *D = dsets + d;
+    const long long b = t - D->first;
+    const int *seq = D->seq_index;
+    const long long si = seq ? (long long)seq[b] : b;
+    const long long *base = D->chain.base, *stride = D->chain.stride;
+    build_frame(D->chain.L, D->chain.status, [&](int l) { return params + base[l] + stride[l] * si; },
+                D->frames + b * D->frame_stride_d);
 }
 
 // ------------------------------------------------------------------------------------------
