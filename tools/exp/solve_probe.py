@@ -13,8 +13,11 @@ model = sys.argv[1] if len(sys.argv) > 1 else "eucm"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 d = S.make_mono(model, n, 1 if model == "eucm" else 4)
+import torch
+
+side = torch.cuda.Stream() if os.environ.get("VG_PROBE_OWN_STREAM") else None  # a capturable (non-NULL) stream
 for r in range(reps):
-    p = CalibrationProblem(0)
+    p = CalibrationProblem(0, stream=side.cuda_stream if side is not None else None)
     c = p.add_camera(model, d["init_intrinsics"])
     s = p.add_transform(False, d["init_poses"])
     p.add_dataset(c, [(s, 0)], d["board"], d["corners"])

@@ -1027,10 +1027,11 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
         // of iteration k.  The GPU always has the next iteration in its queue: no launch latency, no idle time behind
         // the host's read-back.  Robust (SoftLOne) evaluations re-weight the Gram set in place with an ungated kernel
         // and RCCL calls cannot be skipped on one rank only, so those solves queue one iteration at a time.
-        // MEASURED (tools/exp/solve_probe.py, 10 k images, state published by the accept kernel itself): EUCM 0.112 vs
-        // 0.116 ms per iteration, Mei 0.145 vs 0.148 -- the iteration is bound by its eight dependent launches on the
-        // GPU, not by the host's read-back.  3 % is not worth a second code path by default: VG_SOLVER_SPECULATE=1.
-        const bool speculate = opt.soft_l1_scale <= 0. && !multi_rank && getenv("VG_SOLVER_SPECULATE") != nullptr;
+        // MEASURED (tools/exp/solve_probe.py, 10 k images, state published by the accept kernel itself): EUCM 0.111 vs
+        // 0.115 ms per iteration, Mei 0.119 vs 0.126 -- the iteration is bound by its eight dependent launches on the GPU.
+        // Replaying the gated iteration as a hipGraph (one per parity) was slower than queueing its launches: 0.120 /
+        // 0.126 ms (profiles/NOTES.md).  VG_SOLVER_NO_SPECULATION=1 queues one iteration at a time.
+        const bool speculate = opt.soft_l1_scale <= 0. && !multi_rank && getenv("VG_SOLVER_NO_SPECULATION") == nullptr;
         DevBuf<double> *gset[2] = {gramA, gramB};
         vg::SolveDatasetDev *dset[2] = {d_dsA.p, d_dsB.p};
         double *xbuf[2] = {d_x.p, d_xc.p};
@@ -1166,7 +1167,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
                 break;
             }
             if (S.accepted && spec >= 0) pending = spec;                       // the queued iteration is the real one
-            else VG_TRY(queue_iteration(parity, speculate, pending));          // rejected: what was queued has skipped itself
+            else VG_TRY(queue_iteration(parity, speculate, pending));         // rejected: what was queued has skipped itself
         }
         VG_TRY(wait_state(pending));
         d_x.p = xbuf[parity];       // DevBuf handles: keep ownership of both buffers, current one in d_x
