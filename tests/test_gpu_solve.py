@@ -776,3 +776,43 @@ def test_constant_wheel_geometry_reduces_to_fixed_priors(vg):
     assert np.array_equal(x[W:], d["init_wheels"])
     assert summ["final_cost"] < 1e-3 * summ["initial_cost"] and summ["termination"].startswith("CONVERGENCE")
     p.close()
+
+
+def test_cached_solver_blocks_are_reused_and_released(vg):
+    """vg_problem_solve works in one device block + one pinned block that the library keeps for the next solve
+    (vg_release_cached_memory returns them): a solve after the release, a solve on the reused blocks and the first solve
+    give the same answer bit for bit, a smaller problem fits the kept blocks, and the release really frees the memory."""
+    import torch
+
+    from visgeom_amd import capi, synthetic as S
+
+    lib = capi.load()
+
+    def solve(n):
+        d = S.make_mono("eucm", n, 2, sigma=0.1)
+        p, cam, seq, ds = mono_problem(vg, d, "eucm")
+        s = p.solve(max_num_iterations=30)
+        x = p.get_parameters()
+        p.close()
+        return s, x
+
+    lib.vg_release_cached_memory()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free0, _ = torch.cuda.mem_get_info()
+    s1, x1 = solve(2000)                    # allocates the blocks
+    free_kept, _ = torch.cuda.mem_get_info()
+    s2, x2 = solve(2000)                    # reuses them
+    s3, x3 = solve(300)                     # a smaller problem fits
+    s4, x4 = solve(2000)
+    assert free0 - free_kept > 4 << 20      # something is being kept (two Gram sets of 2 000 images alone are 5.4 MB)
+    lib.vg_release_cached_memory()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 4 << 20, "the released blocks did not come back: %.1f MiB" % ((free0 - free1) / 2**20)
+    s5, x5 = solve(2000)                    # allocates again
+    for s, x in ((s2, x2), (s4, x4), (s5, x5)):
+        assert np.array_equal(x, x1) and s["final_cost"] == s1["final_cost"] and s["num_iterations"] == s1["num_iterations"]
+    assert s3["termination"].startswith("CONVERGENCE")
+    lib.vg_release_cached_memory()
+    lib.vg_release_cached_memory()          # idempotent
