@@ -265,6 +265,10 @@ int vg_dataset_gram_fused(vg_problem *p, int dataset_id, double *gram);
  * vg_dataset_gram_fused + vg_dataset_gram_sum.  The sum equals vg_dataset_gram_sum's to rounding (different fixed
  * order) and is run-to-run reproducible. */
 int vg_dataset_gram_fused_sum(vg_problem *p, int dataset_id, double *gram, double *sum);
+/* vg_dataset_gram_fused for EVERY dataset of the problem (grams[d]: device [n_blocks][W*W], may be NULL for an empty
+ * dataset): the datasets the vector-pipe kernel handles (chains of one or two members) share ONE launch -- a stereo pair
+ * or a rig is several launches of a few hundred workgroups otherwise, each ending in a nearly empty round. */
+int vg_problem_gram_fused(vg_problem *p, double *const *grams);
 /* two-pass: the same Gram matrices from rows already materialised by vg_dataset_evaluate
  * (all of residuals, jac_intr and every jac_member[l] are required). */
 int vg_dataset_gram_from_rows(vg_problem *p, int dataset_id, const double *residuals, const double *jac_intr,

@@ -88,9 +88,13 @@ def main():
 
         def jtj():
             p.prepare()
-            for (ds, _, _, _), (gram, gsum) in zip(dss, grams):
-                p.gram_fused(ds, gram)
-                p.gram_sum(ds, gram, gsum)
+            if len(dss) > 1:   # every dataset in one pass (vg_problem_gram_fused: merged launch), then the fixed-order sums
+                p.gram_fused_all([g for g, _ in grams])
+                for (ds, _, _, _), (gram, gsum) in zip(dss, grams):
+                    p.gram_sum(ds, gram, gsum)
+            else:
+                for (ds, _, _, _), (gram, gsum) in zip(dss, grams):
+                    p.gram_fused_sum(ds, gram, gsum)
 
         t_emit, t_emit_only, t_jtj = timed(emit), timed(emit_only), timed(jtj)
         t_per_ds = timed(emit_per_dataset)

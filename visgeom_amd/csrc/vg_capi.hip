@@ -233,11 +233,12 @@ template <int MODEL, int L, int CH>
 int launch_gram_valu_lch(hipStream_t stream, const vg::GramValuArgs &a, bool inline_chain)
 {
     const dim3 grid(a.n_wg), blk(vg::kValuThreads);
+    const size_t lds = vg::gram_valu_lds_bytes(vg::CameraTraits<MODEL>::K + 6 * L + 1, L);
     if constexpr (L == 1) {
-        if (inline_chain) hipLaunchKernelGGL((vg::vg_gram_valu_kernel<MODEL, 1, true, CH>), grid, blk, 0, stream, a);
-        else hipLaunchKernelGGL((vg::vg_gram_valu_kernel<MODEL, 1, false, CH>), grid, blk, 0, stream, a);
+        if (inline_chain) hipLaunchKernelGGL((vg::vg_gram_valu_kernel<MODEL, 1, true, CH>), grid, blk, lds, stream, a);
+        else hipLaunchKernelGGL((vg::vg_gram_valu_kernel<MODEL, 1, false, CH>), grid, blk, lds, stream, a);
     } else {
-        hipLaunchKernelGGL((vg::vg_gram_valu_kernel<MODEL, L, false, CH>), grid, blk, 0, stream, a);
+        hipLaunchKernelGGL((vg::vg_gram_valu_kernel<MODEL, L, false, CH>), grid, blk, lds, stream, a);
     }
     VG_HIP(hipGetLastError());
     return VG_OK;
@@ -894,6 +895,49 @@ int vgi::gram_fused_at(vg_problem *p, int dataset_id, const double *d_params, do
     return vgi::gram_sum_into(p, dataset_id, gram, sum);
 }
 
+int vgi::gram_fused_merged_at(vg_problem *p, const double *d_params, double *const *grams, std::vector<char> &taken)
+{
+    static const bool off = getenv("VG_GRAM_NO_MERGE") != nullptr || getenv("VG_GRAM_CH1") != nullptr;  // measurement hooks
+    const int n_ds = (int)p->dss.size();
+    taken.assign((size_t)n_ds, 0);
+    std::vector<int> ids;
+    for (int i = 0; i < n_ds && !off; i++) {
+        const Dataset &d = p->dss[i];
+        if (d.n_blocks > 0 && d.n_blocks <= 0x7fffffff && grams[i] && gram_uses_valu(p, d) && (d.L == 1 || d.L == 2) &&
+            d.N > vg::kValuLanesPerImage)
+            ids.push_back(i);
+    }
+    if (ids.size() < 2) return VG_OK;
+    for (size_t g0 = 0; g0 < ids.size(); g0 += vg::kGramMultiMax) {
+        vg::GramValuMultiArgs m;
+        m.n = (int)(ids.size() - g0 < (size_t)vg::kGramMultiMax ? ids.size() - g0 : (size_t)vg::kGramMultiMax);
+        if (m.n < 2) break;  // a lone leftover goes the ordinary way
+        unsigned int wgs = 0;
+        size_t lds = 0;
+        for (int k = 0; k < m.n; k++) {
+            const Dataset &d = p->dss[ids[g0 + k]];
+            const Camera &cam = p->cams[d.camera];
+            vg::GramValuArgs &a = m.ds[k];
+            fill_gram_args(p, d, a.g, grams[ids[g0 + k]], d_params);
+            a.chain_params = d_params + d.chain.base[0];
+            a.chain_stride = d.chain.stride[0];
+            a.seq_index = d.seq_identity ? nullptr : d.d_seq;
+            a.n_wg = (unsigned int)((d.n_blocks + vg::kValuImagesPerBlock - 1) / vg::kValuImagesPerBlock);
+            a.partials = nullptr;
+            m.kind[k] = 3 * cam.model + (d.L == 2 ? 2 : (gram_inline_chain(p, d) ? 0 : 1));
+            m.first_wg[k] = wgs;
+            wgs += a.n_wg;
+            const size_t need = vg::gram_valu_lds_bytes(cam.K + 6 * d.L + 1, d.L);
+            lds = need > lds ? need : lds;
+            taken[(size_t)ids[g0 + k]] = 1;
+        }
+        for (int k = m.n; k <= vg::kGramMultiMax; k++) m.first_wg[k] = wgs;
+        hipLaunchKernelGGL(vg::vg_gram_valu_multi_kernel, dim3(wgs), dim3(vg::kValuThreads), lds, p->stream, m);
+        VG_HIP(hipGetLastError());
+    }
+    return VG_OK;
+}
+
 extern "C" {
 
 int vg_dataset_gram_fused(vg_problem *p, int dataset_id, double *gram)
@@ -904,6 +948,22 @@ int vg_dataset_gram_fused(vg_problem *p, int dataset_id, double *gram)
     VG_HIP(hipSetDevice(p->device));
     if (!gram_inline_chain(p, p->dss[dataset_id]) && (rc = vgi::ensure_frames(p)) != VG_OK) return rc;
     return vgi::gram_fused_at(p, dataset_id, p->d_params, gram, nullptr);
+}
+
+int vg_problem_gram_fused(vg_problem *p, double *const *grams)
+{
+    if (!p || !grams) return fail(VG_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!p->finalized) return fail(VG_ERR_STATE, "problem not finalized");
+    VG_HIP(hipSetDevice(p->device));
+    int rc;
+    for (size_t i = 0; i < p->dss.size(); i++)
+        if (p->dss[i].n_blocks && !grams[i]) return fail(VG_ERR_INVALID_ARGUMENT, "gram is NULL");
+    if (vgi::gram_needs_frames(p) && (rc = vgi::ensure_frames(p)) != VG_OK) return rc;
+    std::vector<char> taken;
+    if ((rc = vgi::gram_fused_merged_at(p, p->d_params, grams, taken)) != VG_OK) return rc;
+    for (size_t i = 0; i < p->dss.size(); i++)
+        if (!taken[i] && p->dss[i].n_blocks && (rc = vgi::gram_fused_at(p, (int)i, p->d_params, grams[i], nullptr)) != VG_OK) return rc;
+    return VG_OK;
 }
 
 int vg_dataset_gram_fused_sum(vg_problem *p, int dataset_id, double *gram, double *sum)

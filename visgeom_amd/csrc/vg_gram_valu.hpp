@@ -270,21 +270,27 @@ __device__ __forceinline__ void valu_chunk(const double *__restrict__ intr, cons
 // CH = corners per lane in a full chunk (32 CH corners of the image): 3 covers an 8 x 12 board in one chunk for the 13-wide
 // blocks (one pass of the halving tree per image); the 17-wide block of Mei keeps two corners' rows in registers, so its
 // 8 x 12 board is one chunk of 64 corners and one of 32.  Whatever does not fill a full chunk runs in CH = 1 chunks.
+// dynamic LDS of a workgroup: the frames of its 8 images | one E-vector per wave for the workgroup's partial sum
+__host__ __device__ constexpr size_t gram_valu_lds_bytes(int W, int L)
+{
+    return sizeof(double) * (size_t)(kValuImagesPerBlock * frame_stride(L) + (kValuThreads / kWave) * (W * (W + 1) / 2));
+}
+
+// the work of workgroup `block` of a dataset (the kernels below only differ in how a workgroup finds its dataset)
 template <int MODEL, int L, bool INLINE, int CH>
-__global__ __launch_bounds__(kValuThreads, 2) void vg_gram_valu_kernel(GramValuArgs a)
+__device__ __forceinline__ void gram_valu_body(const GramValuArgs &a, const unsigned int block, double *lds)
 {
     static_assert(L >= 0 && L <= 2 && (!INLINE || L == 1), "chains of at most two members; the in-kernel walk is the single DIRECT member's");
     using Rows = ValuRows<MODEL, L, CH>;
     constexpr int W = Rows::W, E = Rows::E, FS = frame_stride(L);
     static_assert(W <= kValuMaxW && (W <= 13 || CH <= 2) && (W <= 19 || CH == 1), "the rows of a chunk must fit the register file");
     constexpr int kOut = halved(E, 5);
-    __shared__ __attribute__((aligned(16))) double lds[kValuImagesPerBlock * FS + (kValuThreads / kWave) * E];
     double *fr_lds = lds, *red = lds + kValuImagesPerBlock * FS;
     if (gate_closed(a.g.gate, a.g.gate_expect)) return;
 
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
     const int sl = lane & (kValuLanesPerImage - 1);
-    const unsigned int b0 = blockIdx.x * kValuImagesPerBlock;
+    const unsigned int b0 = block * kValuImagesPerBlock;
     const unsigned int b = b0 + (unsigned)(tid / kValuLanesPerImage);
     const bool bvalid = b < a.g.n_blocks;
 
@@ -376,8 +382,48 @@ __global__ __launch_bounds__(kValuThreads, 2) void vg_gram_valu_kernel(GramValuA
             double s = red[tid];
 #pragma unroll
             for (int w = 1; w < kValuThreads / kWave; w++) s += red[w * E + tid];  // fixed order
-            a.partials[(size_t)tid * a.n_wg + blockIdx.x] = s;
+            a.partials[(size_t)tid * a.n_wg + block] = s;
         }
+    }
+}
+
+template <int MODEL, int L, bool INLINE, int CH>
+__global__ __launch_bounds__(kValuThreads, 2) void vg_gram_valu_kernel(GramValuArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double valu_lds[];
+    gram_valu_body<MODEL, L, INLINE, CH>(a, blockIdx.x, valu_lds);
+}
+
+// Several datasets of a problem in ONE launch (stereo pair, rig): 5 000 images are 625 workgroups on 512 resident slots,
+// i.e. a launch of its own runs two rounds with the second one a fifth full; four such launches waste most of four
+// rounds.  The workgroups of all datasets form one range; each finds its dataset and runs that dataset's body (full-chunk
+// corners per lane by row width as in launch_gram_valu_l; boards of more than 32 points only).
+constexpr int kGramMultiMax = 6;
+
+struct GramValuMultiArgs {
+    GramValuArgs ds[kGramMultiMax];
+    unsigned int first_wg[kGramMultiMax + 1];
+    int kind[kGramMultiMax];  // 3 * model + {0: one member walked in the kernel, 1: one member on prepared frames, 2: two members}
+    int n;
+};
+
+__global__ __launch_bounds__(kValuThreads, 2) void vg_gram_valu_multi_kernel(GramValuMultiArgs m)
+{
+    extern __shared__ __attribute__((aligned(16))) double valu_lds[];
+    int d = 0;
+    while (d + 1 < m.n && blockIdx.x >= m.first_wg[d + 1]) d++;
+    const unsigned int block = blockIdx.x - m.first_wg[d];
+    const GramValuArgs &a = m.ds[d];
+    switch (m.kind[d]) {
+    case 3 * kEUCM + 0: gram_valu_body<kEUCM, 1, true, 3>(a, block, valu_lds); break;
+    case 3 * kEUCM + 1: gram_valu_body<kEUCM, 1, false, 3>(a, block, valu_lds); break;
+    case 3 * kEUCM + 2: gram_valu_body<kEUCM, 2, false, 2>(a, block, valu_lds); break;
+    case 3 * kUCM + 0: gram_valu_body<kUCM, 1, true, 3>(a, block, valu_lds); break;
+    case 3 * kUCM + 1: gram_valu_body<kUCM, 1, false, 3>(a, block, valu_lds); break;
+    case 3 * kUCM + 2: gram_valu_body<kUCM, 2, false, 2>(a, block, valu_lds); break;
+    case 3 * kMEI + 0: gram_valu_body<kMEI, 1, true, 2>(a, block, valu_lds); break;
+    case 3 * kMEI + 1: gram_valu_body<kMEI, 1, false, 2>(a, block, valu_lds); break;
+    default: gram_valu_body<kMEI, 2, false, 1>(a, block, valu_lds); break;
     }
 }
 

@@ -835,12 +835,19 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
     auto enqueue_evaluate = [&](const double *x_dev, DevBuf<double> *set) -> int {
         int r;
         if (vgi::gram_needs_frames(p) && (r = vgi::prepare_at(p, x_dev)) != VG_OK) return r;
+        // several datasets: the ones the vector-pipe kernel takes share one launch
+        std::vector<char> merged((size_t)n_ds, 0);
+        if (n_ds > 1) {
+            std::vector<double *> gp((size_t)n_ds);
+            for (int d = 0; d < n_ds; d++) gp[(size_t)d] = set[d].p;
+            if ((r = vgi::gram_fused_merged_at(p, x_dev, gp.data(), merged)) != VG_OK) return r;
+        }
         for (int d = 0; d < n_ds; d++) {
             double *sum_d = d_sums.p + (size_t)d * Wmax * Wmax;
             const bool robust = opt.soft_l1_scale > 0. && p->dss[d].n_blocks;
             // single dataset, no loss function: Gram blocks and their sum in two launches
             const bool fused_sum = !sum_slab_blocks && !robust;
-            if ((r = vgi::gram_fused_at(p, d, x_dev, set[d].p, fused_sum ? sum_d : nullptr)) != VG_OK) return r;
+            if (!merged[(size_t)d] && (r = vgi::gram_fused_at(p, d, x_dev, set[d].p, fused_sum ? sum_d : nullptr)) != VG_OK) return r;
             if (robust) {
                 // robustified blocks: J'^T J' = rho' J^T J, J'^T r' = rho' J^T r, cost term rho(s)   (Ceres' Corrector
                 // with rho'' < 0, always the case for SoftLOne) -- re-weight the Gram blocks in place, nothing

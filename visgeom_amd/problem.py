@@ -303,6 +303,13 @@ class CalibrationProblem:
         """per-image Gram of [J | r], J never materialised (needs prepare() at the current parameters)."""
         capi.check(self._lib.vg_dataset_gram_fused(self._h, d, ctypes.c_void_p(gram.data_ptr())))
 
+    def gram_fused_all(self, grams):
+        """gram_fused for every dataset (grams[d]: its tensor), one merged launch where possible (vg_problem_gram_fused)."""
+        arr = (ctypes.c_void_p * max(len(grams), 1))()
+        for i, g in enumerate(grams):
+            arr[i] = g.data_ptr() if g is not None else None
+        capi.check(self._lib.vg_problem_gram_fused(self._h, arr))
+
     def gram_fused_sum(self, d, gram, out):
         """gram_fused + the fixed-order sum over the dataset's blocks in two launches (vg_dataset_gram_fused_sum)."""
         capi.check(self._lib.vg_dataset_gram_fused_sum(self._h, d, ctypes.c_void_p(gram.data_ptr()),
