@@ -166,3 +166,29 @@ def test_all_datasets_in_one_launch_equal_the_per_dataset_entry(vg):
         assert_block_parity(got[0][0][b].cpu().numpy(), [got[0][1][b].cpu().numpy(), got[0][2][0][b].cpu().numpy()],
                             rr[b], [jir[b], jmr[0][b]], r["corners"][0][b], "merged launch, prepared frames")
     p.close()
+
+
+@pytest.mark.parametrize("n", [57, 8])
+def test_all_gram_blocks_in_one_launch_equal_the_per_dataset_entry(vg, n):
+    """vg_problem_gram_fused sends the rig's four datasets (W = 12, 19, 19, 23; chains [D] and [I, D]) through ONE
+    vector-pipe launch: same bits as four vg_dataset_gram_fused calls (a workgroup runs the same body either way), on
+    both chain routes, and ragged workgroup counts (57 images = 7 full workgroups + 1) do not leak across datasets."""
+    import torch
+
+    from visgeom_amd import synthetic as S
+
+    r = S.make_rig(n, sigma=0.1)
+    p, cams, x1k, seq, dss = build_rig(vg, r)
+    for forced in (False, True):
+        p.force_prepared_frames(forced)
+        ref = [p.alloc_gram(ds)[0] for ds in dss]
+        got = [torch.full_like(g, float("nan")) for g in ref]
+        p.prepare()
+        for ds, g in zip(dss, ref):
+            p.gram_fused(ds, g)
+        p.prepare()
+        p.gram_fused_all(got)
+        p.synchronize()
+        for k, (a, b) in enumerate(zip(ref, got)):
+            assert torch.equal(a, b), "dataset %d, forced frames %s" % (k, forced)
+    p.close()
