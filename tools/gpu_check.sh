@@ -30,4 +30,6 @@ timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONF
 echo "rocprof pmc SQ rc=$?"
 find "$P" -type f | head -40
 f=$(find "$P/trace" -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && head -8 "$f"
+k=$(find "$P/trace" -name '*kernel_trace.csv' | head -1)
+[ -n "$k" ] && python "$R/tools/kernel_context.py" "$k" "gram_valu_kernel<0, 1, true, 3>" > "$R/gpurun_out/gram_kernel_by_context_$TAG.txt" 2>&1
 find "$P" -name '*.csv' -size +8M -delete
