@@ -252,25 +252,27 @@ VG_HD void eval_corner(const double *__restrict__ p, double x, double y, double 
 // Results differ from the reference-order evaluation above by a few ulp; the rows never leave the CU and the
 // Gram matrices are checked (tests/test_gpu_gram.py) against a long-double Gram of reference-order rows at 1e-10.
 // ------------------------------------------------------------------------------------------
-VG_HD void eval_corner_fast(const double *__restrict__ p, double x, double y, double z, CornerEval<6> &e,
-                            std::integral_constant<int, kEUCM>)
+__device__ __forceinline__ void eval_corner_fast(const double *__restrict__ p, double x, double y, double z, CornerEval<6> &e,
+                                                 std::integral_constant<int, kEUCM>)
 {
 #pragma clang fp contract(fast)
     const double alpha = p[0], beta = p[1], fu = p[2], fv = p[3], u0 = p[4], v0 = p[5];
     const double x2y2 = x * x + y * y;
-    const double rho = sqrt(z * z + beta * x2y2);
+    double rho, ir_raw;
+    sqrt_rsqrt_nr(z * z + beta * x2y2, rho, ir_raw);
     const double gamma = 1. - alpha;
     const double eta = alpha * rho + gamma * z;
-    const double ie_raw = 1. / eta;
+    const double ie_raw = rcp_nr(eta);
     bool ok = !(eta < 1e-3);
     if (alpha > 0.5) {
-        const double C = (alpha - 1.) / (alpha + alpha - 1.);
+        const double C = (alpha - 1.) * rcp_nr(alpha + alpha - 1.);
         if (z * ie_raw < C) ok = false;
     }
     e.ok = ok;
     // failed projection -> zero rows (eucm.h:141-150,198-206).  The two reciprocals are SELECTED to zero, so every
-    // masked product below is 0 * finite = exactly 0 (eta or rho == 0 would otherwise give 0 * inf = NaN)
-    const double ie = ok ? ie_raw : 0., ir = ok ? 1. / rho : 0.;
+    // masked product below is 0 * finite = exactly 0 (eta == 0 gives an infinite ie_raw that is never used; rho and
+    // 1 / rho are finite by construction)
+    const double ie = ok ? ie_raw : 0., ir = ok ? ir_raw : 0.;
     const double m = ok ? 1. : 0.;
     const double xn = x * ie, yn = y * ie;
     e.u = fu * xn + u0;
@@ -302,14 +304,15 @@ VG_HD void eval_corner_fast(const double *__restrict__ p, double x, double y, do
     e.Jv[5] = m;
 }
 
-VG_HD void eval_corner_fast(const double *__restrict__ p, double x, double y, double z, CornerEval<5> &e,
-                            std::integral_constant<int, kUCM>)
+__device__ __forceinline__ void eval_corner_fast(const double *__restrict__ p, double x, double y, double z, CornerEval<5> &e,
+                                                 std::integral_constant<int, kUCM>)
 {
 #pragma clang fp contract(fast)
     const double xi = p[0], fu = p[1], fv = p[2], u0 = p[3], v0 = p[4];
     const double xx = x * x, yy = y * y;
-    const double rho = sqrt(xx + yy + z * z);
-    const double ri = 1. / rho, di = 1. / (xi * rho + z);
+    double rho, ri;
+    sqrt_rsqrt_nr(xx + yy + z * z, rho, ri);
+    const double di = rcp_nr(xi * rho + z);
     const double d2 = di * di;
     const double xn = x * di, yn = y * di;
     e.ok = true;
@@ -334,15 +337,16 @@ VG_HD void eval_corner_fast(const double *__restrict__ p, double x, double y, do
     e.Jv[4] = 1.;
 }
 
-VG_HD void eval_corner_fast(const double *__restrict__ p, double x, double y, double z, CornerEval<10> &e,
-                            std::integral_constant<int, kMEI>)
+__device__ __forceinline__ void eval_corner_fast(const double *__restrict__ p, double x, double y, double z, CornerEval<10> &e,
+                                                 std::integral_constant<int, kMEI>)
 {
 #pragma clang fp contract(fast)
     const double xi = p[0], k1 = p[1], k2 = p[2], k3 = p[3], k4 = p[4], k5 = p[5];
     const double fu = p[6], fv = p[7], u0 = p[8], v0 = p[9];
     const double xx = x * x, yy = y * y;
-    const double rho = sqrt(xx + yy + z * z);
-    const double ri = 1. / rho, di = 1. / (xi * rho + z);
+    double rho, ri;
+    sqrt_rsqrt_nr(xx + yy + z * z, rho, ri);
+    const double di = rcp_nr(xi * rho + z);
     const double d2 = di * di;
     const double xn = x * di, yn = y * di;
     const double xxn = xn * xn, yyn = yn * yn, xyn = xn * yn;
@@ -392,7 +396,7 @@ VG_HD void eval_corner_fast(const double *__restrict__ p, double x, double y, do
 }
 
 template <int MODEL>
-VG_HD void eval_corner_fast(const double *__restrict__ p, double x, double y, double z,
+__device__ __forceinline__ void eval_corner_fast(const double *__restrict__ p, double x, double y, double z,
                             CornerEval<CameraTraits<MODEL>::K> &e)
 {
     eval_corner_fast(p, x, y, z, e, std::integral_constant<int, MODEL>{});

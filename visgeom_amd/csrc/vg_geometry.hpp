@@ -17,6 +17,30 @@ struct Quat {
     double x, y, z, w;
 };
 
+// Reciprocal and square root for the fused kernels: the hardware's ~2^-23 estimates (v_rcp_f64 / v_rsq_f64) refined by
+// Newton steps to 1-2 ulp, without the scaling, denormal and special-value handling of an IEEE division / sqrt (11 and
+// ~15 instructions each, three of them per corner).  Arguments are lengths and depths of points in front of a camera.
+__device__ __forceinline__ double rcp_nr(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.), r, r);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.), r, r);
+    return r;
+}
+
+// s = sqrt(x), rs = 1 / sqrt(x) in one go; x is floored at 1e-300 (x == 0: s = 1e-150, rs = 1e150, both finite)
+__device__ __forceinline__ void sqrt_rsqrt_nr(double x, double &s, double &rs)
+{
+    x = fmax(x, 1e-300);
+    double y = __builtin_amdgcn_rsq(x);
+    y = __builtin_fma(0.5 * y, __builtin_fma(-x * y, y, 1.), y);
+    y = __builtin_fma(0.5 * y, __builtin_fma(-x * y, y, 1.), y);
+    double t = x * y;
+    t = __builtin_fma(0.5 * y, __builtin_fma(-t, t, x), t);
+    s = t;
+    rs = y;
+}
+
 // translation + rotation vector, parameter order [t(3), r(3)]  (geometry/transformation.h:46)
 struct Transf {
     double t[3];
@@ -338,16 +362,16 @@ VG_HD void build_frame_single_direct(const double *xi, double *frame)
 // of the dependent instruction chain of build_frame_single_direct -- the chain walk is a serial prologue of every
 // workgroup of vg_gram_valu_kernel.  Below the reference's first-order threshold (theta < 1e-5, where its R12 is
 // I - hat(r)^2, 1e-10 away from I) and in the band just above it the reference-order routine is used unchanged.
-VG_HD void build_frame_single_direct_fast(const double *xi, double *frame)
+__device__ __forceinline__ void build_frame_single_direct_fast(const double *xi, double *frame)
 {
 #pragma clang fp contract(fast)
     const double r0 = xi[3], r1 = xi[4], r2 = xi[5];
-    const double th = sqrt(r0 * r0 + r1 * r1 + r2 * r2);
+    double th, ti;
+    sqrt_rsqrt_nr(r0 * r0 + r1 * r1 + r2 * r2, th, ti);
     if (th < 1.00000001e-5) {  // first-order forms, and the band where the reference's round trip decides the branch
         build_frame_single_direct(xi, frame);
         return;
     }
-    const double ti = 1. / th;
     const double u0 = r0 * ti, u1 = r1 * ti, u2 = r2 * ti;
     const double h = 0.5 * th;
     double sh, ch;
@@ -364,7 +388,7 @@ VG_HD void build_frame_single_direct_fast(const double *xi, double *frame)
     frame[6] = -s * u1 + cv * u2 * u0;
     frame[7] = s * u0 + cv * u2 * u1;
     // interOmegaRot, geometry_core.h:170-179: I + K1 uhat + K2 uhat^2,  K1 = h sinc(h)^2,  K2 = 1 - sinc(theta)
-    const double K1 = sh * sh / h, K2 = 1. - s * ti;
+    const double K1 = sh * sh * (2. * ti), K2 = 1. - s * ti;  // sh^2 / h with 1 / h = 2 / theta
     frame[21] = 1. + K2 * (u0 * u0 - 1.);
     frame[25] = 1. + K2 * (u1 * u1 - 1.);
     frame[29] = 1. + K2 * (u2 * u2 - 1.);
