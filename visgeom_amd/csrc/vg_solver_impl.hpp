@@ -931,11 +931,12 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
     // ================================================================== device loop
     // Problems made of grid blocks only (no priors, no odometry, no host-staged all-reduce): the reduced solve and the
     // step acceptance run in two one-workgroup kernels, the trust-region state lives on the device, and an iteration
-    // is a fixed sequence of launches with ONE host synchronisation at its end (three
-    // synchronisations and a loop of one-double copies per iteration).
-    // Measured (tools/prof_solve.py, one MI355X): 10 k EUCM images 0.166 vs 0.21 ms per iteration, Mei equal, the
-    // 45-column rig 0.43 vs 0.37 -- there the one-workgroup factorisation of the reduced system costs more than the
-    // host's round trip, so wide systems keep the host loop.  VG_SOLVER_HOST_LOOP / VG_SOLVER_DEVICE_LOOP force a side.
+    // is a fixed sequence of eight launches; the host only reads the state the accept kernel publishes in pinned memory
+    // (the first version synchronised three times per iteration and copied G doubles one by one).
+    // Measured (tools/exp/solve_probe.py, tools/prof_solve.py, one MI355X): 10 k EUCM images 0.110 ms per iteration
+    // against 0.21 for the host-driven loop, Mei 0.118; the 45-column rig 0.338 against 0.293 -- there the one-workgroup
+    // factorisation of the reduced system costs more than the host's round trip, so wide systems keep the host loop.
+    // VG_SOLVER_HOST_LOOP / VG_SOLVER_DEVICE_LOOP force a side.
     static const bool force_host_loop = getenv("VG_SOLVER_HOST_LOOP") != nullptr;      // measurement / A-B hooks
     static const bool force_device_loop = getenv("VG_SOLVER_DEVICE_LOOP") != nullptr;
     if (coupled.empty() && p->priors.empty() && !opt.allreduce && !force_host_loop && (G <= 32 || force_device_loop)) {
