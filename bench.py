@@ -288,15 +288,20 @@ def main():
     from visgeom_amd import capi
 
     single_launch = capi.load().vg_dataset_single_launch(p._h, ds) == 1
-    traffic = None
+    # HBM traffic per launch cannot be measured from inside this process (PMC counters need rocprofv3): it is read from the
+    # committed summary of the separate --pmc passes of this same command (tools/gpu_check.sh, tools/prof_summary.py)
+    traffic, traffic_source = None, None
     prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(prof):
         try:
-            traffic = json.load(open(prof)).get("%s_%d" % (a.model, a.images), {}).get("hbm_bytes_per_launch")
+            entry = json.load(open(prof)).get("%s_%d" % (a.model, a.images), {})
+            traffic = entry.get("hbm_bytes_per_launch")
+            if traffic is not None:
+                traffic_source = "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tag %s" % entry.get("tag")
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                 # single-member DIRECT chain, output within reach of the Infinity Cache: the emit kernel derives the
                 # frames itself and the step is this ONE launch; larger sets run chain prep + emit
                 "kernel": "vg_emit_kernel<%s,jac,frames-in-LDS%s>" % (a.model, ",inline-chain" if single_launch else ""),
