@@ -297,6 +297,11 @@ int vg_comm_unique_id(char *id /* VG_COMM_ID_BYTES */);
 int vg_comm_create(vg_comm **out, const char *id, int n_ranks, int rank, int device);
 /* wrap an ncclComm_t the host application already owns (not destroyed by vg_comm_destroy) */
 int vg_comm_adopt(vg_comm **out, void *nccl_comm, int device);
+/* A communicator without RCCL behind it: this process stands for `replicas` ranks that all hold the SAME shard, so every
+ * sum over ranks is `replicas` times the local value.  It lets a one-GPU box run the multi-rank control flow of the solver
+ * (packed collectives, summable convergence tests, identical branches on every rank): the result must be the one-rank
+ * solution with the cost multiplied by `replicas`. */
+int vg_comm_create_replicated(vg_comm **out, int replicas, int device);
 int vg_comm_size(const vg_comm *c);
 int vg_comm_rank(const vg_comm *c);
 /* in-place sum of n doubles at device_buf over all ranks (ncclAllReduce, ncclDouble, ncclSum), enqueued on hip_stream */

@@ -76,3 +76,66 @@ def test_n_ranks_over_rccl_equal_the_single_gpu_solve():
     out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     text = out.stdout.decode()
     assert out.returncode == 0 and "RCCL_WORKER_OK world=%d" % world in text, text[-4000:]
+
+
+@pytest.mark.parametrize("replicas", [2, 8])
+def test_multi_rank_control_flow_on_one_gpu_with_a_replicated_communicator(replicas):
+    """vg_comm_create_replicated: this rank stands for `replicas` ranks holding the same shard, every sum over ranks is
+    replicas x the local value.  The solver then runs exactly what N real ranks run -- packed collectives of the summed
+    Gram blocks / step scalars / Schur complement, the summable 2-norm instead of the max-norm of the pose gradient, no
+    speculative queueing -- and must end at the one-rank optimum with `replicas` times the cost: mono (device-resident loop),
+    stereo (several datasets, merged Gram launch) and a rig (host-driven loop, 45 global columns)."""
+    import visgeom_amd as vg
+    from visgeom_amd import distributed as D, synthetic as S
+
+    comm = D.Comm.replicated(replicas)
+    assert (comm.n_ranks, comm.rank) == (replicas, 0)
+
+    def check(build, iters=150):
+        p = build()
+        s0 = p.solve(max_num_iterations=iters)
+        x0 = p.get_parameters()
+        p.close()
+        q = build()
+        s1 = q.solve(comm=comm, max_num_iterations=iters)
+        x1 = q.get_parameters()
+        q.close()
+        assert s0["termination"].startswith("CONVERGENCE") and s1["termination"].startswith("CONVERGENCE"), (s0, s1)
+        assert abs(s1["final_cost"] - replicas * s0["final_cost"]) <= 1e-9 * replicas * s0["final_cost"]
+        assert abs(s1["initial_cost"] - replicas * s0["initial_cost"]) <= 1e-12 * replicas * s0["initial_cost"]
+        scale = np.maximum(np.abs(x0), 1.0)
+        assert np.max(np.abs(x1 - x0) / scale) < 1e-6, np.max(np.abs(x1 - x0) / scale)   # both stop at rounding level
+
+    for model in ("eucm", "mei"):
+        check(lambda: _problem(vg, model, 40)[0])
+
+    st = S.make_stereo(30, sigma=0.1)
+
+    def stereo():
+        p = vg.CalibrationProblem(0)
+        c1 = p.add_camera("eucm", st["init_intrinsics1"])
+        c2 = p.add_camera("eucm", st["init_intrinsics2"])
+        x12 = p.add_transform(True, st["init_xi12"])
+        seq = p.add_transform(False, st["init_poses"])
+        p.add_dataset(c1, [(seq, 0)], st["board"], st["corners1"])
+        p.add_dataset(c2, [(x12, 1), (seq, 0)], st["board"], st["corners2"])
+        p.finalize()
+        return p
+
+    check(stereo)
+
+    r = S.make_rig(25, sigma=0.1)
+
+    def rig():
+        p = vg.CalibrationProblem(0)
+        cams = [p.add_camera(m, r["init_intrinsics"][k]) for k, m in enumerate(r["models"])]
+        x1k = [p.add_transform(True, r["init_xi1k"][k]) for k in range(3)]
+        seq = p.add_transform(False, r["init_poses"])
+        p.add_dataset(cams[0], [(seq, 0)], r["board"], r["corners"][0])
+        for k in range(3):
+            p.add_dataset(cams[k + 1], [(x1k[k], 1), (seq, 0)], r["board"], r["corners"][k + 1])
+        p.finalize()
+        return p
+
+    check(rig, iters=300)
+    comm.close()

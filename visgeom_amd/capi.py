@@ -121,6 +121,7 @@ SIGNATURES = {
     "vg_comm_unique_id": (ctypes.c_int, [ctypes.c_char_p]),
     "vg_comm_create": (ctypes.c_int, [_vpp, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "vg_comm_adopt": (ctypes.c_int, [_vpp, _vp, ctypes.c_int]),
+    "vg_comm_create_replicated": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int]),
     "vg_comm_size": (ctypes.c_int, [_vp]),
     "vg_comm_rank": (ctypes.c_int, [_vp]),
     "vg_comm_allreduce_sum": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, _vp]),

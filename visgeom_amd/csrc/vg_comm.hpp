@@ -19,6 +19,7 @@ struct vg_comm {
     ncclComm_t comm = nullptr;
     int n_ranks = 1, rank = 0, device = 0;
     bool owned = true;  // created here (destroyed here) or adopted from the host
+    int replicas = 0;   // > 0: no RCCL behind it -- this rank stands for `replicas` ranks holding identical shards
 };
 
 namespace vgc {
@@ -81,10 +82,22 @@ inline int need_api()
             return vgi::fail(VG_ERR_HIP, std::string(#expr) + ": " + vgc::api().error_string(r_));        \
     } while (0)
 
+__global__ void vg_scale_in_place_kernel(double *buf, size_t n, double f)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) buf[i] *= f;
+}
+
 // in-place sum over the ranks of c, enqueued on `stream`; a NULL or one-rank communicator is the identity
 inline int allreduce_sum(const vg_comm *c, double *device_buf, size_t n, hipStream_t stream)
 {
     if (!c || c->n_ranks <= 1 || !n) return VG_OK;
+    if (c->replicas > 0) {  // the sum over `replicas` identical ranks
+        hipLaunchKernelGGL(vg_scale_in_place_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, device_buf, n,
+                           (double)c->replicas);
+        VG_HIP(hipGetLastError());
+        return VG_OK;
+    }
     VG_NCCL(api().all_reduce(device_buf, device_buf, n, ncclDouble, ncclSum, c->comm, stream));
     return VG_OK;
 }
@@ -146,6 +159,22 @@ int vg_comm_adopt(vg_comm **out, void *nccl_comm, int device)
         delete c;
         return vgi::fail(VG_ERR_HIP, std::string("ncclCommCount / ncclCommUserRank: ") + vgc::api().error_string(r));
     }
+    *out = c;
+    return VG_OK;
+}
+
+int vg_comm_create_replicated(vg_comm **out, int replicas, int device)
+{
+    if (!out) return vgi::fail(VG_ERR_INVALID_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    if (replicas < 1) return vgi::fail(VG_ERR_INVALID_ARGUMENT, "replicas must be positive");
+    vg_comm *c = new (std::nothrow) vg_comm();
+    if (!c) return vgi::fail(VG_ERR_ALLOC, "out of host memory");
+    c->n_ranks = replicas;
+    c->rank = 0;
+    c->device = device;
+    c->owned = false;
+    c->replicas = replicas;
     *out = c;
     return VG_OK;
 }

@@ -68,6 +68,19 @@ class Comm:
         self._h = h
         self.n_ranks, self.rank, self.device = int(n_ranks), int(rank), int(device)
 
+    @classmethod
+    def replicated(cls, replicas, device=0):
+        """a communicator standing for `replicas` ranks with identical shards (vg_comm_create_replicated): no RCCL"""
+        from . import capi
+
+        self = cls.__new__(cls)
+        self._lib = capi.load()
+        h = ctypes.c_void_p()
+        capi.check(self._lib.vg_comm_create_replicated(ctypes.byref(h), int(replicas), int(device)))
+        self._h = h
+        self.n_ranks, self.rank, self.device = int(replicas), 0, int(device)
+        return self
+
     @staticmethod
     def unique_id():
         from . import capi
