@@ -5,3 +5,8 @@ __version__ = "0.1.0"
 
 from . import capi  # noqa: F401
 from .problem import BlockGroup, CalibrationProblem, GenericProjectionJac  # noqa: F401
+
+
+def release_cached_memory():
+    """hand the solver's cached device / pinned work blocks back to the driver (vg_release_cached_memory)"""
+    capi.load().vg_release_cached_memory()
