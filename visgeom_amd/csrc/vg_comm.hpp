@@ -185,6 +185,13 @@ int vg_comm_rank(const vg_comm *c) { return c ? c->rank : -1; }
 int vg_comm_allreduce_sum(vg_comm *c, double *device_buf, int64_t n, void *hip_stream)
 {
     if (!c || (n > 0 && !device_buf) || n < 0) return vgi::fail(VG_ERR_INVALID_ARGUMENT, "bad arguments");
+    // the explicit entry always goes through RCCL, also with one rank (where the solver skips the call): the binding is
+    // exercised on every GPU box, not only on multi-GPU nodes
+    if (c->comm && c->n_ranks == 1 && n > 0) {
+        VG_NCCL(vgc::api().all_reduce(device_buf, device_buf, (size_t)n, ncclDouble, ncclSum, c->comm,
+                                      reinterpret_cast<hipStream_t>(hip_stream)));
+        return VG_OK;
+    }
     return vgc::allreduce_sum(c, device_buf, (size_t)n, reinterpret_cast<hipStream_t>(hip_stream));
 }
 
