@@ -73,6 +73,7 @@ CASES = [("eucm", 40, "D", None),      # W = 13                          (config
          ("ucm", 17, "D", None),       # W = 12
          ("mei", 23, "D", None),       # W = 17                          (config 4 shape)
          ("eucm", 19, "ID", None),     # W = 19, stereo cam-2 shape      (config 3)
+         ("mei", 21, "ID", None),      # W = 23: 276 upper-triangle entries, more than a workgroup has threads
          ("mei", 9, "IDDID", None),    # W = 41, three tiles, chain of 5
          ("eucm", 11, "D", 7),         # odd N < wave: image rows end mid-MFMA group
          ("ucm", 6, "ID", 65),         # N = 65: second 64-corner tile holds one corner
@@ -116,6 +117,12 @@ def test_gram_fused_two_pass_and_sum(vg, model, n_images, chain_kind, n_points):
     p.gram_sum(ds, gram, gsum2)
     p.synchronize()
     assert torch.equal(gsum, gsum2), "reduction must be run-to-run reproducible"
+    # blocks + sum in one call (vg_dataset_gram_fused_sum: per-workgroup partials of the vector-pipe kernel, one final launch)
+    gram3, gsum3 = torch.full_like(gram, float("nan")), torch.full_like(gsum, float("nan"))
+    p.gram_fused_sum(ds, gram3, gsum3)
+    p.synchronize()
+    assert torch.equal(gram3, gram)
+    assert np.linalg.norm(gsum3.cpu().numpy() - ref_sum) <= TOL * np.linalg.norm(ref_sum)
     # cost = 1/2 r^T r (what Ceres reports) sits in the last entry
     r, _, _ = vgo.eval_dataset(vgo.MODELS[model], status, board, corners, pv, 0, bases, strides, np.arange(n_images),
                                want_jac=False)

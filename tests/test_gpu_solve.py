@@ -796,6 +796,8 @@ def test_cached_solver_blocks_are_reused_and_released(vg):
         p.close()
         return s, x
 
+    solve(300)                              # first use of the library in a process: code objects, runtime pools
+    solve(2000)
     lib.vg_release_cached_memory()
     torch.cuda.synchronize()
     torch.cuda.empty_cache()

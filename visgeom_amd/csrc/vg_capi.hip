@@ -895,7 +895,20 @@ int vgi::gram_fused_at(vg_problem *p, int dataset_id, const double *d_params, do
     return vgi::gram_sum_into(p, dataset_id, gram, sum);
 }
 
-int vgi::gram_fused_merged_at(vg_problem *p, const double *d_params, double *const *grams, std::vector<char> &taken)
+bool vgi::gram_merge_covers_all(const vg_problem *p)
+{
+    if (getenv("VG_GRAM_NO_MERGE") || getenv("VG_GRAM_CH1")) return false;
+    int n = 0;
+    for (const Dataset &d : p->dss) {
+        if (!d.n_blocks) continue;
+        if (!(d.n_blocks <= 0x7fffffff && gram_uses_valu(p, d) && (d.L == 1 || d.L == 2) && d.N > vg::kValuLanesPerImage)) return false;
+        n++;
+    }
+    return n >= 2 && n % vg::kGramMultiMax != 1;  // a lone leftover group would go the ordinary way
+}
+
+int vgi::gram_fused_merged_at(vg_problem *p, const double *d_params, double *const *grams, std::vector<char> &taken,
+                              double *const *partials)
 {
     static const bool off = getenv("VG_GRAM_NO_MERGE") != nullptr || getenv("VG_GRAM_CH1") != nullptr;  // measurement hooks
     const int n_ds = (int)p->dss.size();
@@ -923,7 +936,7 @@ int vgi::gram_fused_merged_at(vg_problem *p, const double *d_params, double *con
             a.chain_stride = d.chain.stride[0];
             a.seq_index = d.seq_identity ? nullptr : d.d_seq;
             a.n_wg = (unsigned int)((d.n_blocks + vg::kValuImagesPerBlock - 1) / vg::kValuImagesPerBlock);
-            a.partials = nullptr;
+            a.partials = partials ? partials[ids[g0 + k]] : nullptr;
             m.kind[k] = 3 * cam.model + (d.L == 2 ? 2 : (gram_inline_chain(p, d) ? 0 : 1));
             m.first_wg[k] = wgs;
             wgs += a.n_wg;
@@ -960,7 +973,7 @@ int vg_problem_gram_fused(vg_problem *p, double *const *grams)
         if (p->dss[i].n_blocks && !grams[i]) return fail(VG_ERR_INVALID_ARGUMENT, "gram is NULL");
     if (vgi::gram_needs_frames(p) && (rc = vgi::ensure_frames(p)) != VG_OK) return rc;
     std::vector<char> taken;
-    if ((rc = vgi::gram_fused_merged_at(p, p->d_params, grams, taken)) != VG_OK) return rc;
+    if ((rc = vgi::gram_fused_merged_at(p, p->d_params, grams, taken, nullptr)) != VG_OK) return rc;
     for (size_t i = 0; i < p->dss.size(); i++)
         if (!taken[i] && p->dss[i].n_blocks && (rc = vgi::gram_fused_at(p, (int)i, p->d_params, grams[i], nullptr)) != VG_OK) return rc;
     return VG_OK;

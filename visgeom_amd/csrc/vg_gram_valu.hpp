@@ -378,11 +378,11 @@ __device__ __forceinline__ void gram_valu_body(const GramValuArgs &a, const unsi
     }
     if (a.partials) {
         __syncthreads();
-        if (tid < E) {
-            double s = red[tid];
+        for (int e = tid; e < E; e += kValuThreads) {  // E = 276 for the 23-wide block: more entries than threads
+            double s = red[e];
 #pragma unroll
-            for (int w = 1; w < kValuThreads / kWave; w++) s += red[w * E + tid];  // fixed order
-            a.partials[(size_t)tid * a.n_wg + block] = s;
+            for (int w = 1; w < kValuThreads / kWave; w++) s += red[w * E + e];  // fixed order
+            a.partials[(size_t)e * a.n_wg + block] = s;
         }
     }
 }
@@ -460,6 +460,52 @@ __global__ __launch_bounds__(256) void vg_gram_partials_sum_kernel(const double 
         const int c = r + rem;
         out[r * W + c] = t;
         out[c * W + r] = t;
+    }
+}
+
+// vg_gram_partials_sum_kernel for SEVERAL datasets in one launch (the merged Gram launch left one [E][n_wg] array per
+// dataset): one workgroup per (dataset, entry), same order of summation per dataset as the single-dataset kernel.
+struct PartialSumDataset {
+    const double *partials;  // [E][n_wg]
+    double *out;             // [W][W]
+    unsigned int n_wg;
+    int W;
+    unsigned int first_block;  // first workgroup of this dataset in the launch (E of them)
+};
+
+__global__ __launch_bounds__(256) void vg_gram_partials_sum_multi_kernel(const PartialSumDataset *__restrict__ ds, int n_ds)
+{
+    int d = 0;
+    while (d + 1 < n_ds && blockIdx.x >= ds[d + 1].first_block) d++;
+    const PartialSumDataset D = ds[d];
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+    const int e = (int)(blockIdx.x - D.first_block);
+    const double *src = D.partials + (size_t)e * D.n_wg;
+    double s = 0.;
+    for (unsigned int i0 = 0; i0 < D.n_wg; i0 += 8 * 256) {
+        double v[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const unsigned int i = i0 + q * 256 + tid;
+            v[q] = i < D.n_wg ? src[i] : 0.;
+        }
+        s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, kWave);
+    __shared__ double red[4];
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    if (tid == 0) {
+        const double t = (red[0] + red[1]) + (red[2] + red[3]);
+        int r = 0, rem = e;
+        while (rem >= D.W - r) {
+            rem -= D.W - r;
+            r++;
+        }
+        const int c = r + rem;
+        D.out[r * D.W + c] = t;
+        D.out[c * D.W + r] = t;
     }
 }
 

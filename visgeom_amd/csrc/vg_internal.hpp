@@ -137,7 +137,9 @@ int ensure_frames(vg_problem *p);  // chain prep at the problem's own parameters
 int gram_fused_at(vg_problem *p, int dataset_id, const double *d_params, double *gram, double *sum);
 // the fused Gram of every dataset the merged vector-pipe launch can take (taken[d] = 1), at a device parameter buffer;
 // grams[d] = that dataset's [n_blocks][W*W] output.  The others are the caller's (gram_fused_at).
-int gram_fused_merged_at(vg_problem *p, const double *d_params, double *const *grams, std::vector<char> &taken);
+int gram_fused_merged_at(vg_problem *p, const double *d_params, double *const *grams, std::vector<char> &taken,
+                         double *const *partials /* per dataset [E][ceil(n_blocks / 8)] or NULL */);
+bool gram_merge_covers_all(const vg_problem *p);  // every non-empty dataset goes through the merged launch
 bool gram_needs_frames(const vg_problem *p);  // false when every dataset's Gram kernel walks its chain itself
 int gram_sum_into(vg_problem *p, int dataset_id, const double *gram, double *sum);
 }  // namespace vgi

@@ -830,6 +830,33 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
         VG_TRY(d_sumA.upload(ta));
         VG_TRY(d_sumB.upload(tb));
     }
+    // several datasets, all of them on the merged vector-pipe launch and no loss function: the launch leaves per-workgroup
+    // partial sums and ONE launch adds them -- the slab pass, which reads every Gram block again, is not needed
+    const bool use_partials = n_ds > 1 && !(opt.soft_l1_scale > 0.) && vgi::gram_merge_covers_all(p);
+    std::vector<DevBuf<double>> wg_partials((size_t)n_ds);
+    std::vector<double *> wg_partials_ptr((size_t)n_ds, nullptr);
+    DevBuf<vg::PartialSumDataset> d_psum;
+    unsigned int psum_blocks = 0;
+    int n_psum = 0;
+    if (use_partials) {
+        std::vector<vg::PartialSumDataset> tab;
+        for (int d = 0; d < n_ds; d++) {
+            if (!p->dss[d].n_blocks) continue;  // its slot of d_sums stays zero
+            vg::PartialSumDataset pd;
+            pd.n_wg = (unsigned int)((p->dss[d].n_blocks + vg::kValuImagesPerBlock - 1) / vg::kValuImagesPerBlock);
+            pd.W = Wd[d];
+            const int E = Wd[d] * (Wd[d] + 1) / 2;
+            VG_TRY(wg_partials[(size_t)d].alloc((size_t)E * pd.n_wg));
+            wg_partials_ptr[(size_t)d] = wg_partials[(size_t)d].p;
+            pd.partials = wg_partials[(size_t)d].p;
+            pd.out = d_sums.p + (size_t)d * Wmax * Wmax;
+            pd.first_block = psum_blocks;
+            psum_blocks += (unsigned int)E;
+            tab.push_back(pd);
+        }
+        n_psum = (int)tab.size();
+        VG_TRY(d_psum.upload(tab));
+    }
     // queue the evaluation of the Gram matrices at a device parameter buffer into gram set `set`, their fixed-order sums
     // into d_sums and the ONE collective of an evaluation (no host synchronisation)
     auto enqueue_evaluate = [&](const double *x_dev, DevBuf<double> *set) -> int {
@@ -840,7 +867,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
         if (n_ds > 1) {
             std::vector<double *> gp((size_t)n_ds);
             for (int d = 0; d < n_ds; d++) gp[(size_t)d] = set[d].p;
-            if ((r = vgi::gram_fused_merged_at(p, x_dev, gp.data(), merged)) != VG_OK) return r;
+            if ((r = vgi::gram_fused_merged_at(p, x_dev, gp.data(), merged, use_partials ? wg_partials_ptr.data() : nullptr)) != VG_OK) return r;
         }
         for (int d = 0; d < n_ds; d++) {
             double *sum_d = d_sums.p + (size_t)d * Wmax * Wmax;
@@ -858,7 +885,11 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             }
             if (!sum_slab_blocks && !fused_sum && (r = vgi::gram_sum_into(p, d, set[d].p, sum_d)) != VG_OK) return r;
         }
-        if (sum_slab_blocks) {
+        if (use_partials) {
+            hipLaunchKernelGGL(vg::vg_gram_partials_sum_multi_kernel, dim3(psum_blocks), dim3(256), 0, st,
+                               (const vg::PartialSumDataset *)d_psum.p, n_psum);
+            VG_HIP(hipGetLastError());
+        } else if (sum_slab_blocks) {
             const vg::SumDataset *tab = set == gramA ? d_sumA.p : d_sumB.p;
             int n_tab = 0;
             for (int d = 0; d < n_ds; d++) n_tab += p->dss[d].n_blocks ? 1 : 0;
