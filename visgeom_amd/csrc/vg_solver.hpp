@@ -213,7 +213,7 @@ struct BacksubArgs {
     unsigned long long *gmax_bits; // max |gp| over active poses, as the bit pattern of a non-negative double
     const double *x;               // current parameter vector
     double *xg;                    // [G] current values of the global columns (gathered for the host)
-    const double *lo, *hi;         // box of every parameter
+    const double *lo, *hi;         // [G] box of every global column (poses are unbounded)
     double *x_new;                 // clamp(x + delta, lo, hi) of the global columns and of this kernel's poses
 };
 
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(kBsThreads) void vg_backsub_kernel(BacksubArgs b)
         const long long gp = b.gcol_param[t];
         b.delta[gp] = b.dg[t];
         b.xg[t] = b.x[gp];
-        b.x_new[gp] = clampd(b.x[gp] + b.dg[t], b.lo[gp], b.hi[gp]);
+        b.x_new[gp] = clampd(b.x[gp] + b.dg[t], b.lo[t], b.hi[t]);
     }
     if ((int)(blockIdx.x * kBsPosesPerBlock) >= a.n_poses) return;  // workgroups that only carry global columns
     const int gl = threadIdx.x & (kBsGroup - 1), grp = threadIdx.x >> 4;
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(kBsThreads) void vg_backsub_kernel(BacksubArgs b)
             for (int c = 0; c < 6; c++) {
                 const double v = active ? -x[c] : 0.;
                 dp[c] = v;
-                b.x_new[pp + c] = clampd(xk[c] + v, b.lo[pp + c], b.hi[pp + c]);  // the candidate point (poses are unbounded: x + dp)
+                b.x_new[pp + c] = xk[c] + v;  // the candidate point (poses are unbounded)
                 const double g = gk[c];
                 s0 += g * v;
                 s1 += clampd(dk[c], a.dmin, a.dmax) * v * v;
@@ -339,15 +339,13 @@ __global__ __launch_bounds__(kBsThreads) void vg_backsub_kernel(BacksubArgs b)
     }
 }
 
-// x_new = clamp(x + delta, lo, hi)
-__global__ __launch_bounds__(256) void vg_apply_step_kernel(const double *__restrict__ x, const double *__restrict__ delta,
-                                                             const double *__restrict__ lo, const double *__restrict__ hi,
-                                                             long long n, double *__restrict__ x_new)
+// x_new = x + delta (pose parameters: unbounded)
+__global__ __launch_bounds__(256) void vg_apply_step_kernel(const double *__restrict__ x, const double *__restrict__ delta, long long n,
+                                                             double *__restrict__ x_new)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const double v = x[i] + delta[i];
-    x_new[i] = v < lo[i] ? lo[i] : (v > hi[i] ? hi[i] : v);
+    x_new[i] = x[i] + delta[i];
 }
 
 // Gram of a plain row-major matrix X [n_rows][C], one wave per group of `rows_per_group` rows (a multiple of 4),

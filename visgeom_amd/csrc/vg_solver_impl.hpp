@@ -584,14 +584,15 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
 
     std::vector<unsigned char> gfrozen(G, 0), pose_frozen((size_t)n_poses, 0);
     std::vector<long long> gcol_param(G), pose_param((size_t)n_poses);
-    std::vector<double> lo((size_t)n_params, -std::numeric_limits<double>::infinity()),
-        hi((size_t)n_params, std::numeric_limits<double>::infinity());
+    // box bounds exist for intrinsics only (eucm.h:228-246, ucm.h:199-215, mei.h:287-313, set at unified_calibration.cpp:
+    // 621-627), i.e. for global columns: one pair per column, nothing per pose parameter
+    std::vector<double> glo((size_t)G, -std::numeric_limits<double>::infinity()), ghi((size_t)G, std::numeric_limits<double>::infinity());
     for (size_t c = 0; c < p->cams.size(); c++)
         for (int k = 0; k < p->cams[c].K; k++) {
             gfrozen[cam_goff[c] + k] = p->cams[c].constant;
             gcol_param[cam_goff[c] + k] = p->cams[c].offset + k;
             if (opt.use_bounds && !p->cams[c].constant)
-                vg_intrinsic_bounds(p->cams[c].model, k, &lo[p->cams[c].offset + k], &hi[p->cams[c].offset + k]);
+                vg_intrinsic_bounds(p->cams[c].model, k, &glo[(size_t)(cam_goff[c] + k)], &ghi[(size_t)(cam_goff[c] + k)]);
         }
     for (size_t b = 0; b < p->pblocks.size(); b++)
         for (int k = 0; k < p->pblocks[b].size; k++) {
@@ -722,7 +723,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
     // one device block + one pinned block for the whole solve (SolveArena); sizes: the buffers below, generously rounded
     size_t up_need = 64 * 1024 + (size_t)n_ds * 1024;
     up_need += sizeof(int) * (inv.size() + ref_ptr.size() + ref_ds.size() + ref_blk.size()) + (size_t)n_poses * (1 + sizeof(long long));
-    up_need += sizeof(double) * 2 * (size_t)n_params + sizeof(long long) * (size_t)G + 16 * 256;
+    up_need += sizeof(double) * 2 * (size_t)G + sizeof(long long) * (size_t)G + 16 * 256;
     size_t dev_need = up_need + (4u << 20);
     for (int d = 0; d < n_ds; d++) {
         const size_t ww = (size_t)Wd[d] * Wd[d];
@@ -735,7 +736,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
     ArenaScope arena_scope(p->device, dev_need, pin_need, up_need);
     std::vector<DevBuf<double>> gramA_v((size_t)(n_ds ? n_ds : 1)), gramB_v((size_t)(n_ds ? n_ds : 1));  // sized once, never resized
     DevBuf<double> *const gramA = gramA_v.data(), *const gramB = gramB_v.data();
-    DevBuf<double> d_sums, d_x, d_xc, d_delta, d_lo, d_hi, d_rec, d_rows, d_rgroups, d_rgram, d_dg, d_scal;
+    DevBuf<double> d_sums, d_x, d_xc, d_delta, d_glo, d_ghi, d_rec, d_rows, d_rgroups, d_rgram, d_dg, d_scal;
     DevBuf<vg::SolveDatasetDev> d_dsA, d_dsB;
     DevBuf<int> d_inv, d_ref_ptr, d_ref_ds, d_ref_blk, d_bad;
     DevBuf<unsigned char> d_pf;
@@ -759,8 +760,8 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
     VG_TRY(d_pf.upload(pose_frozen));
     VG_TRY(d_pose_param.upload(pose_param));
     VG_TRY(d_gcol_param.upload(gcol_param));
-    VG_TRY(d_lo.upload(lo));
-    VG_TRY(d_hi.upload(hi));
+    VG_TRY(d_glo.upload(glo));
+    VG_TRY(d_ghi.upload(ghi));
     mark("uploads");
     VG_TRY(d_sums.alloc((size_t)n_ds * Wmax * Wmax + 5));
     VG_TRY(d_x.alloc((size_t)n_params));
@@ -972,7 +973,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
     static const bool force_device_loop = getenv("VG_SOLVER_DEVICE_LOOP") != nullptr;
     if (coupled.empty() && p->priors.empty() && !opt.allreduce && !force_host_loop && (G <= 32 || force_device_loop)) {
         DevBuf<vg::LmState> d_state;
-        DevBuf<double> d_U, d_gvec, d_S, d_xcur, d_glo, d_ghi;
+        DevBuf<double> d_U, d_gvec, d_S, d_xcur;
         DevBuf<int> d_Wd;
         DevBuf<unsigned char> d_gfrozen;
         VG_TRY(d_state.alloc(1));
@@ -980,13 +981,6 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
         VG_TRY(d_gvec.alloc((size_t)2 * G));
         VG_TRY(d_S.alloc((size_t)G * G));
         VG_TRY(d_xcur.alloc((size_t)G));
-        std::vector<double> glo(G), ghi(G);
-        for (int a2 = 0; a2 < G; a2++) {
-            glo[a2] = lo[(size_t)gcol_param[a2]];
-            ghi[a2] = hi[(size_t)gcol_param[a2]];
-        }
-        VG_TRY(d_glo.upload(glo));
-        VG_TRY(d_ghi.upload(ghi));
         VG_TRY(d_Wd.upload(Wd));
         VG_TRY(d_gfrozen.upload(gfrozen));
         vg::LmState h0;
@@ -1142,8 +1136,8 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             ba.gmax_bits = d_gmax.p;
             ba.x = xbuf[par];
             ba.xg = d_xg.p;
-            ba.lo = d_lo.p;
-            ba.hi = d_hi.p;
+            ba.lo = d_glo.p;
+            ba.hi = d_ghi.p;
             ba.x_new = xbuf[1 - par];   // the step is applied where it is computed: no separate launch
             if (n_poses || G) {
                 const unsigned int bs_grid = n_bs_groups ? n_bs_groups : 1u;
@@ -1380,7 +1374,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             if (step_ok && opt.use_bounds)
                 for (int a2 = 0; a2 < G; a2++) {
                     if (held[a2]) continue;
-                    const double l2 = lo[(size_t)gcol_param[a2]], h2 = hi[(size_t)gcol_param[a2]];
+                    const double l2 = glo[(size_t)a2], h2 = ghi[(size_t)a2];
                     if ((h_xcur[a2] <= l2 && dg[a2] < 0.) || (h_xcur[a2] >= h2 && dg[a2] > 0.)) {
                         held[a2] = 1;
                         changed = true;
@@ -1409,9 +1403,9 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             ba.gmax_bits = d_gmax.p;
             ba.x = d_x.p;
             ba.xg = d_xg.p;
-            ba.lo = d_lo.p;
-            ba.hi = d_hi.p;
-            ba.x_new = d_xc.p;   // overwritten by vg_apply_step_kernel below (host-eliminated sequences add their steps first)
+            ba.lo = d_glo.p;
+            ba.hi = d_ghi.p;
+            ba.x_new = d_xc.p;   // host-eliminated sequences overwrite their poses below
             if (n_poses || G) {  // G <= kBsThreads: one workgroup is enough for the global columns alone
                 const unsigned int bs_grid = n_bs_groups ? n_bs_groups : 1u;
                 if (G < 64) hipLaunchKernelGGL(vg::vg_backsub_kernel<4>, dim3(bs_grid), dim3(vg::kBsThreads), 0, st, ba);
@@ -1433,10 +1427,13 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
                 VG_HIP(hipMemcpyAsync(d_delta.p + c2.param_off, dp.data(), sizeof(double) * dp.size(), hipMemcpyHostToDevice, st));
                 VG_HIP(hipStreamSynchronize(st));
             }
-            if (n_params) {
-                hipLaunchKernelGGL(vg::vg_apply_step_kernel, dim3((unsigned)((n_params + 255) / 256)), dim3(256), 0, st,
-                                   (const double *)d_x.p, (const double *)d_delta.p, (const double *)d_lo.p,
-                                   (const double *)d_hi.p, (long long)n_params, d_xc.p);
+            // the back-substitution kernel wrote the candidate of every global column and of every pose it owns; the
+            // poses of host-eliminated sequences (unbounded) take their steps here
+            for (auto &c2 : coupled) {
+                const long long n2 = (long long)c2.n * 6;
+                hipLaunchKernelGGL(vg::vg_apply_step_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, st,
+                                   (const double *)d_x.p + c2.param_off, (const double *)d_delta.p + c2.param_off, n2,
+                                   d_xc.p + c2.param_off);
                 VG_HIP(hipGetLastError());
             }
             double *ps = pin_small.p + G;  // [gmax 1 | xg G]
@@ -1458,7 +1455,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             // global values of the candidate: clamp(x + dg), as vg_apply_step_kernel does
             std::vector<double> xg_c(G);
             for (int a2 = 0; a2 < G; a2++) {
-                const double v = h_xg[a2] + dg[a2], l2 = lo[(size_t)gcol_param[a2]], h2 = hi[(size_t)gcol_param[a2]];
+                const double v = h_xg[a2] + dg[a2], l2 = glo[(size_t)a2], h2 = ghi[(size_t)a2];
                 xg_c[a2] = v < l2 ? l2 : (v > h2 ? h2 : v);
             }
             for (auto &c2 : coupled) {
@@ -1503,7 +1500,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
                 // projected gradient for bounded parameters: |Project(x - g) - x|
                 const double xv = h_xg[a2];
                 double xg = xv - gg[a2];
-                const double l2 = lo[(size_t)gcol_param[a2]], h2 = hi[(size_t)gcol_param[a2]];
+                const double l2 = glo[(size_t)a2], h2 = ghi[(size_t)a2];
                 xg = xg < l2 ? l2 : (xg > h2 ? h2 : xg);
                 gmax_g = std::fabs(xg - xv) > gmax_g ? std::fabs(xg - xv) : gmax_g;
             }
@@ -1537,7 +1534,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             std::swap(d_x.p, d_xc.p);
             for (auto &c2 : coupled) c2.x.swap(c2.xc);
             for (int a2 = 0; a2 < G; a2++) {  // what vg_apply_step_kernel wrote: clamp(x + dg)
-                const double v = h_xg[a2] + dg[a2], l2 = lo[(size_t)gcol_param[a2]], h2 = hi[(size_t)gcol_param[a2]];
+                const double v = h_xg[a2] + dg[a2], l2 = glo[(size_t)a2], h2 = ghi[(size_t)a2];
                 h_xcur[a2] = v < l2 ? l2 : (v > h2 ? h2 : v);
             }
             U.swap(Uc);
