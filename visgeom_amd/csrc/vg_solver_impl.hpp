@@ -727,7 +727,8 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
     size_t dev_need = up_need + (4u << 20);
     for (int d = 0; d < n_ds; d++) {
         const size_t ww = (size_t)Wd[d] * Wd[d];
-        dev_need += 2 * sizeof(double) * ((size_t)p->dss[d].n_blocks * ww + 32) + sizeof(double) * ((size_t)p->dss[d].n_blocks / vg::kSlab + 2) * ww;
+        dev_need += 2 * sizeof(double) * ((size_t)p->dss[d].n_blocks * ww + 32) + sizeof(double) * ((size_t)p->dss[d].n_blocks / vg::kSlab + 2) * ww +
+                    sizeof(double) * ((size_t)p->dss[d].n_blocks / vg::kValuImagesPerBlock + 2) * ww;  // slab / per-workgroup partial sums
     }
     dev_need += sizeof(double) * (3 * (size_t)n_params + (size_t)n_poses * vg::kPoseRec + (size_t)n_rows * C + ((size_t)n_groups + n_slabs + 8) * C * C +
                                   (size_t)n_poses + 8 * (size_t)C * C);
