@@ -192,3 +192,42 @@ def test_all_gram_blocks_in_one_launch_equal_the_per_dataset_entry(vg, n):
         for k, (a, b) in enumerate(zip(ref, got)):
             assert torch.equal(a, b), "dataset %d, forced frames %s" % (k, forced)
     p.close()
+
+
+def test_merged_gram_launch_with_datasets_it_cannot_take(vg):
+    """vg_problem_gram_fused on a problem whose datasets do NOT all fit the merged launch: a 96-point EUCM set [D], a
+    7-point UCM set [D] (boards of at most 32 points keep their own one-corner-per-lane launch) and a 96-point Mei set
+    [I, D].  Two go together, one goes alone, the results are those of three vg_dataset_gram_fused calls; the solver
+    (which then cannot use the merged partial sums) still reaches a stationary point with a lower cost."""
+    import torch
+
+    from visgeom_amd import synthetic as S
+
+    n = 21
+    r = S.make_rig(n, sigma=0.1)
+    rng = np.random.default_rng(5)
+    small_idx = rng.choice(96, 7, replace=False)
+    p = vg.CalibrationProblem(0)
+    cams = [p.add_camera(r["models"][k], r["init_intrinsics"][k]) for k in (1, 0, 3)]      # EUCM, UCM, Mei
+    x13 = p.add_transform(True, r["init_xi1k"][2])
+    seq = p.add_transform(False, r["init_poses"])
+    # camera 0 of the rig is the UCM one with the identity mount: chains [D]; the EUCM camera is given chain [D] on its own
+    # sequence so that all three datasets are valid problems of their own
+    seq2 = p.add_transform(False, r["init_poses"])
+    dss = [p.add_dataset(cams[0], [(seq2, 0)], r["board"], r["corners"][0]),
+           p.add_dataset(cams[1], [(seq, 0)], r["board"][small_idx], r["corners"][0][:, small_idx]),
+           p.add_dataset(cams[2], [(x13, 1), (seq, 0)], r["board"], r["corners"][3])]
+    p.finalize()
+    ref = [p.alloc_gram(ds)[0] for ds in dss]
+    got = [torch.full_like(g, float("nan")) for g in ref]
+    p.prepare()
+    for ds, g in zip(dss, ref):
+        p.gram_fused(ds, g)
+    p.prepare()
+    p.gram_fused_all(got)
+    p.synchronize()
+    for k, (a, b) in enumerate(zip(ref, got)):
+        assert torch.equal(a, b), "dataset %d" % k
+    s = p.solve(max_num_iterations=100)
+    assert s["termination"].startswith("CONVERGENCE") and s["final_cost"] < s["initial_cost"]
+    p.close()

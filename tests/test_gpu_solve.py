@@ -818,3 +818,49 @@ def test_cached_solver_blocks_are_reused_and_released(vg):
     assert s3["termination"].startswith("CONVERGENCE")
     lib.vg_release_cached_memory()
     lib.vg_release_cached_memory()          # idempotent
+
+
+def test_soft_l1_loss_on_a_stereo_pair(vg):
+    """The robust loss on a problem with SEVERAL datasets (the merged Gram launch, then the per-dataset re-weighting, then
+    the slab sums -- the partial-sum shortcut must stay off): stereo pair, both cameras' intrinsics and the stereo
+    transform free, poses constant, one image of camera 2 shifted by 20 px; against scipy's minimum of sum_b rho(|r_b|^2)
+    over the oracle's residuals."""
+    from scipy.optimize import least_squares
+
+    from visgeom_amd import synthetic as S
+
+    n, a = 10, 1.5
+    st = S.make_stereo(n, sigma=0.1)
+    c2 = st["corners2"].copy()
+    c2[3] += np.array([20.0, 12.0])
+    K = 6
+    x0 = np.concatenate([st["init_intrinsics1"], st["init_intrinsics2"], st["init_xi12"], st["gt_poses"].ravel()])
+
+    def blocks(z):
+        x = x0.copy()
+        x[:18] = z
+        r1, _, _ = vgo.eval_dataset(0, [0], st["board"], st["corners1"], x, 0, [18], [6], np.arange(n), want_jac=False)
+        r2, _, _ = vgo.eval_dataset(0, [1, 0], st["board"], c2, x, K, [12, 18], [0, 6], np.arange(n), want_jac=False)
+        return np.concatenate([r1.reshape(n, -1), r2.reshape(n, -1)])
+
+    def robust(z):
+        r = blocks(z)
+        s = np.sum(r * r, axis=1)
+        rho = 2 * a * a * (np.sqrt(1 + s / (a * a)) - 1)
+        return (r * np.sqrt(rho / s)[:, None]).ravel()
+
+    ref = least_squares(robust, x0[:18], jac="3-point", x_scale="jac", xtol=1e-15, ftol=1e-15, gtol=1e-15, max_nfev=4000)
+    p = vg.CalibrationProblem(0)
+    cam1 = p.add_camera("eucm", st["init_intrinsics1"])
+    cam2 = p.add_camera("eucm", st["init_intrinsics2"])
+    x12 = p.add_transform(True, st["init_xi12"])
+    seq = p.add_transform(False, st["gt_poses"], constant=True)
+    p.add_dataset(cam1, [(seq, 0)], st["board"], st["corners1"])
+    p.add_dataset(cam2, [(x12, 1), (seq, 0)], st["board"], c2)
+    p.finalize()
+    summ = p.solve(max_num_iterations=400, use_bounds=0, soft_l1_scale=a)
+    z = p.get_parameters()[:18]
+    p.close()
+    print("soft-l1 stereo", summ["termination"], summ["num_iterations"], "cost %.8e scipy %.8e" % (summ["final_cost"], ref.cost))
+    assert abs(summ["final_cost"] - ref.cost) <= 1e-8 * ref.cost
+    assert rel(z[:12], ref.x[:12]) < 1e-5 and np.max(np.abs(z[12:] - ref.x[12:])) < 1e-6
