@@ -864,3 +864,38 @@ def test_soft_l1_loss_on_a_stereo_pair(vg):
     print("soft-l1 stereo", summ["termination"], summ["num_iterations"], "cost %.8e scipy %.8e" % (summ["final_cost"], ref.cost))
     assert abs(summ["final_cost"] - ref.cost) <= 1e-8 * ref.cost
     assert rel(z[:12], ref.x[:12]) < 1e-5 and np.max(np.abs(z[12:] - ref.x[12:])) < 1e-6
+
+
+@pytest.mark.parametrize("model", ["eucm", "mei"])
+def test_iteration_limits_of_the_device_resident_loop(vg, model):
+    """max_num_iterations = 0, 1, 2, 3 ... on the device-resident loop, which queues iteration k + 1 before it knows the
+    outcome of iteration k: the limit must hold exactly (no queued iteration may slip in), the cost must be the one a longer
+    run shows after the same number of iterations, and a run stopped by the limit can be continued to the same optimum."""
+    from visgeom_amd import synthetic as S
+
+    d = S.make_mono(model, 64, 2, sigma=0.1)
+    x_start = None
+    costs = []
+    for k in range(0, 6):
+        p, cam, seq, ds = mono_problem(vg, d, model)
+        if x_start is None:
+            x_start = p.get_parameters()
+        s = p.solve(max_num_iterations=k)
+        x = p.get_parameters()
+        assert s["num_iterations"] == k, s
+        if k == 0:
+            assert np.array_equal(x, x_start) and s["final_cost"] == s["initial_cost"]
+        assert s["termination"] in ("NO_CONVERGENCE",) or k >= 3, s
+        costs.append(s["final_cost"])
+        if k == 3:   # continue from where the limit stopped it
+            s2 = p.solve(max_num_iterations=200)
+            x2 = p.get_parameters()
+            assert s2["termination"].startswith("CONVERGENCE") and abs(s2["initial_cost"] - s["final_cost"]) <= 1e-12 * s["final_cost"]
+        p.close()
+    assert all(b <= a for a, b in zip(costs, costs[1:])), costs
+    q, _, _, _ = mono_problem(vg, d, model)
+    sf = q.solve(max_num_iterations=200)
+    xf = q.get_parameters()
+    q.close()
+    assert abs(s2["final_cost"] - sf["final_cost"]) <= 1e-10 * sf["final_cost"]
+    assert np.max(np.abs(x2 - xf) / np.maximum(np.abs(xf), 1.0)) < 1e-7
