@@ -323,3 +323,54 @@ def test_wheeled_base_with_odometry_intrinsic_entry(gpu, tmp_path):
     with pytest.raises(Exception, match="has already been initialized"):
         c.addResiduals(str(tmp_path / "bad_twice.json"))
     c.close()
+
+
+def test_odometry_intrinsic_on_a_sequence_initialised_from_the_images(gpu, tmp_path):
+    """odometry_intrinsic with "init": false (unified_calibration.cpp:695-731 not taken): the grid data comes first and
+    initialises xiOdomBase from the images through the chain [xiBaseCam I, xiOdomBase I, xiOdomBoard D]; the OdometryCost
+    blocks are then added on the existing elements.  Same problem as the "init": true file, another starting point: the
+    same optimum.  A sequence shorter than the intervals need is refused (the reference would index past its end)."""
+    import json
+
+    from visgeom_amd import synthetic as S
+    from visgeom_amd.calibration import GenericCameraCalibration
+
+    n = 12
+    d = S.make_wheeled(n, sigma=0.1)
+    path = S.write_wheeled_json(str(tmp_path), d, name="a")
+    ca = GenericCameraCalibration()
+    ca.addResiduals(path)
+    ca.compute(max_num_iterations=300)
+    wheels_a, cost_a = ca.intrinsics("xiOdomBase").copy(), ca.summary["final_cost"]
+    ca.close()
+
+    root = json.load(open(path))
+    odo, grid = root["data"]
+    # the hand-eye and board transforms at their generating values: the image-based initialisation peels them off the
+    # camera-frame pose (getInitTransform :311-348), so it is only as good as they are
+    for t in root["transformations"]:
+        if t["name"] == "xiBaseCam":
+            t["value"] = d["gt_xi_base_cam"].tolist()
+        if t["name"] == "xiOdomBoard":
+            t["value"] = d["gt_xi_odom_board"].tolist()
+    root["data"] = [dict(grid, init="xiOdomBase"), dict(odo, init=False)]
+    json.dump(root, open(tmp_path / "b.json", "w"))
+    cb = GenericCameraCalibration()
+    cb.addResiduals(str(tmp_path / "b.json"))
+    seq0 = cb.transform("xiOdomBase")
+    assert seq0.shape == (n, 6) and np.max(np.abs(seq0 - d["gt_base"])) < 0.05      # initialised from the images
+    cb.compute(max_num_iterations=300)
+    print("wheels init:true", wheels_a, "init:false", cb.intrinsics("xiOdomBase"), "cost %.8e %.8e" % (cost_a, cb.summary["final_cost"]))
+    assert abs(cb.summary["final_cost"] - cost_a) <= 1e-6 * cost_a
+    assert rel(cb.intrinsics("xiOdomBase"), wheels_a) < 1e-4
+    cb.close()
+
+    short = dict(root, data=[dict(grid, init="xiOdomBase"), dict(odo, init=False)])
+    frames = json.load(open(tmp_path / short["data"][0]["data_file"]))
+    json.dump(frames[:n - 3], open(tmp_path / "short_corners.json", "w"))
+    short["data"][0] = dict(short["data"][0], data_file="short_corners.json")
+    json.dump(short, open(tmp_path / "c.json", "w"))
+    cc = GenericCameraCalibration()
+    with pytest.raises(Exception, match="fewer elements than the odometry intervals need"):
+        cc.addResiduals(str(tmp_path / "c.json"))
+    cc.close()
