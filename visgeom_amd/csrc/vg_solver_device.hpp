@@ -242,27 +242,36 @@ __global__ __launch_bounds__(kLmThreads) void vg_lm_accept_kernel(LmAcceptArgs a
     }
     __syncthreads();
     if (tid != 0) return;
+    // The scalar logic runs on a LOCAL copy of the state: read once (together with the two counters), written back once.
+    // Through the pointer every read after a write had to be a fresh global load (the compiler cannot rule out aliasing
+    // with the counters): half a dozen dependent memory round trips in a one-thread section.
+    LmState S = *st;
+    const int n_bad = *a.bad;
+    const unsigned long long gmax_bits = *a.gmax_bits;
     double cost2_c = 0.;
-    for (int d = 0; d < a.n_ds; d++) cost2_c += a.sums[d * WW + (size_t)a.Wd[d] * a.Wd[d] - 1];
+    for (int d = 0; d < a.n_ds; d++) cost2_c += sums[d * WW + (size_t)a.Wd[d] * a.Wd[d] - 1];
+    auto publish = [&]() {
+        *st = S;
+        if (a.host_state) *a.host_state = S;
+    };
     if (a.init) {
-        st->cost2 = cost2_c;
-        st->cost2_init = cost2_c;
-        st->mu = 1. / st->radius;
-        st->gate = st->ucur;
-        if (a.host_state) *a.host_state = *st;
+        S.cost2 = cost2_c;
+        S.cost2_init = cost2_c;
+        S.mu = 1. / S.radius;
+        S.gate = S.ucur;
+        publish();
         return;
     }
-    st->cost2_c = cost2_c;
+    S.cost2_c = cost2_c;
     const double *sc = a.scal_partials ? s_sc : a.sums + (size_t)a.n_ds * WW;
-    const int n_bad = *a.bad;
     *a.bad = 0;
-    double gmax_p = __longlong_as_double((long long)*a.gmax_bits);
+    double gmax_p = __longlong_as_double((long long)gmax_bits);
     *a.gmax_bits = 0ull;
-    st->n_bad += n_bad;
-    const bool step_ok = st->step_ok != 0 && n_bad == 0;
-    const double mu = st->mu;
+    S.n_bad += n_bad;
+    const bool step_ok = S.step_ok != 0 && n_bad == 0;
+    const double mu = S.mu;
     double rho = 0., step2 = 0., cost_change = 0., model_change = 0.;
-    st->iter++;
+    S.iter++;
     if (step_ok) {
         double xg2 = 0.;
         for (int k = 0; k < G; k++) xg2 += s_x[k] * s_x[k];
@@ -282,56 +291,56 @@ __global__ __launch_bounds__(kLmThreads) void vg_lm_accept_kernel(LmAcceptArgs a
             const double xp = clampd(xv - s_g[k], s_lo[k], s_hi[k]);
             gmax_g = fmax(gmax_g, fabs(xp - xv));
         }
-        st->grad_max = fmax(gmax_g, gmax_p);
+        S.grad_max = fmax(gmax_g, gmax_p);
         model_change = 0.5 * (mu * (ddg + ddp) - (gdg + gdp));  // 1/2 delta^T (mu D delta - g)
         step2 = dg2 + dp2;
-        cost_change = 0.5 * (st->cost2 - cost2_c);
+        cost_change = 0.5 * (S.cost2 - cost2_c);
         rho = model_change > 0. ? cost_change / model_change : -1.;
-        if (st->grad_max <= a.gtol) {
-            st->term = VG_TERM_CONVERGENCE_GRADIENT;
-            st->done = 1;
+        if (S.grad_max <= a.gtol) {
+            S.term = VG_TERM_CONVERGENCE_GRADIENT;
+            S.done = 1;
         } else if (sqrt(step2) <= a.ptol * (sqrt(xg2 + xp2) + a.ptol)) {
-            st->term = VG_TERM_CONVERGENCE_PARAMETER;
-            st->done = 1;
+            S.term = VG_TERM_CONVERGENCE_PARAMETER;
+            S.done = 1;
         }
     }
-    st->rho = rho;
-    st->step_norm = sqrt(step2);
-    st->cost_change = cost_change;
-    st->model_change = model_change;
-    st->accepted = 0;
-    if (st->done) {
-        st->gate = -1;
-        if (a.host_state) *a.host_state = *st;
+    S.rho = rho;
+    S.step_norm = sqrt(step2);
+    S.cost_change = cost_change;
+    S.model_change = model_change;
+    S.accepted = 0;
+    if (S.done) {
+        S.gate = -1;
+        publish();
         return;
     }
     const bool success = step_ok && isfinite(cost2_c) && rho > a.min_rel_decrease;
     if (success) {
-        st->n_success++;
-        st->accepted = 1;
-        st->ucur = 1 - st->ucur;
+        S.n_success++;
+        S.accepted = 1;
+        S.ucur = 1 - S.ucur;
         for (int k = 0; k < G; k++) a.xcur[k] = clampd(s_x[k] + s_dg[k], s_lo[k], s_hi[k]);  // what the step kernel wrote
-        const double prev = st->cost2;
-        st->cost2 = cost2_c;
+        const double prev = S.cost2;
+        S.cost2 = cost2_c;
         const double t = 2. * rho - 1.;
         const double f = 1. - t * t * t;
-        st->radius = fmin(st->radius / fmax(f, 1. / 3.), a.max_radius);
-        st->decrease_factor = 2.;
+        S.radius = fmin(S.radius / fmax(f, 1. / 3.), a.max_radius);
+        S.decrease_factor = 2.;
         if (fabs(prev - cost2_c) <= a.ftol * prev) {
-            st->term = VG_TERM_CONVERGENCE_FUNCTION;
-            st->done = 1;
+            S.term = VG_TERM_CONVERGENCE_FUNCTION;
+            S.done = 1;
         }
     } else {
-        st->radius /= st->decrease_factor;
-        st->decrease_factor *= 2.;
-        if (st->radius < a.min_radius) {
-            st->term = VG_TERM_RADIUS_TOO_SMALL;
-            st->done = 1;
+        S.radius /= S.decrease_factor;
+        S.decrease_factor *= 2.;
+        if (S.radius < a.min_radius) {
+            S.term = VG_TERM_RADIUS_TOO_SMALL;
+            S.done = 1;
         }
     }
-    st->mu = 1. / st->radius;
-    st->gate = st->done ? -1 : st->ucur;
-    if (a.host_state) *a.host_state = *st;
+    S.mu = 1. / S.radius;
+    S.gate = S.done ? -1 : S.ucur;
+    publish();
 }
 
 }  // namespace vg
