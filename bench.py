@@ -181,12 +181,15 @@ def main():
             except Exception as e:  # noqa: BLE001
                 box["error"] = repr(e)
 
+        # the agreement runs over a gloo side group on HOST tensors: every rank takes it unconditionally, also one whose
+        # helper thread is still inside ncclCommInitRank (that thread is abandoned; a device collective next to it could
+        # not be matched, a host one can)
+        side = dist.new_group(backend="gloo")
         th = threading.Thread(target=_make, daemon=True)
         th.start()
         th.join(float(os.environ.get("VG_BENCH_COMM_TIMEOUT", "120")))
-        ok = torch.tensor([1 if "comm" in box else 0], device="cuda:%d" % local_rank, dtype=torch.int32)
-        if not th.is_alive():  # a rank still inside ncclCommInitRank cannot take part in another collective
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        ok = torch.tensor([1 if ("comm" in box and not th.is_alive()) else 0], dtype=torch.int32)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=side)
         if int(ok.item()) == 1 and "comm" in box:
             comm = box["comm"]
             if rank == 0:

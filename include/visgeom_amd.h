@@ -102,14 +102,22 @@ void vg_block_destroy(vg_block *b);
  *                          every variable parameter block of a pass is state + offset): a new pass is the previous
  *                          one displaced by the displacement of the calling block's pointers; blocks whose pointers
  *                          never move (constant parameter blocks) are read in place.  The host guarantees that the
- *                          displaced addresses are readable (they are inside the state array by construction).
- * Pointers passed to vg_block_evaluate must stay readable until the block is called again.  Not thread safe. */
+ *                          A displaced address is only read when it lies inside memory the host has PASSED to some
+ *                          block of the group before (the group keeps the address ranges it has been shown; the blocks of
+ *                          one state array coalesce into one range), so a new state array costs one block-by-block pass
+ *                          before it is batched, and pointer arithmetic never leaves memory the host has shown.
+ * Pointers passed to vg_block_evaluate must stay readable until the block is called again OR the group is invalidated:
+ * call vg_block_group_invalidate when that memory goes away -- in the drop-in, right after ceres::Solve returns (its state
+ * arrays are freed) and before the report's Problem::Evaluate / Evaluate calls on user memory.  Not thread safe. */
 typedef struct vg_block_group vg_block_group;
 enum vg_group_mode { VG_GROUP_IN_PLACE = 0, VG_GROUP_STATE_VECTOR = 1 };
 int vg_block_group_create(vg_block_group **out, int device, int mode);
 /* vg_block_create with membership; blocks may be added at any time (the group re-learns its layout) */
 int vg_block_create_in_group(vg_block **out, vg_block_group *g, int model, int chain_len, const int *status, int n_points,
                              const double *grid /*3N host*/, const double *obs /*2N host*/);
+/* Forget where parameters live (bound pointers, shown address ranges, which pointers move): every block evaluates alone
+ * once more and is bound again before the next pass.  The resident problem (which blocks form a dataset) is kept. */
+int vg_block_group_invalidate(vg_block_group *g);
 /* counters since creation: passes over the whole group / calls answered from a pass / calls evaluated alone */
 int vg_block_group_stats(const vg_block_group *g, int64_t *n_blocks, int64_t *batched_evaluations, int64_t *served, int64_t *alone);
 /* destroy the group after (or before) its blocks; surviving blocks continue on the per-block path */
@@ -302,6 +310,13 @@ int vg_comm_adopt(vg_comm **out, void *nccl_comm, int device);
  * (packed collectives, summable convergence tests, identical branches on every rank): the result must be the one-rank
  * solution with the cost multiplied by `replicas`. */
 int vg_comm_create_replicated(vg_comm **out, int replicas, int device);
+/* n_ranks communicators for n_ranks host THREADS of this process that drive ONE device, each with its own problem, stream
+ * and shard (out: array of n_ranks handles, handle r is rank r; every handle is destroyed by its user).  No RCCL behind it:
+ * a collective parks every rank's buffer in a device slot, meets at a host barrier and adds the slots in rank order.  It is a
+ * test transport: it runs the solver's real multi-rank data flow -- different shards, ranks without images, the in-place
+ * collectives -- on a one-GPU box, which vg_comm_create_replicated (identical shards) cannot.  A rank that fails or does
+ * not arrive within 120 s breaks the group: every pending and later collective returns VG_ERR_STATE. */
+int vg_comm_create_local(vg_comm **out /* [n_ranks] */, int n_ranks, int device);
 int vg_comm_size(const vg_comm *c);
 int vg_comm_rank(const vg_comm *c);
 /* in-place sum of n doubles at device_buf over all ranks (ncclAllReduce, ncclDouble, ncclSum), enqueued on hip_stream */

@@ -89,6 +89,53 @@ def test_state_vector_host_is_served_from_one_pass_per_point(model):
     group.close()
 
 
+def test_an_array_the_group_was_never_shown_is_not_read_and_invalidate_forgets():
+    """a displaced address is formed by pointer arithmetic; it is only READ when it lies inside memory some
+    block has been called with.  A third state array therefore costs one block-by-block pass (each call shows its
+    addresses) before it is batched; vg_block_group_invalidate (the host calls it when ceres::Solve returns and its state
+    arrays are freed) voids everything the group knew about addresses."""
+    import visgeom_amd as vg
+
+    n = 21
+    d, host, group, blocks, plain, fill = make(vg, "eucm", n, "state_vector")
+    x, xpd = np.zeros(host.size), np.zeros(host.size)
+    fill(x, 0.0)
+    run_pass(host, x, blocks, plain)
+    fill(xpd, 1e-3)
+    run_pass(host, xpd, blocks, plain)
+    fill(x, 2e-3)
+    run_pass(host, x, blocks, plain)
+    assert group.stats() == {"blocks": n, "batched": 1, "served": n, "alone": 2 * n}
+    y = np.zeros(host.size)                                # a state array no block has ever been called with
+    fill(y, 3e-3)
+    run_pass(host, y, blocks, plain)                       # pass refused at its first call, every block alone
+    assert group.stats() == {"blocks": n, "batched": 1, "served": n, "alone": 3 * n}
+    fill(y, 4e-3)
+    run_pass(host, y, blocks, plain)                       # now y has been shown: one pass again
+    assert group.stats() == {"blocks": n, "batched": 2, "served": 2 * n, "alone": 3 * n}
+    # the solve is over: state arrays go away, the report evaluates on user memory (one array per block)
+    group.invalidate()
+    del x, xpd, y
+    user_intr = d["init_intrinsics"].copy()
+    user_poses = [d["init_poses"][i].copy() for i in range(n)]
+
+    def user_pass():
+        for i, (b, q) in enumerate(zip(blocks, plain)):
+            r, J = b.Evaluate([user_intr, user_poses[i]])
+            r0, J0 = q.Evaluate([user_intr.copy(), user_poses[i].copy()])
+            assert np.array_equal(r, r0) and np.array_equal(J[0], J0[0]) and np.array_equal(J[1], J0[1]), i
+
+    user_pass()
+    assert group.stats() == {"blocks": n, "batched": 2, "served": 2 * n, "alone": 4 * n}
+    user_intr *= 1.001                                     # a new point, evaluated in place
+    user_pass()
+    st = group.stats()
+    assert st["batched"] == 3 and st["alone"] == 4 * n and st["served"] == 3 * n
+    for b in blocks + plain:
+        b.close()
+    group.close()
+
+
 def test_constant_intrinsics_stay_in_user_memory():
     import visgeom_amd as vg
 

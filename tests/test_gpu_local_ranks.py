@@ -1,0 +1,190 @@
+"""The solver's multi-rank data flow with REAL, DIFFERENT shards on a one-GPU box: N host threads, each with its own
+problem, stream and image range, joined by an in-process communicator (vg_comm_create_local: device slots + host barrier,
+slots added in rank order).  What a replicated communicator cannot show -- ranks without images, a dataset that is empty
+on one rank only, a failed pose block on one rank -- runs here through the same in-place device collectives an RCCL
+communicator gets (vg_solver_impl.hpp: one all-reduce of [summed Gram blocks | step scalars] per evaluation, one of
+[Schur Gram | bad-pose count] per linear solve).  The result must be the single-problem solve."""
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def vg():
+    import torch
+
+    assert torch.cuda.is_available()
+    import visgeom_amd
+
+    return visgeom_amd
+
+
+def rel(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return np.max(np.abs(a - b) / np.maximum(np.abs(b), 1.0))
+
+
+def run_ranks(builders, **opts):
+    """builders[r]() -> CalibrationProblem of rank r (built inside the rank's thread, on the rank's stream)"""
+    import torch
+
+    from visgeom_amd import distributed as D
+
+    n = len(builders)
+    comms = D.Comm.local_group(n)
+    out, err = [None] * n, [None] * n
+
+    def worker(r):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                q = builders[r]()
+                s = q.solve(comm=comms[r], **opts)
+                out[r] = (s, q.get_parameters())
+                q.close()
+        except Exception as e:  # noqa: BLE001 -- reported by the main thread
+            err[r] = e
+        finally:
+            comms[r].close()   # a rank that leaves breaks the group instead of leaving the others waiting
+
+    th = [threading.Thread(target=worker, args=(r,)) for r in range(n)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=600)
+    assert not any(t.is_alive() for t in th), "a rank hangs"
+    assert all(e is None for e in err), err
+    return out
+
+
+def mono(vg, d, model, lo, hi):
+    def build():
+        p = vg.CalibrationProblem(0)
+        cam = p.add_camera(model, d["init_intrinsics"])
+        seq = p.add_transform(False, d["init_poses"][lo:hi])
+        p.add_dataset(cam, [(seq, 0)], d["board"], d["corners"][lo:hi])
+        p.finalize()
+        return p
+    return build
+
+
+@pytest.mark.parametrize("model,cuts", [("eucm", (0, 70, 120, 120)), ("eucm", (0, 0, 50, 120)), ("mei", (0, 33, 90))])
+def test_unequal_and_empty_mono_shards_equal_one_problem(vg, model, cuts):
+    """device-resident loop (G <= 32).  cuts with a repeated value = a rank WITHOUT images: it has no poses and no
+    back-substitution workgroups, so it rewrites neither the scalar tail of the packed sums nor the Schur Gram -- both
+    hold cross-rank totals after the first in-place collective and must be cleared by that rank every iteration."""
+    from visgeom_amd import synthetic as S
+
+    n = cuts[-1]
+    d = S.make_mono(model, n, 2, sigma=0.1)
+    p = mono(vg, d, model, 0, n)()
+    s_ref = p.solve(max_num_iterations=200)
+    x_ref = p.get_parameters()
+    p.close()
+    K = d["init_intrinsics"].size
+    res = run_ranks([mono(vg, d, model, cuts[r], cuts[r + 1]) for r in range(len(cuts) - 1)], max_num_iterations=200)
+    s0, x0 = res[0]
+    assert s_ref["termination"].startswith("CONVERGENCE")
+    for s, x in res:
+        assert s["termination"] == s0["termination"] and s["num_iterations"] == s0["num_iterations"], (s, s0)
+        assert s["termination"].startswith("CONVERGENCE")
+        assert np.array_equal(x[:K], x0[:K])                     # the replicated global block stays bit-identical
+        assert s["final_cost"] == s0["final_cost"]
+        assert abs(s["final_cost"] - s_ref["final_cost"]) <= 1e-9 * s_ref["final_cost"]
+        assert abs(s["initial_cost"] - s_ref["initial_cost"]) <= 1e-12 * s_ref["initial_cost"]
+    assert rel(x0[:K], x_ref[:K]) < 1e-6
+    poses = np.concatenate([x[K:] for _, x in res])
+    assert np.max(np.abs(poses - x_ref[K:])) < 1e-6
+
+
+def test_a_dataset_that_is_empty_on_one_rank(vg):
+    """stereo, two ranks: rank 1 holds frames in which only camera 1 saw the board, so its second dataset has no blocks
+    while rank 0's has -- the slot of that dataset in rank 1's packed sums must not keep the previous total"""
+    from visgeom_amd import synthetic as S
+
+    n, cut = 30, 18
+    st = S.make_stereo(n, sigma=0.1)
+
+    def stereo(lo, hi, hi2):
+        def build():
+            p = vg.CalibrationProblem(0)
+            c1 = p.add_camera("eucm", st["init_intrinsics1"])
+            c2 = p.add_camera("eucm", st["init_intrinsics2"])
+            x12 = p.add_transform(True, st["init_xi12"])
+            seq = p.add_transform(False, st["init_poses"][lo:hi])
+            p.add_dataset(c1, [(seq, 0)], st["board"], st["corners1"][lo:hi])
+            p.add_dataset(c2, [(x12, 1), (seq, 0)], st["board"], st["corners2"][lo:hi2],
+                          image_index=np.arange(hi2 - lo, dtype=np.int32))
+            p.finalize()
+            return p
+        return build
+
+    p = stereo(0, n, cut)()
+    s_ref = p.solve(max_num_iterations=200)
+    x_ref = p.get_parameters()
+    p.close()
+    res = run_ranks([stereo(0, cut, cut), stereo(cut, n, cut)], max_num_iterations=200)
+    (s0, x0), (s1, x1) = res
+    assert s0["termination"] == s1["termination"] and s0["num_iterations"] == s1["num_iterations"]
+    assert s0["termination"].startswith("CONVERGENCE") and s_ref["termination"].startswith("CONVERGENCE")
+    assert np.array_equal(x0[:18], x1[:18])
+    assert abs(s0["final_cost"] - s_ref["final_cost"]) <= 1e-9 * s_ref["final_cost"]
+    assert rel(x0[:18], x_ref[:18]) < 1e-6
+    assert np.max(np.abs(np.concatenate([x0[18:], x1[18:]]) - x_ref[18:])) < 1e-6
+
+
+def test_rig_on_three_ranks_one_of_them_empty(vg):
+    """45 global columns: the wide reduced system, three ranks with 13 / 0 / 12 frames"""
+    from visgeom_amd import synthetic as S
+
+    r = S.make_rig(25, sigma=0.1)
+
+    def rig(lo, hi):
+        def build():
+            p = vg.CalibrationProblem(0)
+            cams = [p.add_camera(m, r["init_intrinsics"][k]) for k, m in enumerate(r["models"])]
+            x1k = [p.add_transform(True, r["init_xi1k"][k]) for k in range(3)]
+            seq = p.add_transform(False, r["init_poses"][lo:hi])
+            p.add_dataset(cams[0], [(seq, 0)], r["board"], r["corners"][0][lo:hi])
+            for k in range(3):
+                p.add_dataset(cams[k + 1], [(x1k[k], 1), (seq, 0)], r["board"], r["corners"][k + 1][lo:hi])
+            p.finalize()
+            return p
+        return build
+
+    p = rig(0, 25)()
+    s_ref = p.solve(max_num_iterations=300)
+    x_ref = p.get_parameters()
+    p.close()
+    res = run_ranks([rig(0, 13), rig(13, 13), rig(13, 25)], max_num_iterations=300)
+    G = 45
+    s0, x0 = res[0]
+    for s, x in res:
+        assert s["termination"] == s0["termination"] and s["num_iterations"] == s0["num_iterations"]
+        assert s["termination"].startswith("CONVERGENCE")
+        assert np.array_equal(x[:G], x0[:G])
+    assert abs(s0["final_cost"] - s_ref["final_cost"]) <= 1e-9 * s_ref["final_cost"]
+    assert rel(x0[:G], x_ref[:G]) < 1e-6
+    assert np.max(np.abs(np.concatenate([x[G:] for _, x in res]) - x_ref[G:])) < 1e-6
+
+
+@pytest.mark.parametrize("model", ["eucm", "ucm"])
+def test_a_failed_pose_block_on_one_rank_is_seen_by_all(vg, model):
+    """NaN observations in one image of rank 1: its damped 6 x 6 block is not positive definite.  The count travels with
+    the Schur Gram's all-reduce, so both ranks reject the step together (a rank-local decision would make rank 1 skip the
+    collectives of the candidate evaluation: a hang) and both report the same termination and the same count."""
+    from visgeom_amd import synthetic as S
+
+    d = S.make_mono(model, 40, 2, sigma=0.1)
+    d = dict(d)
+    d["corners"] = d["corners"].copy()
+    d["corners"][31, 5] = np.nan
+    res = run_ranks([mono(vg, d, model, 0, 20), mono(vg, d, model, 20, 40)], max_num_iterations=25)
+    (s0, x0), (s1, x1) = res
+    assert s0["termination"] == s1["termination"] and s0["num_iterations"] == s1["num_iterations"]
+    assert s0["num_successful_steps"] == 0 and s1["num_successful_steps"] == 0
+    assert "not positive definite" in s0["message"] and s0["message"] == s1["message"]
+    K = d["init_intrinsics"].size
+    assert np.array_equal(x0[:K], d["init_intrinsics"]) and np.array_equal(x1[:K], d["init_intrinsics"])

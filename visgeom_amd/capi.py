@@ -72,6 +72,7 @@ SIGNATURES = {
     "vg_block_destroy": (None, [_vp]),
     "vg_block_group_create": (ctypes.c_int, [_vpp, ctypes.c_int, ctypes.c_int]),
     "vg_block_create_in_group": (ctypes.c_int, [_vpp, _vp, ctypes.c_int, ctypes.c_int, _ip, ctypes.c_int, _dp, _dp]),
+    "vg_block_group_invalidate": (ctypes.c_int, [_vp]),
     "vg_block_group_stats": (ctypes.c_int, [_vp, _i64p, _i64p, _i64p, _i64p]),
     "vg_block_group_destroy": (None, [_vp]),
     "vg_problem_create": (ctypes.c_int, [_vpp, ctypes.c_int, _vp]),
@@ -122,6 +123,7 @@ SIGNATURES = {
     "vg_comm_create": (ctypes.c_int, [_vpp, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "vg_comm_adopt": (ctypes.c_int, [_vpp, _vp, ctypes.c_int]),
     "vg_comm_create_replicated": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int]),
+    "vg_comm_create_local": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int]),
     "vg_comm_size": (ctypes.c_int, [_vp]),
     "vg_comm_rank": (ctypes.c_int, [_vp]),
     "vg_comm_allreduce_sum": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, _vp]),

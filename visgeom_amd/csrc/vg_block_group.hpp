@@ -50,6 +50,12 @@ struct vg_block_group {
     uint64_t served_since_batch = 0;
     int64_t cooldown = 0;       // calls to answer block by block before the next pass is attempted
     uint64_t n_batched = 0, n_served = 0, n_alone = 0;  // statistics (vg_block_group_stats)
+    // VG_GROUP_STATE_VECTOR: the address ranges parameter blocks have actually been PASSED at (sorted, disjoint, touching
+    // ranges merged: the blocks of one state array coalesce into one range).  A displaced address is only ever read when
+    // it lies inside one of them -- the prediction "same layout, other array" is then about memory the host has shown to
+    // the group, not about arithmetic on a pointer.
+    std::vector<std::pair<uintptr_t, uintptr_t>> seen;
+    int n_stale = 0;            // after vg_block_group_invalidate: blocks not called again yet (no pass until 0)
 };
 
 namespace vgg {
@@ -132,14 +138,54 @@ inline int seal(vg_block_group *g)
     return VG_OK;
 }
 
-// where slot k of block j lives in the pass that block `caller` has just opened with `params`
+inline void seen_add(vg_block_group *g, const double *ptr, int len)
+{
+    const uintptr_t lo = reinterpret_cast<uintptr_t>(ptr), hi = lo + sizeof(double) * (size_t)len;
+    auto &v = g->seen;
+    auto it = std::upper_bound(v.begin(), v.end(), lo, [](uintptr_t a, const std::pair<uintptr_t, uintptr_t> &e) { return a < e.first; });
+    if (it != v.begin() && (it - 1)->second >= lo) {  // overlaps or touches its predecessor
+        --it;
+        if (it->second >= hi) return;                 // already inside (the common case once a state array is known)
+        it->second = hi;
+    } else {
+        it = v.insert(it, std::make_pair(lo, hi));
+    }
+    auto nx = it + 1;
+    while (nx != v.end() && nx->first <= it->second) {
+        if (nx->second > it->second) it->second = nx->second;
+        nx = v.erase(nx);
+    }
+}
+
+inline bool seen_contains(const vg_block_group *g, const double *ptr, int len)
+{
+    const uintptr_t lo = reinterpret_cast<uintptr_t>(ptr), hi = lo + sizeof(double) * (size_t)len;
+    const auto &v = g->seen;
+    auto it = std::upper_bound(v.begin(), v.end(), lo, [](uintptr_t a, const std::pair<uintptr_t, uintptr_t> &e) { return a < e.first; });
+    return it != v.begin() && (it - 1)->first <= lo && (it - 1)->second >= hi;
+}
+
+// every parameter pointer a state-vector host passes is remembered (see vg_block_group::seen)
+inline void observe(vg_block_group *g, const vg_block *b, double const *const *params)
+{
+    if (g->mode != VG_GROUP_STATE_VECTOR) return;
+    for (int k = 0; k <= b->L; k++) seen_add(g, params[k], k == 0 ? b->K : 6);
+}
+
+// where slot k of block j lives in the pass that block `caller` has just opened with `params`; NULL when the prediction
+// would be a displaced address the host has never passed (the pass is then not attempted)
 inline const double *predict(const vg_block_group *g, const vg_block *j, int k, const vg_block *caller, double const *const *params)
 {
     for (int q = 0; q <= caller->L; q++)
         if (caller->bound[q] == j->bound[k]) return params[q];  // the same parameter block as one of the caller's
     if (g->mode == VG_GROUP_STATE_VECTOR && j->moves[k]) {
         for (int q = 0; q <= caller->L; q++)
-            if (caller->moves[q] && params[q] != caller->bound[q]) return j->bound[k] + (params[q] - caller->bound[q]);
+            if (caller->moves[q] && params[q] != caller->bound[q]) {
+                // pointer difference through integers: the two pointers belong to different arrays
+                const uintptr_t a = reinterpret_cast<uintptr_t>(j->bound[k]) + (reinterpret_cast<uintptr_t>(params[q]) - reinterpret_cast<uintptr_t>(caller->bound[q]));
+                const double *cand = reinterpret_cast<const double *>(a);
+                return seen_contains(g, cand, k == 0 ? j->K : 6) ? cand : nullptr;
+            }
     }
     return j->bound[k];
 }
@@ -149,11 +195,26 @@ inline int evaluate_all(vg_block_group *g, const vg_block *caller, double const 
 {
     VG_HIP(hipSetDevice(g->device));
     vg_problem *p = g->p;
+    // every address is decided before the first one is read: one block whose parameters would have to be fetched from
+    // memory the host never showed cancels the pass (the caller evaluates alone, the group cools down)
+    std::vector<const double *> srcs;
+    srcs.reserve(g->blocks.size() * 2);
+    for (auto &d : g->dss)
+        for (vg_block *j : d.members)
+            for (int k = 0; k <= d.L; k++) {
+                const double *src = predict(g, j, k, caller, params);
+                if (!src) {
+                    g->cooldown = (int64_t)g->blocks.size() - 1;  // the rest of this pass block by block (each call shows
+                    return VG_OK;                                  // its addresses), the next point is tried again
+                }
+                srcs.push_back(src);
+            }
+    size_t si = 0;
     for (auto &d : g->dss) {
         for (size_t i = 0; i < d.members.size(); i++) {
             vg_block *j = d.members[i];
             for (int k = 0; k <= d.L; k++) {
-                const double *src = predict(g, j, k, caller, params);
+                const double *src = srcs[si++];
                 const int len = k == 0 ? d.K : 6;
                 double *used = j->used.data() + (k == 0 ? 0 : d.K + 6 * (k - 1));
                 std::memcpy(used, src, sizeof(double) * len);

@@ -1234,6 +1234,25 @@ int vg_block_group_stats(const vg_block_group *g, int64_t *n_blocks, int64_t *ba
     return VG_OK;
 }
 
+int vg_block_group_invalidate(vg_block_group *g)
+{
+    if (!g) return fail(VG_ERR_INVALID_ARGUMENT, "group is NULL");
+    g->seen.clear();
+    g->n_known = 0;
+    g->n_stale = 0;
+    g->cooldown = 0;
+    for (vg_block *b : g->blocks) {
+        b->used_valid = false;
+        b->calls = 0;
+        for (int k = 0; k <= b->L; k++) b->moves[k] = false;
+        if (b->is_bound) {
+            b->stale = true;
+            g->n_stale++;
+        }
+    }
+    return VG_OK;
+}
+
 void vg_block_group_destroy(vg_block_group *g)
 {
     if (!g) return;
@@ -1261,6 +1280,19 @@ int vg_block_evaluate(vg_block *b, double const *const *parameters, double *resi
     if (jacobians)
         for (int i = 0; i <= b->L; i++) want_jac = want_jac || jacobians[i] != nullptr;
     int rc;
+    vgg::observe(g, b, parameters);
+    if (g->sealed && g->n_stale > 0) {
+        // after vg_block_group_invalidate: what the group knew about where parameters live is void; every block
+        // evaluates alone once and is bound again before the next pass
+        if ((rc = block_evaluate_alone(b, parameters, residuals, jacobians)) != VG_OK) return rc;
+        g->n_alone++;
+        vgg::bind(g, b, parameters);
+        if (b->stale) {
+            b->stale = false;
+            g->n_stale--;
+        }
+        return VG_OK;
+    }
     if (!g->sealed) {
         // first pass: every block is seen once on its own and bound to the pointers it was called with
         if ((rc = block_evaluate_alone(b, parameters, residuals, jacobians)) != VG_OK) return rc;
@@ -1300,6 +1332,7 @@ void vg_block_destroy(vg_block *b)
         g->blocks.erase(std::remove(g->blocks.begin(), g->blocks.end(), b), g->blocks.end());
         if (b->is_bound && g->n_bound > 0) g->n_bound--;
         if (b->calls >= 2 && g->n_known > 0) g->n_known--;
+        if (b->stale && g->n_stale > 0) g->n_stale--;
     }
     (void)hipSetDevice(b->device);
     if (b->d_out) (void)hipFree(b->d_out);

@@ -11,15 +11,51 @@
 
 #include <dlfcn.h>
 
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
+
 #include <rccl/rccl.h>  // types and prototypes only; every call goes through the table below
 
 #include "vg_internal.hpp"
+
+namespace vgc {
+// The ranks of an in-process communicator (vg_comm_create_local): N host threads of ONE process driving ONE device, each
+// with its own problem, stream and shard.  A collective is: every rank parks its buffer in its slot, all meet at a host
+// barrier, every rank adds the slots in rank order (the same fixed order everywhere: identical totals bit for bit).
+struct LocalGroup {
+    int n = 0, device = 0, refs = 0;
+    size_t cap = 0;            // doubles per slot
+    double *slots = nullptr;   // device [n][cap]
+    std::mutex m;
+    std::condition_variable cv;
+    int arrived = 0;
+    unsigned long long generation = 0;
+    bool broken = false;       // a rank failed or timed out: every later collective fails instead of hanging
+    bool barrier()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        if (broken) return false;
+        const unsigned long long gen = generation;
+        if (++arrived == n) {
+            arrived = 0;
+            generation++;
+            cv.notify_all();
+            return true;
+        }
+        if (!cv.wait_for(lk, std::chrono::seconds(120), [&] { return generation != gen || broken; })) broken = true;
+        if (broken) cv.notify_all();
+        return !broken;
+    }
+};
+}  // namespace vgc
 
 struct vg_comm {
     ncclComm_t comm = nullptr;
     int n_ranks = 1, rank = 0, device = 0;
     bool owned = true;  // created here (destroyed here) or adopted from the host
     int replicas = 0;   // > 0: no RCCL behind it -- this rank stands for `replicas` ranks holding identical shards
+    vgc::LocalGroup *local = nullptr;  // in-process ranks (threads) on one device, no RCCL behind it
 };
 
 namespace vgc {
@@ -88,10 +124,32 @@ __global__ void vg_scale_in_place_kernel(double *buf, size_t n, double f)
     if (i < n) buf[i] *= f;
 }
 
+__global__ void vg_local_sum_slots_kernel(const double *slots, size_t cap, int n_ranks, double *buf, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.;
+    for (int r = 0; r < n_ranks; r++) s += slots[(size_t)r * cap + i];
+    buf[i] = s;
+}
+
 // in-place sum over the ranks of c, enqueued on `stream`; a NULL or one-rank communicator is the identity
 inline int allreduce_sum(const vg_comm *c, double *device_buf, size_t n, hipStream_t stream)
 {
     if (!c || c->n_ranks <= 1 || !n) return VG_OK;
+    if (c->local) {  // in-process ranks: host-synchronous (a test transport, not a fast one)
+        LocalGroup *g = c->local;
+        if (n > g->cap) return vgi::fail(VG_ERR_INVALID_ARGUMENT, "message larger than the local communicator's slots");
+        VG_HIP(hipMemcpyAsync(g->slots + (size_t)c->rank * g->cap, device_buf, sizeof(double) * n, hipMemcpyDeviceToDevice, stream));
+        VG_HIP(hipStreamSynchronize(stream));
+        if (!g->barrier()) return vgi::fail(VG_ERR_STATE, "local communicator: a rank failed or did not arrive");
+        hipLaunchKernelGGL(vg_local_sum_slots_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                           (const double *)g->slots, g->cap, g->n, device_buf, n);
+        VG_HIP(hipGetLastError());
+        VG_HIP(hipStreamSynchronize(stream));
+        if (!g->barrier()) return vgi::fail(VG_ERR_STATE, "local communicator: a rank failed or did not arrive");  // slots free again
+        return VG_OK;
+    }
     if (c->replicas > 0) {  // the sum over `replicas` identical ranks
         hipLaunchKernelGGL(vg_scale_in_place_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, device_buf, n,
                            (double)c->replicas);
@@ -179,6 +237,40 @@ int vg_comm_create_replicated(vg_comm **out, int replicas, int device)
     return VG_OK;
 }
 
+int vg_comm_create_local(vg_comm **out, int n_ranks, int device)
+{
+    if (!out) return vgi::fail(VG_ERR_INVALID_ARGUMENT, "out is NULL");
+    for (int r = 0; r < (n_ranks > 0 ? n_ranks : 0); r++) out[r] = nullptr;
+    if (n_ranks < 1 || n_ranks > 64) return vgi::fail(VG_ERR_INVALID_ARGUMENT, "n_ranks must be in [1, 64]");
+    VG_HIP(hipSetDevice(device));
+    vgc::LocalGroup *g = new (std::nothrow) vgc::LocalGroup();
+    if (!g) return vgi::fail(VG_ERR_ALLOC, "out of host memory");
+    g->n = n_ranks;
+    g->device = device;
+    g->cap = 1u << 16;  // 64 Ki doubles per rank: the solver's messages are at most 128^2 + 1
+    if (hipMalloc(reinterpret_cast<void **>(&g->slots), sizeof(double) * g->cap * (size_t)n_ranks) != hipSuccess) {
+        delete g;
+        return vgi::fail(VG_ERR_ALLOC, "hipMalloc of the local communicator's slots failed");
+    }
+    for (int r = 0; r < n_ranks; r++) {
+        vg_comm *c = new (std::nothrow) vg_comm();
+        if (!c) {
+            for (int q = 0; q < r; q++) { delete out[q]; out[q] = nullptr; }
+            (void)hipFree(g->slots);
+            delete g;
+            return vgi::fail(VG_ERR_ALLOC, "out of host memory");
+        }
+        c->n_ranks = n_ranks;
+        c->rank = r;
+        c->device = device;
+        c->owned = false;
+        c->local = g;
+        g->refs++;
+        out[r] = c;
+    }
+    return VG_OK;
+}
+
 int vg_comm_size(const vg_comm *c) { return c ? c->n_ranks : -1; }
 int vg_comm_rank(const vg_comm *c) { return c ? c->rank : -1; }
 
@@ -199,6 +291,23 @@ void vg_comm_destroy(vg_comm *c)
 {
     if (!c) return;
     if (c->owned && c->comm && vgc::api().handle) (void)vgc::api().comm_destroy(c->comm);
+    if (c->local) {
+        vgc::LocalGroup *g = c->local;
+        bool last;
+        {
+            std::lock_guard<std::mutex> lk(g->m);
+            last = --g->refs == 0;
+            if (!last) {  // a rank leaving early must not leave the others waiting for it
+                g->broken = true;
+                g->cv.notify_all();
+            }
+        }
+        if (last) {
+            (void)hipSetDevice(g->device);
+            (void)hipFree(g->slots);
+            delete g;
+        }
+    }
     delete c;
 }
 

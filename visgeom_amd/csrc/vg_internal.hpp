@@ -124,6 +124,7 @@ struct vg_block {
     const double *bound[1 + vg::kMaxChain] = {nullptr};  // parameter pointers of the last call
     bool moves[1 + vg::kMaxChain] = {false};             // ... that pointer has differed between two calls
     bool is_bound = false, used_valid = false;
+    bool stale = false;                                  // bound before the last vg_block_group_invalidate, not called since
     int calls = 0;                                       // evaluations seen (saturates at 2: from then on `moves` is known)
     std::vector<double> used;                            // parameter values the group's last pass used for this block
 };

@@ -67,7 +67,8 @@ struct SchurArgs {
     const double *mu_dev;  // device loop: the damping parameter lives in the LM state (overrides mu when not NULL)
     double *rec;           // [n_poses][kPoseRec]
     double *rows;          // [n_poses * 6][G + 1]
-    int *bad;              // number of poses whose damped block was not positive definite
+    double *bad;           // number of poses whose damped block was not positive definite: a double in the slot behind the
+                           // Schur Gram (rgram[(G+1)^2]), so that it is summed over ranks by that buffer's all-reduce
     const int *gate;       // speculative launches of the device loop: run only if *gate == gate_expect (NULL: always)
     int gate_expect;
 };
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(256) void vg_schur_rows_kernel(SchurArgs a)
             rec[27 + k] = f.vd[k];
         }
         rec[33] = f.active ? 1. : 0.;
-        if (f.mode == 0 && !f.pd && a.ref_ptr[i + 1] > a.ref_ptr[i]) atomicAdd(a.bad, 1);
+        if (f.mode == 0 && !f.pd && a.ref_ptr[i + 1] > a.ref_ptr[i]) atomicAdd(a.bad, 1.);
     }
     double *out = a.rows + (size_t)i * 6 * C + gcol;
     if (f.mode == 2) {  // host-eliminated sequence: hand over the raw column of W_i^T (last column: g_i)

@@ -146,7 +146,8 @@ struct LmAcceptArgs {
     const int *Wd;                     // [n_ds]
     const double *dg;                  // [G]
     unsigned long long *gmax_bits;     // max |g_pose| (bit pattern); reset here
-    int *bad;                          // poses whose damped block was not positive definite; reset here
+    double *bad;                       // poses whose damped block was not positive definite, summed over ranks (it sits
+                                       //   behind rgram and travelled with its all-reduce); reset here
     double *xcur;                      // [G] global values at the current point (updated on acceptance)
     const double *x;                   // init: the parameter vector, to gather xcur
     const long long *gcol_param;       // [G]
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(kLmThreads) void vg_lm_accept_kernel(LmAcceptArgs a
     // Through the pointer every read after a write had to be a fresh global load (the compiler cannot rule out aliasing
     // with the counters): half a dozen dependent memory round trips in a one-thread section.
     LmState S = *st;
-    const int n_bad = *a.bad;
+    const int n_bad = (int)*a.bad;  // the GLOBAL count: every rank takes the same accept / reject branch
     const unsigned long long gmax_bits = *a.gmax_bits;
     double cost2_c = 0.;
     for (int d = 0; d < a.n_ds; d++) cost2_c += sums[d * WW + (size_t)a.Wd[d] * a.Wd[d] - 1];
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(kLmThreads) void vg_lm_accept_kernel(LmAcceptArgs a
     }
     S.cost2_c = cost2_c;
     const double *sc = a.scal_partials ? s_sc : a.sums + (size_t)a.n_ds * WW;
-    *a.bad = 0;
+    *a.bad = 0.;
     double gmax_p = __longlong_as_double((long long)gmax_bits);
     *a.gmax_bits = 0ull;
     S.n_bad += n_bad;

@@ -739,7 +739,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
     DevBuf<double> *const gramA = gramA_v.data(), *const gramB = gramB_v.data();
     DevBuf<double> d_sums, d_x, d_xc, d_delta, d_glo, d_ghi, d_rec, d_rows, d_rgroups, d_rgram, d_dg, d_scal;
     DevBuf<vg::SolveDatasetDev> d_dsA, d_dsB;
-    DevBuf<int> d_inv, d_ref_ptr, d_ref_ds, d_ref_blk, d_bad;
+    DevBuf<int> d_inv, d_ref_ptr, d_ref_ds, d_ref_blk;
     DevBuf<unsigned char> d_pf;
     DevBuf<long long> d_pose_param, d_gcol_param;
     int rc;
@@ -771,7 +771,10 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
     VG_TRY(d_rec.alloc((size_t)n_poses * vg::kPoseRec));
     VG_TRY(d_rows.alloc((size_t)n_rows * C));
     VG_TRY(d_rgroups.alloc((size_t)n_groups * C * C));
-    VG_TRY(d_rgram.alloc((size_t)C * C));
+    // [Gram of the pose rows (C x C) | number of pose blocks that were not positive definite]: ONE buffer, so that the
+    // count is summed over ranks by the same all-reduce and every rank takes the same accept / reject branch
+    VG_TRY(d_rgram.alloc((size_t)C * C + 1));
+    double *const d_bad = d_rgram.p + (size_t)C * C;
     VG_TRY(d_dg.alloc((size_t)(G ? G : 1)));
     const unsigned int n_bs_groups = (unsigned int)((n_poses + vg::kBsPosesPerBlock - 1) / vg::kBsPosesPerBlock);
     // d_sums = [per-dataset summed Gram blocks (n_ds x Wmax^2) | scalar sums of the step (5)]: everything that is SUMMED
@@ -788,16 +791,14 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
     d_scal_sum.p = d_sums.p + n_sums;
     d_gmax.p = reinterpret_cast<unsigned long long *>(d_small.p);
     d_xg.p = d_small.p + 1;
-    VG_TRY(d_bad.alloc(1));
     VG_HIP(hipMemsetAsync(d_delta.p, 0, sizeof(double) * (size_t)(n_params ? n_params : 1), st));
     VG_HIP(hipMemcpyAsync(d_x.p, p->d_params, sizeof(double) * (size_t)n_params, hipMemcpyDeviceToDevice, st));
 
-    std::vector<double> h_sums((size_t)n_ds * Wmax * Wmax + 5), h_rgram((size_t)C * C);
+    std::vector<double> h_sums((size_t)n_ds * Wmax * Wmax + 5), h_rgram((size_t)C * C + 1);
     std::vector<double> U((size_t)G * G), gg(G), Uc((size_t)G * G), ggc(G), S((size_t)G * G), rhs(G), dg(G), h_xg(G);
-    PinnedBuf pin_sums, pin_rgram, pin_small, pin_bad;
+    PinnedBuf pin_sums, pin_rgram, pin_small;
     long long n_bad_pose_blocks = 0;
-    VG_TRY(pin_bad.alloc(1));
-    *reinterpret_cast<int *>(pin_bad.p) = 0;  // pin_small: [dg (G) | gmax (1) | xg (G)]
+    // pin_small: [dg (G) | gmax (1) | xg (G)]
     VG_TRY(pin_sums.alloc(h_sums.size()));
     VG_TRY(pin_rgram.alloc(h_rgram.size()));
     VG_TRY(pin_small.alloc((size_t)2 * G + 2));
@@ -900,7 +901,15 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             hipLaunchKernelGGL(vg::vg_gram_final_sum_multi_kernel, dim3(sum_final_blocks), dim3(256), 0, st, tab, n_tab);
             VG_HIP(hipGetLastError());
         }
-        // the ONE collective of an evaluation: [summed Gram blocks | scalar sums of the step], device buffer, in place
+        // the ONE collective of an evaluation: [summed Gram blocks | scalar sums of the step], device buffer, in place.
+        // In place means that after the first collective every slot holds a cross-rank total: whatever this rank does
+        // not rewrite before the next one (the block of a dataset without images here, the scalar tail of a rank
+        // without poses) has to be cleared, or that total is added in again.
+        if (comm && comm->n_ranks > 1) {
+            for (int d = 0; d < n_ds; d++)
+                if (!p->dss[d].n_blocks) VG_HIP(hipMemsetAsync(d_sums.p + (size_t)d * Wmax * Wmax, 0, sizeof(double) * Wmax * Wmax, st));
+            if (!n_bs_groups) VG_HIP(hipMemsetAsync(d_sums.p + n_sums, 0, sizeof(double) * 5, st));
+        }
         return vgc::allreduce_sum(comm, d_sums.p, n_pack, st);
     };
     // evaluate at a device parameter buffer and assemble U / gg / cost on the host
@@ -991,8 +1000,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
         h0.mu = 1. / h0.radius;
         h0.term = VG_TERM_NO_CONVERGENCE;
         VG_HIP(hipMemcpyAsync(d_state.p, &h0, sizeof h0, hipMemcpyHostToDevice, st));
-        VG_HIP(hipMemsetAsync(d_bad.p, 0, sizeof(int), st));
-        if (!n_poses) VG_HIP(hipMemsetAsync(d_rgram.p, 0, sizeof(double) * h_rgram.size(), st));
+        VG_HIP(hipMemsetAsync(d_rgram.p, 0, sizeof(double) * h_rgram.size(), st));  // also the bad-pose counter behind it
         vg::LmState final_state;
 
         vg::LmAcceptArgs aa;
@@ -1004,7 +1012,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
         aa.Wd = d_Wd.p;
         aa.dg = d_dg.p;
         aa.gmax_bits = d_gmax.p;
-        aa.bad = d_bad.p;
+        aa.bad = d_bad;
         aa.xcur = d_xcur.p;
         aa.x = d_x.p;
         aa.gcol_param = d_gcol_param.p;
@@ -1112,7 +1120,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             sa.dmax = opt.max_lm_diagonal;
             sa.rec = d_rec.p;
             sa.rows = d_rows.p;
-            sa.bad = d_bad.p;
+            sa.bad = d_bad;
             sa.gate = gate;
             sa.gate_expect = par;
             if (n_poses) {
@@ -1121,6 +1129,9 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
                 VG_TRY(launch_dense_gram(st, d_rows.p, n_rows, C, rows_per_group, n_groups, d_rgroups.p));
                 vg::launch_strided_sum(st, d_rgroups.p, n_groups, C * C, d_rgram.p);
                 VG_HIP(hipGetLastError());
+            } else if (multi_rank) {
+                // a rank without poses still joins the sum: the buffer holds the cross-rank total of the previous iteration
+                VG_HIP(hipMemsetAsync(d_rgram.p, 0, sizeof(double) * h_rgram.size(), st));
             }
             VG_TRY(vgc::allreduce_sum(comm, d_rgram.p, h_rgram.size(), st));  // Schur complement of the poses of all ranks
             vg::LmSolveArgs r2 = ra;
@@ -1299,11 +1310,11 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
         sa.dmax = opt.max_lm_diagonal;
         sa.rec = d_rec.p;
         sa.rows = d_rows.p;
-        sa.bad = d_bad.p;
+        sa.bad = d_bad;
         std::fill(h_rgram.begin(), h_rgram.end(), 0.);
         bool coupled_ok = true;
         if (n_poses) {
-            VG_HIP(hipMemsetAsync(d_bad.p, 0, sizeof(int), st));
+            VG_HIP(hipMemsetAsync(d_bad, 0, sizeof(double), st));
             hipLaunchKernelGGL(vg::vg_schur_rows_kernel, dim3((unsigned)((n_poses * C + 255) / 256)), dim3(256), 0, st, sa);
             VG_HIP(hipGetLastError());
             // sequences coupled by odometry: raw V / g / W^T come back, the host eliminates the block-tridiagonal
@@ -1333,17 +1344,18 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
         if (n_poses || (comm && comm->n_ranks > 1)) {
             VG_TRY(vgc::allreduce_sum(comm, d_rgram.p, h_rgram.size(), st));  // Schur complement of the poses of all ranks
             VG_HIP(hipMemcpyAsync(pin_rgram.p, d_rgram.p, sizeof(double) * h_rgram.size(), hipMemcpyDeviceToHost, st));
-            if (n_poses) VG_HIP(hipMemcpyAsync(pin_bad.p, d_bad.p, sizeof(int), hipMemcpyDeviceToHost, st));
             VG_HIP(hipStreamSynchronize(st));
             std::memcpy(h_rgram.data(), pin_rgram.p, sizeof(double) * h_rgram.size());
-            // poses whose damped 6 x 6 block was not positive definite (NaN / Inf in their Gram block): the step is
-            // invalid as a whole -- rejected like a failed factorisation of the reduced system, and counted
-            if (n_poses && *reinterpret_cast<const int *>(pin_bad.p) > 0) {
-                coupled_ok = false;
-                n_bad_pose_blocks += *reinterpret_cast<const int *>(pin_bad.p);
-            }
         }
         VG_TRY(allreduce(h_rgram));
+        // poses whose damped 6 x 6 block was not positive definite (NaN / Inf in their Gram block): the step is invalid
+        // as a whole -- rejected like a failed factorisation of the reduced system, and counted.  The count is the one
+        // summed over ALL ranks (last slot of the buffer): a rank-local decision here would make this rank skip the
+        // collectives of the candidate evaluation while the others enter them.
+        if (h_rgram[(size_t)C * C] > 0.) {
+            coupled_ok = false;
+            n_bad_pose_blocks += (long long)h_rgram[(size_t)C * C];
+        }
         t_schur += now_s() - t0;
 
         // ---- reduced system on the host

@@ -81,6 +81,24 @@ class Comm:
         self.n_ranks, self.rank, self.device = int(replicas), 0, int(device)
         return self
 
+    @classmethod
+    def local_group(cls, n_ranks, device=0):
+        """n_ranks communicators for n_ranks THREADS of this process on one device (vg_comm_create_local): the solver's
+        real multi-rank data flow with different shards per rank, on a one-GPU box"""
+        from . import capi
+
+        lib = capi.load()
+        hs = (ctypes.c_void_p * int(n_ranks))()
+        capi.check(lib.vg_comm_create_local(hs, int(n_ranks), int(device)))
+        out = []
+        for r in range(int(n_ranks)):
+            self = cls.__new__(cls)
+            self._lib = lib
+            self._h = ctypes.c_void_p(hs[r])
+            self.n_ranks, self.rank, self.device = int(n_ranks), r, int(device)
+            out.append(self)
+        return out
+
     @staticmethod
     def unique_id():
         from . import capi

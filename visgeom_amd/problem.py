@@ -38,6 +38,11 @@ class BlockGroup:
         self._h = h
         self.device = device
 
+    def invalidate(self):
+        """the memory behind the pointers the blocks were called with is going away (after ceres::Solve returns): every
+        block evaluates alone once more before the next pass (vg_block_group_invalidate)"""
+        capi.check(self._lib.vg_block_group_invalidate(self._h))
+
     def stats(self):
         v = [ctypes.c_int64(0) for _ in range(4)]
         capi.check(self._lib.vg_block_group_stats(self._h, *[ctypes.byref(x) for x in v]))
@@ -97,6 +102,9 @@ class GenericProjectionJac:
         sizes = getattr(self, "_sizes", None) or self.parameter_block_sizes()
         self._sizes = sizes
         ps = [_c(p) for p in params]  # contiguous float64 views are passed as they are: the pointers are the caller's
+        # a block group reads these addresses again when another block opens the next pass: conversions of lists /
+        # non-contiguous / non-float64 inputs are temporaries, so they are kept alive until this block's next call
+        self._last_params = ps
         if len(ps) != len(sizes) or any(p.size != s for p, s in zip(ps, sizes)):
             raise ValueError("parameter blocks must have sizes %s" % sizes)
         pp = (_dp * len(ps))(*[_ptr(p) for p in ps])
