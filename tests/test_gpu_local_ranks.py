@@ -170,21 +170,49 @@ def test_rig_on_three_ranks_one_of_them_empty(vg):
     assert np.max(np.abs(np.concatenate([x[G:] for _, x in res]) - x_ref[G:])) < 1e-6
 
 
-@pytest.mark.parametrize("model", ["eucm", "ucm"])
-def test_a_failed_pose_block_on_one_rank_is_seen_by_all(vg, model):
-    """NaN observations in one image of rank 1: its damped 6 x 6 block is not positive definite.  The count travels with
-    the Schur Gram's all-reduce, so both ranks reject the step together (a rank-local decision would make rank 1 skip the
-    collectives of the candidate evaluation: a hang) and both report the same termination and the same count."""
+@pytest.mark.parametrize("model,n_ranks", [("eucm", 1), ("eucm", 2), ("mei", 3)])
+def test_nan_observations_fail_the_solve_on_every_rank(vg, model, n_ranks):
+    """NaN observations in one image of the last rank: the cost at the starting point is NaN.  Ceres fails such a solve
+    (evaluation failed, TerminationType FAILURE); here every rank must report FAILURE with nothing moved -- the summed cost
+    travels in the packed all-reduce, so the ranks that hold only clean images see it too -- and nobody may hang."""
     from visgeom_amd import synthetic as S
 
-    d = S.make_mono(model, 40, 2, sigma=0.1)
-    d = dict(d)
+    d = dict(S.make_mono(model, 40, 2, sigma=0.1))
     d["corners"] = d["corners"].copy()
-    d["corners"][31, 5] = np.nan
-    res = run_ranks([mono(vg, d, model, 0, 20), mono(vg, d, model, 20, 40)], max_num_iterations=25)
-    (s0, x0), (s1, x1) = res
-    assert s0["termination"] == s1["termination"] and s0["num_iterations"] == s1["num_iterations"]
-    assert s0["num_successful_steps"] == 0 and s1["num_successful_steps"] == 0
-    assert "not positive definite" in s0["message"] and s0["message"] == s1["message"]
+    d["corners"][37, 5] = np.nan
+    cuts = np.linspace(0, 40, n_ranks + 1).astype(int)
+    if n_ranks == 1:
+        p = mono(vg, d, model, 0, 40)()
+        res = [(p.solve(max_num_iterations=25), p.get_parameters())]
+        p.close()
+    else:
+        res = run_ranks([mono(vg, d, model, cuts[r], cuts[r + 1]) for r in range(n_ranks)], max_num_iterations=25)
     K = d["init_intrinsics"].size
-    assert np.array_equal(x0[:K], d["init_intrinsics"]) and np.array_equal(x1[:K], d["init_intrinsics"])
+    for r, (s, x) in enumerate(res):
+        assert s["termination"] == "FAILURE" and s["num_iterations"] == 0 and s["num_successful_steps"] == 0, s
+        assert "not finite" in s["message"]
+        assert np.array_equal(x[:K], d["init_intrinsics"])
+        assert np.array_equal(x[K:], d["init_poses"][cuts[r]:cuts[r + 1]].ravel())
+
+
+def test_nan_observations_fail_the_host_driven_loop_too(vg):
+    """the same through the host-driven loop (a TransformationPrior keeps a problem off the device-resident loop)"""
+    from visgeom_amd import synthetic as S
+
+    st = S.make_stereo(12, sigma=0.1)
+    c2 = st["corners2"].copy()
+    c2[3, 17, 1] = np.inf
+    p = vg.CalibrationProblem(0)
+    c1 = p.add_camera("eucm", st["init_intrinsics1"])
+    cam2 = p.add_camera("eucm", st["init_intrinsics2"])
+    x12 = p.add_transform(True, st["init_xi12"])
+    seq = p.add_transform(False, st["init_poses"])
+    p.add_dataset(c1, [(seq, 0)], st["board"], st["corners1"])
+    p.add_dataset(cam2, [(x12, 1), (seq, 0)], st["board"], c2)
+    p.add_transformation_prior(x12, [10.0] * 6)
+    p.finalize()
+    x0 = p.get_parameters()
+    s = p.solve(max_num_iterations=25)
+    assert s["termination"] == "FAILURE" and s["num_iterations"] == 0 and "not finite" in s["message"], s
+    assert np.array_equal(p.get_parameters(), x0)
+    p.close()

@@ -168,7 +168,11 @@ __global__ __launch_bounds__(kLmThreads) void vg_lm_accept_kernel(LmAcceptArgs a
 {
     const int G = a.G, tid = threadIdx.x;
     LmState *st = a.st;
-    if (st->done || (a.gate_expect >= 0 && st->gate != a.gate_expect)) return;
+    if (st->done) {  // over before this launch (e.g. a non-finite cost at the starting point): the host still gets the state
+        if (tid == 0 && a.host_state) *a.host_state = *st;
+        return;
+    }
+    if (a.gate_expect >= 0 && st->gate != a.gate_expect) return;
     const int slot = a.init ? st->ucur : 1 - st->ucur;  // where the freshly evaluated point's blocks go
     double *Uc = a.U + (size_t)slot * G * G, *gc = a.gg + (size_t)slot * G;
     const size_t WW = (size_t)a.Wmax * a.Wmax;
@@ -260,6 +264,14 @@ __global__ __launch_bounds__(kLmThreads) void vg_lm_accept_kernel(LmAcceptArgs a
         S.cost2_init = cost2_c;
         S.mu = 1. / S.radius;
         S.gate = S.ucur;
+        // NaN / Inf in the residuals of the starting point: Ceres' evaluator fails the solve ("Residual and Jacobian
+        // evaluation failed", TerminationType FAILURE) -- without this test the NaNs are silently dropped by the fmax of
+        // the gradient norm and the solve "converges" at once
+        if (!isfinite(cost2_c)) {
+            S.done = 1;
+            S.term = VG_TERM_FAILURE;
+            S.gate = -1;
+        }
         publish();
         return;
     }

@@ -1232,6 +1232,10 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             std::snprintf(msg, sizeof msg, "function tolerance reached: |cost change| / cost = %.3e",
                           S.cost2 > 0 ? std::fabs(2. * S.cost_change) / (S.cost2 + 2. * S.cost_change) : 0.);
         else if (term == VG_TERM_RADIUS_TOO_SMALL) std::snprintf(msg, sizeof msg, "trust region radius below %.1e", opt.min_trust_region_radius);
+        else if (term == VG_TERM_FAILURE) {
+            iter = 0;
+            std::snprintf(msg, sizeof msg, "the cost at the starting point is not finite (NaN / Inf in the residuals)");
+        }
         if (S.n_bad) {
             const size_t len = std::strlen(msg);
             std::snprintf(msg + len, sizeof msg - len, "%s%d pose block(s) not positive definite", len ? "; " : "", S.n_bad);
@@ -1289,7 +1293,11 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
     char msg[160] = "";
     if (opt.verbose) std::printf("iter      cost      cost_change  |gradient|   |step|    tr_ratio  tr_radius\n%4d  %.6e\n", 0, initial_cost);
 
-    for (iter = 1; iter <= opt.max_num_iterations; iter++) {
+    if (!std::isfinite(cost2)) {  // as Ceres: a failed evaluation of the starting point fails the solve
+        term = VG_TERM_FAILURE;
+        std::snprintf(msg, sizeof msg, "the cost at the starting point is not finite (NaN / Inf in the residuals)");
+    }
+    for (iter = 1; term != VG_TERM_FAILURE && iter <= opt.max_num_iterations; iter++) {
         const double mu = 1. / radius;
         // ---- eliminate the poses: rows -> Gram -> S_sub, c
         double t0 = now_s();
@@ -1574,7 +1582,8 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             }
         }
     }
-    if (iter > opt.max_num_iterations) {
+    if (term == VG_TERM_FAILURE) iter = 0;
+    else if (iter > opt.max_num_iterations) {
         iter = opt.max_num_iterations;
         std::snprintf(msg, sizeof msg, "maximum number of iterations reached");
     }
