@@ -1075,6 +1075,309 @@ void vgo_odometry_cost_eval(const double A[36], int n, const double *deltaQ, con
     free(jz);
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Localization costs on the same camera models:
+ *   CameraJacobian            include/projection/jacobian.h:51-119
+ *   Triangulator              include/reconstruction/triangulator.h:31-38, src/reconstruction/triangulator.cpp:114-259
+ *   MonoReprojectCost         include/localization/local_cost_functions.h:159-180, src/localization/local_cost_functions.cpp:216-278
+ *   SparseReprojectCost       .h:183-208, .cpp:281-391
+ * ---------------------------------------------------------------------------------------- */
+
+/* CameraJacobian ctors, jacobian.h:54-71.  T23 == NULL: the one-transform ctor. */
+void vgo_camera_jacobian_init(const double T12[6], const double *T23, double L11[9], double L12[9], double L22[9])
+{
+    double n12[3] = {-T12[3], -T12[4], -T12[5]}, M[9];
+    vgo_inter_omega_rot(T12 + 3, M);
+    if (T23) {
+        double R21[9], R32[9], n23[3] = {-T23[3], -T23[4], -T23[5]};
+        vgo_rotation_matrix(n12, R21); /* T12.rotMatInv() */
+        vgo_rotation_matrix(n23, R32); /* T23.rotMatInv() */
+        mat3_mul(R32, R21, L11);       /* L11 = R32 * R21 */
+        mat3_mul(L11, M, L22);         /* L22 = L11 * M   */
+        /* L12 = -R32 * hat(T23.trans()) * R21 * M : left to right */
+        double nR32[9], H[9], a[9], b[9];
+        for (int i = 0; i < 9; i++) nR32[i] = -R32[i];
+        hat_(T23, H);
+        mat3_mul(nR32, H, a);
+        mat3_mul(a, R21, b);
+        mat3_mul(b, M, L12);
+    } else {
+        vgo_rotation_matrix(n12, L11); /* L11( T12.rotMatInv() ) */
+        for (int i = 0; i < 9; i++) L12[i] = 0.; /* L12( Matrix3d::Zero() ) */
+        mat3_mul(L11, M, L22);         /* L22( L11 * interOmegaRot(T12.rot()) ) */
+    }
+}
+
+/* CameraJacobian::dpdxi jacobian.h:75-96 and ::dfdxi :99-113 (grad != NULL).  two = twoTransforms. */
+void vgo_camera_jacobian_eval(int model, const double *intr, int two, const double L11[9], const double L12[9],
+                              const double L22[9], const double X2[3], const double *grad /* [2] or NULL */,
+                              double *dudxi, double *dvdxi, double *dfdxi)
+{
+    double P[6];
+    const int ok = vgo_projection_jacobian(model, intr, X2, P, P + 3);
+    if (!ok) {
+        if (dudxi) for (int i = 0; i < 6; i++) dudxi[i] = 0.;
+        if (dvdxi) for (int i = 0; i < 6; i++) dvdxi[i] = 0.;
+        if (dfdxi) for (int i = 0; i < 6; i++) dfdxi[i] = 0.;
+        return;
+    }
+    double H[9], B[9];
+    hat_(X2, H);
+    mat3_mul(H, L22, B); /* hat(X2) * L22 */
+    if (two) for (int i = 0; i < 9; i++) B[i] = B[i] - L12[i];
+    for (int row = 0; row < 2; row++) {
+        double *out = row == 0 ? dudxi : dvdxi;
+        if (!out) continue;
+        const double *p = P + 3 * row;
+        const double n[3] = {-p[0], -p[1], -p[2]};
+        for (int j = 0; j < 3; j++) out[j] = n[0] * L11[0 + j] + n[1] * L11[3 + j] + n[2] * L11[6 + j]; /* -row * L11 */
+        for (int j = 0; j < 3; j++) out[3 + j] = p[0] * B[0 + j] + p[1] * B[3 + j] + p[2] * B[6 + j];   /* row * B */
+    }
+    if (dfdxi && grad) {
+        double d[3], n[3];
+        for (int j = 0; j < 3; j++) d[j] = grad[0] * P[j] + grad[1] * P[3 + j]; /* dfdX = grad * projJac */
+        for (int j = 0; j < 3; j++) n[j] = -d[j];
+        for (int j = 0; j < 3; j++) dfdxi[j] = n[0] * L11[0 + j] + n[1] * L11[3 + j] + n[2] * L11[6 + j];
+        for (int j = 0; j < 3; j++) dfdxi[3 + j] = d[0] * B[0 + j] + d[1] * B[3 + j] + d[2] * B[6 + j];
+    }
+}
+
+/* Triangulator::regDiv, triangulator.cpp:114-128 */
+static double tri_reg_div(double num, double denom, double eps)
+{
+    if (denom > eps * num) return num / denom;
+    else if (num == 0) return 2. / eps;
+    else return 2. / eps - denom / (num * eps * eps);
+}
+
+static double dot3(const double a[3], const double b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+static void mat3_vec(const double A[9], const double v[3], double out[3])
+{
+    for (int i = 0; i < 3; i++) out[i] = A[3 * i] * v[0] + A[3 * i + 1] * v[1] + A[3 * i + 2] * v[2];
+}
+
+/* Triangulator::computeRegular, triangulator.cpp:145-259.  R, t = transf.rotMat(), transf.trans() (triangulator.h:34-35);
+ * any of res1 / res2 / jac1 / jac2 may be NULL (jacN needs resN). */
+void vgo_triangulate_regular(const double R[9], const double t[3], double eps, const double p[3], const double q_in[3],
+                             double *res1, double *res2, double *jac1, double *jac2)
+{
+    double q[3], r[3];
+    mat3_vec(R, q_in, q); /* q = R * q */
+    for (int i = 0; i < 3; i++) r[i] = p[i] + q[i];
+    double pq = dot3(p, q);
+    double pp = dot3(p, p);
+    double qq = dot3(q, q);
+    double tp = dot3(t, p);
+    double tq = dot3(t, q);
+    double tr = dot3(t, r);
+    double tt = dot3(t, t);
+    double rp = dot3(r, p);
+    double rq = dot3(r, q);
+    (void)pq; (void)pp; (void)qq;
+    double delta = tp * rq - tq * rp;
+    double delta1 = 0., delta2 = 0.;
+    if (res1) {
+        delta1 = tt * rq - tr * tq;
+        *res1 = tri_reg_div(delta1, delta, eps);
+    }
+    if (res2) {
+        delta2 = tt * rp - tr * tp;
+        *res2 = tri_reg_div(delta2, delta, eps);
+    }
+    if (jac1 || jac2) {
+        double deltaInv = 1. / delta;
+        double qSkew[9];
+        hat_(q, qSkew);
+        double jacDeltaV[3], jacDeltaOmega[3], w[3];
+        for (int i = 0; i < 3; i++) jacDeltaV[i] = rq * p[i] - rp * q[i];
+        for (int i = 0; i < 3; i++) w[i] = tp * p[i] - tq * p[i] - rp * t[i];
+        mat3_vec(qSkew, w, jacDeltaOmega);
+        if (jac1) {
+            double d1V[3], d1O[3];
+            for (int i = 0; i < 3; i++) d1V[i] = 2 * rq * t[i] - tq * r[i] - tr * q[i];
+            for (int i = 0; i < 3; i++) w[i] = tt * p[i] - tq * t[i] - tr * t[i];
+            mat3_vec(qSkew, w, d1O);
+            if (delta > eps * delta1) {
+                for (int i = 0; i < 3; i++) jac1[i] = deltaInv * (d1V[i] - *res1 * jacDeltaV[i]);
+                for (int i = 0; i < 3; i++) jac1[3 + i] = deltaInv * (d1O[i] - *res1 * jacDeltaOmega[i]);
+            } else if (delta1 == 0) {
+                for (int i = 0; i < 6; i++) jac1[i] = 0.;
+            } else {
+                const double coef = 1. / (eps * eps);
+                double deltaInv1 = 1. / delta1;
+                double k = -coef * deltaInv1;
+                double k1 = coef * delta * deltaInv1 * deltaInv1;
+                for (int i = 0; i < 3; i++) jac1[i] = k * jacDeltaV[i] + k1 * d1V[i];
+                for (int i = 0; i < 3; i++) jac1[3 + i] = k * jacDeltaOmega[i] + k1 * d1O[i];
+            }
+        }
+        if (jac2) {
+            double d2V[3], d2O[3];
+            for (int i = 0; i < 3; i++) d2V[i] = 2 * rp * t[i] - tp * r[i] - tr * p[i];
+            for (int i = 0; i < 3; i++) w[i] = tt * p[i] - tp * t[i];
+            mat3_vec(qSkew, w, d2O);
+            if (delta > eps * delta2) {
+                for (int i = 0; i < 3; i++) jac2[i] = deltaInv * (d2V[i] - *res2 * jacDeltaV[i]);
+                for (int i = 0; i < 3; i++) jac2[3 + i] = deltaInv * (d2O[i] - *res2 * jacDeltaOmega[i]);
+            } else if (delta2 == 0) {
+                for (int i = 0; i < 6; i++) jac2[i] = 0.;
+            } else {
+                const double coef = -1. / (eps * eps);
+                double deltaInv2 = 1. / delta2;
+                double k = coef * deltaInv2;
+                double k2 = coef * delta * deltaInv2 * deltaInv2;
+                for (int i = 0; i < 3; i++) jac2[i] = k * jacDeltaV[i] - k2 * d2V[i];
+                for (int i = 0; i < 3; i++) jac2[3 + i] = k * jacDeltaOmega[i] - k2 * d2O[i];
+            }
+        }
+    }
+}
+
+/* MonoReprojectCost::Evaluate, local_cost_functions.cpp:216-278.  Blocks [6 (xiOdom), 5 (lengths)], 10 residuals.
+ * x1 [5][3] = _xVec1, p2 [5][2] = _pVec2.  jac_odom [10 x 6], jac_len [10 x 5], row-major, either may be NULL. */
+void vgo_mono_reproject(int model, const double *intr, const double xiBaseCam[6], const double *x1, const double *p2,
+                        const double xiOdom[6], const double lengths[5], double residual[10], double *jac_odom,
+                        double *jac_len)
+{
+    /* :221  xi21 = _xiBaseCam.inverseCompose(xiOdom.inverseCompose(_xiBaseCam)) */
+    double inner[6], xi21[6];
+    inverse_compose(xiOdom, xiBaseCam, inner);
+    inverse_compose(xiBaseCam, inner, xi21);
+    /* :224-229  xVec2[i] = _xVec1[i] * params[1][i];  xi21.transform(xVec2, xVec2): R * x, then + trans */
+    double R21[9], xv2[5][3];
+    vgo_rotation_matrix(xi21 + 3, R21);
+    for (int i = 0; i < 5; i++) {
+        double s[3] = {x1[3 * i] * lengths[i], x1[3 * i + 1] * lengths[i], x1[3 * i + 2] * lengths[i]}, rx[3];
+        mat3_vec(R21, s, rx);
+        for (int k = 0; k < 3; k++) xv2[i][k] = rx[k] + xi21[k];
+    }
+    /* :232-244 */
+    for (int i = 0; i < 5; i++) {
+        double uv[2];
+        if (vgo_project_point(model, intr, xv2[i], uv)) {
+            residual[2 * i] = uv[0] - p2[2 * i];
+            residual[2 * i + 1] = uv[1] - p2[2 * i + 1];
+        } else {
+            residual[2 * i + 1] = residual[2 * i] = VGO_DOUBLE_BIG;
+        }
+    }
+    /* :249-259  InterJacobian(_camera, _xiBaseCam.inverse(), xiOdom, JAC_INVERTED) */
+    if (jac_odom) {
+        double inv[6];
+        inverse_(xiBaseCam, inv);
+        inter_jacobian ij;
+        inter_jacobian_init(&ij, inv, xiOdom, 1);
+        for (int i = 0; i < 5; i++) inter_jacobian_dpdxi(&ij, model, intr, xv2[i], jac_odom + i * 12, jac_odom + i * 12 + 6);
+    }
+    /* :262-275  length jacobian: only (row 2i, col i) and (row 2i + 1, col i) are non-zero */
+    if (jac_len) {
+        for (int i = 0; i < 50; i++) jac_len[i] = 0;
+        for (int i = 0; i < 5; i++) {
+            double n2[3], P[6];
+            mat3_vec(R21, x1 + 3 * i, n2);
+            vgo_projection_jacobian(model, intr, xv2[i], P, P + 3);
+            jac_len[i * 11] = P[0] * n2[0] + P[1] * n2[1] + P[2] * n2[2];
+            jac_len[i * 11 + 5] = P[3] * n2[0] + P[4] * n2[1] + P[5] * n2[2];
+        }
+    }
+}
+
+/* SparseReprojectCost::Evaluate, local_cost_functions.cpp:281-391.  One block [6 (xiOdom)], 2n residuals.
+ * x1, x2 [n][3] = _xVec1, _xVec2 (direction vectors in frames 1 / 2), p2 [n][2], size [n] = _sizeVec.
+ * jac [2n x 6] row-major or NULL.  NOTE (:383-389): only the u-row of every point is divided by its size; the v-row
+ * keeps the undivided Jacobian although both residuals are divided (:312) -- reproduced as written. */
+void vgo_sparse_reproject(int model, const double *intr, const double xiBaseCam[6], int n, const double *x1, const double *x2,
+                          const double *p2, const double *size, const double xiOdom[6], double *residual, double *jac)
+{
+    /* :286  xi12 = _xiBaseCam.inverseCompose(xiOdom.compose(_xiBaseCam)) */
+    double inner[6], xi12[6];
+    compose_(xiOdom, xiBaseCam, inner);
+    inverse_compose(xiBaseCam, inner, xi12);
+    /* :291 Triangulator(xi12): R = rotMat(), t = trans(), eps = 1e-3 (triangulator.h:34-35) */
+    double Rt[9];
+    vgo_rotation_matrix(xi12 + 3, Rt);
+    const double eps = 1e-3;
+    double R21[9], n12[3] = {-xi12[3], -xi12[4], -xi12[5]};
+    vgo_rotation_matrix(n12, R21); /* xi12.rotMatInv(): inverseRotate (:308) and the length Jacobian (:338) */
+    double *lam = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    double *jv = (double *)malloc(sizeof(double) * 6 * (size_t)(n > 0 ? n : 1));
+    double *xv2 = (double *)malloc(sizeof(double) * 3 * (size_t)(n > 0 ? n : 1));
+    for (int i = 0; i < n; i++)
+        vgo_triangulate_regular(Rt, xi12, eps, x1 + 3 * i, x2 + 3 * i, lam + i, NULL, jac ? jv + 6 * i : NULL, NULL);
+    /* :303-308  xVec2 = xVec1 * lambda; xi12.inverseTransform: (x - trans), then R(-rot) * */
+    for (int i = 0; i < n; i++) {
+        double d[3];
+        for (int k = 0; k < 3; k++) d[k] = x1[3 * i + k] * lam[i] - xi12[k];
+        mat3_vec(R21, d, xv2 + 3 * i);
+    }
+    /* :311-323 */
+    for (int i = 0; i < n; i++) {
+        double uv[2];
+        if (vgo_project_point(model, intr, xv2 + 3 * i, uv)) {
+            residual[2 * i] = (uv[0] - p2[2 * i]) / size[i];
+            residual[2 * i + 1] = (uv[1] - p2[2 * i + 1]) / size[i];
+        } else {
+            residual[2 * i + 1] = residual[2 * i] = VGO_DOUBLE_BIG;
+        }
+    }
+    if (jac) {
+        /* :331-345 odometry jacobian */
+        double inv[6];
+        inverse_(xiBaseCam, inv);
+        inter_jacobian ij;
+        inter_jacobian_init(&ij, inv, xiOdom, 1);
+        for (int i = 0; i < n; i++) {
+            if (residual[2 * i] == VGO_DOUBLE_BIG) {
+                for (int k = 0; k < 12; k++) jac[i * 12 + k] = 0;
+            } else {
+                inter_jacobian_dpdxi(&ij, model, intr, xv2 + 3 * i, jac + i * 12, jac + i * 12 + 6);
+            }
+        }
+        /* :348-359 */
+        double RcamBase[9], nb[3] = {-xiBaseCam[3], -xiBaseCam[4], -xiBaseCam[5]}, Mo[9], M[9];
+        vgo_rotation_matrix(nb, RcamBase);
+        vgo_inter_omega_rot(xiOdom + 3, Mo);
+        mat3_mul(RcamBase, Mo, M);
+        double R21T[9], A[9], tBaseCam1[3], Hn[9], Q[9];
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) R21T[3 * r + c] = R21[3 * c + r];
+        mat3_mul(RcamBase, R21T, A);       /* (RcamBase * R21.transpose()) */
+        mat3_vec(A, xiBaseCam, tBaseCam1); /*   * _xiBaseCam.trans()       */
+        hat_(tBaseCam1, Hn);
+        for (int k = 0; k < 9; k++) Hn[k] = -Hn[k];
+        mat3_mul(Hn, M, Q);                /* Q = -hat(tBaseCam1) * M */
+        /* :360-381 */
+        for (int i = 0; i < n; i++) {
+            if (residual[2 * i] == VGO_DOUBLE_BIG) continue;
+            double n2[3], P[6];
+            mat3_vec(R21, x1 + 3 * i, n2);
+            vgo_projection_jacobian(model, intr, xv2 + 3 * i, P, P + 3);
+            const double dpdl0 = P[0] * n2[0] + P[1] * n2[1] + P[2] * n2[2];
+            const double dpdl1 = P[3] * n2[0] + P[4] * n2[1] + P[5] * n2[2];
+            const double *dldv = jv + 6 * i, *dldw = jv + 6 * i + 3;
+            double dldt[3], dldr[3];
+            for (int j = 0; j < 3; j++) dldt[j] = dldv[0] * RcamBase[0 + j] + dldv[1] * RcamBase[3 + j] + dldv[2] * RcamBase[6 + j];
+            for (int j = 0; j < 3; j++)
+                dldr[j] = (dldw[0] * M[0 + j] + dldw[1] * M[3 + j] + dldw[2] * M[6 + j]) +
+                          (dldv[0] * Q[0 + j] + dldv[1] * Q[3 + j] + dldv[2] * Q[6 + j]);
+            double *J = jac + i * 12;
+            for (int j = 0; j < 3; j++) {
+                J[j] += dpdl0 * dldt[j];
+                J[3 + j] += dpdl0 * dldr[j];
+                J[6 + j] += dpdl1 * dldt[j];
+                J[9 + j] += dpdl1 * dldr[j];
+            }
+        }
+        /* :383-389  for jptr in [i*12, i*12 + 6): /= size  (the u-row only) */
+        for (int i = 0; i < n; i++)
+            for (int k = 0; k < 6; k++) jac[i * 12 + k] /= size[i];
+    }
+    free(lam);
+    free(jv);
+    free(xv2);
+}
+
 int vgo_max_threads(void)
 {
 #ifdef _OPENMP

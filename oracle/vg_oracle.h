@@ -116,6 +116,24 @@ void vgo_odometry_cost_init(double errV, double errW, double lambda, int n, cons
 void vgo_odometry_cost_eval(const double A[36], int n, const double *deltaQ, const double xi1[6], const double xi2[6],
                             const double intr[3], double residual[6], double J1[36], double J2[36], double J3[18]);
 
+/* ---- localization costs on the same camera models ---- */
+/* CameraJacobian ctors (include/projection/jacobian.h:54-71); T23 NULL = the one-transform ctor */
+void vgo_camera_jacobian_init(const double T12[6], const double *T23, double L11[9], double L12[9], double L22[9]);
+/* CameraJacobian::dpdxi (:75-96) and ::dfdxi (:99-113, when grad and dfdxi are given); outputs [6] each, any may be NULL */
+void vgo_camera_jacobian_eval(int model, const double *intr, int two, const double L11[9], const double L12[9],
+                              const double L22[9], const double X2[3], const double *grad, double *dudxi, double *dvdxi,
+                              double *dfdxi);
+/* Triangulator::computeRegular (src/reconstruction/triangulator.cpp:145-259); R [9] row-major, t [3] of the transform */
+void vgo_triangulate_regular(const double R[9], const double t[3], double eps, const double p[3], const double q[3],
+                             double *res1, double *res2, double *jac1, double *jac2);
+/* MonoReprojectCost::Evaluate (src/localization/local_cost_functions.cpp:216-278): blocks [6, 5], 10 residuals */
+void vgo_mono_reproject(int model, const double *intr, const double xiBaseCam[6], const double *x1 /*[5][3]*/,
+                        const double *p2 /*[5][2]*/, const double xiOdom[6], const double lengths[5], double residual[10],
+                        double *jac_odom /*[10][6]*/, double *jac_len /*[10][5]*/);
+/* SparseReprojectCost::Evaluate (:281-391): block [6], 2n residuals */
+void vgo_sparse_reproject(int model, const double *intr, const double xiBaseCam[6], int n, const double *x1, const double *x2,
+                          const double *p2, const double *size, const double xiOdom[6], double *residual, double *jac);
+
 int vgo_max_threads(void);
 
 #ifdef __cplusplus

@@ -83,6 +83,16 @@ def lib():
         L.vgo_odometry_cost_init.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int, _dp, _dp, _dp, _dp]
         L.vgo_odometry_cost_eval.restype = None
         L.vgo_odometry_cost_eval.argtypes = [_dp, ctypes.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
+        L.vgo_camera_jacobian_init.restype = None
+        L.vgo_camera_jacobian_init.argtypes = [_dp, _dp, _dp, _dp, _dp]
+        L.vgo_camera_jacobian_eval.restype = None
+        L.vgo_camera_jacobian_eval.argtypes = [ctypes.c_int, _dp, ctypes.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
+        L.vgo_triangulate_regular.restype = None
+        L.vgo_triangulate_regular.argtypes = [_dp, _dp, ctypes.c_double, _dp, _dp, _dp, _dp, _dp, _dp]
+        L.vgo_mono_reproject.restype = None
+        L.vgo_mono_reproject.argtypes = [ctypes.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
+        L.vgo_sparse_reproject.restype = None
+        L.vgo_sparse_reproject.argtypes = [ctypes.c_int, _dp, _dp, ctypes.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
         _lib = L
     return _lib
 
@@ -260,6 +270,58 @@ def project_point(model, intr, X):
     intr, X, uv = _c(intr), _c(X), np.full(2, np.nan)
     ok = lib().vgo_project_point(model, _ptr(intr), _ptr(X), _ptr(uv))
     return bool(ok), uv
+
+
+# ---- localization costs ----
+def camera_jacobian(model, intr, T12, T23, X2, grad=None):
+    """CameraJacobian (jacobian.h:51-119) for points X2 [n, 3] -> (dudxi [n, 6], dvdxi [n, 6], dfdxi [n, 6] or None)"""
+    intr, T12, X2 = _c(intr), _c(T12), _c(X2).reshape(-1, 3)
+    T23c = _c(T23) if T23 is not None else None
+    L11, L12, L22 = np.empty(9), np.empty(9), np.empty(9)
+    lib().vgo_camera_jacobian_init(_ptr(T12), _ptr(T23c) if T23c is not None else None, _ptr(L11), _ptr(L12), _ptr(L22))
+    n = X2.shape[0]
+    du, dv = np.empty((n, 6)), np.empty((n, 6))
+    g = _c(grad).reshape(-1, 2) if grad is not None else None
+    df = np.empty((n, 6)) if g is not None else None
+    for i in range(n):
+        lib().vgo_camera_jacobian_eval(model, _ptr(intr), int(T23 is not None), _ptr(L11), _ptr(L12), _ptr(L22), _ptr(X2[i]),
+                                       _ptr(g[i]) if g is not None else None, _ptr(du[i]), _ptr(dv[i]),
+                                       _ptr(df[i]) if df is not None else None)
+    return du, dv, df
+
+
+def triangulate_regular(xi, p, q, eps, want_jac=True):
+    """Triangulator(xi, eps).computeRegular(p, q, res1, res2, jac1, jac2) for one pair -> (l1, l2, jac1 [6], jac2 [6])"""
+    xi, p, q = _c(xi), _c(p), _c(q)
+    R = _c(rotation_matrix(xi[3:]).ravel())
+    t = _c(xi[:3])
+    r1, r2 = np.empty(1), np.empty(1)
+    j1, j2 = (np.empty(6), np.empty(6)) if want_jac else (None, None)
+    lib().vgo_triangulate_regular(_ptr(R), _ptr(t), ctypes.c_double(eps), _ptr(p), _ptr(q), _ptr(r1), _ptr(r2),
+                                  _ptr(j1) if want_jac else None, _ptr(j2) if want_jac else None)
+    return float(r1[0]), float(r2[0]), j1, j2
+
+
+def mono_reproject(model, intr, xi_base_cam, x1, p2, xi_odom, lengths, want_jac=True):
+    """MonoReprojectCost::Evaluate -> (residual [10], jac_odom [10, 6], jac_len [10, 5])"""
+    intr, xb, x1, p2, xo, ln = _c(intr), _c(xi_base_cam), _c(x1).reshape(5, 3), _c(p2).reshape(5, 2), _c(xi_odom), _c(lengths)
+    r = np.empty(10)
+    j0, j1 = (np.empty((10, 6)), np.empty((10, 5))) if want_jac else (None, None)
+    lib().vgo_mono_reproject(model, _ptr(intr), _ptr(xb), _ptr(x1), _ptr(p2), _ptr(xo), _ptr(ln), _ptr(r),
+                             _ptr(j0) if want_jac else None, _ptr(j1) if want_jac else None)
+    return r, j0, j1
+
+
+def sparse_reproject(model, intr, xi_base_cam, x1, x2, p2, size, xi_odom, want_jac=True):
+    """SparseReprojectCost::Evaluate -> (residual [2n], jac [2n, 6])"""
+    intr, xb, xo = _c(intr), _c(xi_base_cam), _c(xi_odom)
+    x1, x2, p2, size = _c(x1).reshape(-1, 3), _c(x2).reshape(-1, 3), _c(p2).reshape(-1, 2), _c(size).ravel()
+    n = x1.shape[0]
+    r = np.empty(2 * n)
+    J = np.empty((2 * n, 6)) if want_jac else None
+    lib().vgo_sparse_reproject(model, _ptr(intr), _ptr(xb), n, _ptr(x1), _ptr(x2), _ptr(p2), _ptr(size), _ptr(xo), _ptr(r),
+                               _ptr(J) if want_jac else None)
+    return r, J
 
 
 def max_threads():
