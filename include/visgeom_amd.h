@@ -427,6 +427,56 @@ int vg_calibration_write_residuals(vg_calibration *c, int dataset, const char *p
 /* transformFromData, include/json.h:36-67: 3 [x,y,theta] / 6 [t,rotvec] / 7 [t,qx,qy,qz,qw] / 12 row-major [R|t] */
 int vg_transform_from_values(int n, const double *values, double *out6);
 
+/* =====================================================================================
+ * 6. Localization reprojection costs on the same device camera models:
+ *      MonoReprojectCost    include/localization/local_cost_functions.h:159-180, src/localization/local_cost_functions.cpp:216-278
+ *      SparseReprojectCost  .h:183-208, .cpp:281-391  (with Triangulator::computeRegular, src/reconstruction/triangulator.cpp:145-259)
+ *      CameraJacobian       include/projection/jacobian.h:51-119
+ *    The reference evaluates these one block at a time inside ceres::Solve; its RANSAC (src/localization/sparse_odom.cpp:
+ *    511-606) solves 200 independent few-point problems per frame pair.  A SET keeps the constructor arguments of many
+ *    blocks resident in HBM; one evaluation of the whole set is two launches (one lane per block for the transform chain,
+ *    one lane per feature for triangulation / projection / the 2 x 6 rows).  The camera is constant (the reference clones
+ *    it in the constructor).  xi_base_cam: the base -> camera transform shared by all blocks of the set.
+ * ===================================================================================== */
+typedef struct vg_reproject_set vg_reproject_set;
+/* SparseReprojectCost ctor (.h:185-195) for n_blocks blocks; block b owns points [offsets[b], offsets[b + 1]) of the
+ * flat arrays (all HOST pointers): x1 / x2 [total][3] = _xVec1 / _xVec2 (direction vectors in camera frames 1 / 2),
+ * p2 [total][2] = _pVec2, size [total] = _sizeVec.  Parameter block [6] (xiOdom), 2 n residuals per block. */
+int vg_sparse_reproject_create(vg_reproject_set **out, int device, void *hip_stream, int model, const double *intrinsics,
+                               const double *xi_base_cam, int64_t n_blocks, const int64_t *offsets, const double *x1,
+                               const double *x2, const double *p2, const double *size);
+/* MonoReprojectCost ctor (.h:161-168): five points per block, x1 [n_blocks][5][3], p2 [n_blocks][5][2] (HOST).
+ * Parameter blocks [6 (xiOdom), 5 (lengths)], 10 residuals per block. */
+int vg_mono_reproject_create(vg_reproject_set **out, int device, void *hip_stream, int model, const double *intrinsics,
+                             const double *xi_base_cam, int64_t n_blocks, const double *x1, const double *p2);
+int64_t vg_reproject_num_blocks(const vg_reproject_set *s);
+int64_t vg_reproject_num_points(const vg_reproject_set *s);
+int64_t vg_reproject_block_offset(const vg_reproject_set *s, int64_t block); /* first point of a block; block == n_blocks: total */
+/* Evaluate of EVERY block of the set (DEVICE pointers, asynchronous on the set's stream): xi_odom [n_blocks][6];
+ * residuals [total][2] (failed projection: the 1e15 pair); jacobian [total][2][6] row-major or NULL: rows 2i / 2i + 1 of
+ * block b's [2 n x 6] Jacobian are at point offsets[b] + i.  Reference behaviour kept as written: only the u-row of a point
+ * is divided by its size (.cpp:383-389), and the depth part of the Jacobian is exact only for an identity base -> camera
+ * rotation (.cpp:355: tBaseCam1 conjugates the odometry rotation once too often). */
+int vg_sparse_reproject_evaluate(vg_reproject_set *s, const double *xi_odom, double *residuals, double *jacobian);
+/* the same for a MonoReprojectCost set: xi_odom [n_blocks][6], lengths [n_blocks][5]; residuals [n_blocks][10];
+ * jac_odom [n_blocks][10][6], jac_lengths [n_blocks][10][5] (row-major, either may be NULL). */
+int vg_mono_reproject_evaluate(vg_reproject_set *s, const double *xi_odom, const double *lengths, double *residuals,
+                               double *jac_odom, double *jac_lengths);
+/* Evaluate of ONE block with ceres::CostFunction::Evaluate's contract (HOST pointers, synchronous): parameters[0] = xiOdom,
+ * parameters[1] = the five lengths (mono only); jacobians NULL or an array of 1 (sparse) / 2 (mono) pointers, each NULL or
+ * row-major [2 n x block size].  Returns VG_OK where the reference returns true (always). */
+int vg_sparse_reproject_block_evaluate(vg_reproject_set *s, int64_t block, double const *const *parameters, double *residuals,
+                                       double **jacobians);
+int vg_mono_reproject_block_evaluate(vg_reproject_set *s, int64_t block, double const *const *parameters, double *residuals,
+                                     double **jacobians);
+int vg_reproject_synchronize(vg_reproject_set *s);
+void vg_reproject_destroy(vg_reproject_set *s);
+/* CameraJacobian (jacobian.h:51-119) for n points: T12 / T23 HOST 6-vectors (T23 NULL: the one-transform constructor),
+ * X2 [n][3], grad [n][2] (NULL without dfdxi) DEVICE; outputs DEVICE, either may be NULL: dpdxi [n][2][6] = (dudxi, dvdxi)
+ * of CameraJacobian::dpdxi (:75-96), dfdxi [n][6] of ::dfdxi (:99-113).  A point the camera cannot project gives zero rows. */
+int vg_camera_jacobian_evaluate(int device, void *hip_stream, int model, const double *intrinsics, const double *T12,
+                                const double *T23, int64_t n, const double *X2, const double *grad, double *dpdxi, double *dfdxi);
+
 /* ---- measurement helpers (bench / profiling only): a pure streaming write / copy with the same
  * 16 B-per-lane access pattern as the emit kernel, to calibrate rocprofv3's WRITE_SIZE / FETCH_SIZE
  * and to measure the achievable HBM rate on the box. */

@@ -145,6 +145,18 @@ SIGNATURES = {
     "vg_calibration_get_transform": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_int64, _dp, _i64p]),
     "vg_calibration_write_residuals": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_char_p, _dp, _i64p]),
     "vg_transform_from_values": (ctypes.c_int, [ctypes.c_int, _dp, _dp]),
+    "vg_sparse_reproject_create": (ctypes.c_int, [_vpp, ctypes.c_int, _vp, ctypes.c_int, _dp, _dp, ctypes.c_int64, _i64p, _dp, _dp, _dp, _dp]),
+    "vg_mono_reproject_create": (ctypes.c_int, [_vpp, ctypes.c_int, _vp, ctypes.c_int, _dp, _dp, ctypes.c_int64, _dp, _dp]),
+    "vg_reproject_num_blocks": (ctypes.c_int64, [_vp]),
+    "vg_reproject_num_points": (ctypes.c_int64, [_vp]),
+    "vg_reproject_block_offset": (ctypes.c_int64, [_vp, ctypes.c_int64]),
+    "vg_sparse_reproject_evaluate": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
+    "vg_mono_reproject_evaluate": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "vg_sparse_reproject_block_evaluate": (ctypes.c_int, [_vp, ctypes.c_int64, _dpp, _dp, _dpp]),
+    "vg_mono_reproject_block_evaluate": (ctypes.c_int, [_vp, ctypes.c_int64, _dpp, _dp, _dpp]),
+    "vg_reproject_synchronize": (ctypes.c_int, [_vp]),
+    "vg_reproject_destroy": (None, [_vp]),
+    "vg_camera_jacobian_evaluate": (ctypes.c_int, [ctypes.c_int, _vp, ctypes.c_int, _dp, _dp, _dp, ctypes.c_int64, _vp, _vp, _vp, _vp]),
     "vg_calib_stream_write": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_double]),
     "vg_calib_stream_copy": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64]),
 }

@@ -1375,3 +1375,4 @@ int vg_calib_stream_copy(void *hip_stream, double *dst, const double *src, int64
 #include "vg_pose_lm.hpp"
 #include "vg_refine_impl.hpp"
 #include "vg_calibration.hpp"
+#include "vg_local_impl.hpp"
