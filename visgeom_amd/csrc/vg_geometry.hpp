@@ -232,83 +232,111 @@ VG_HD void inter_omega_rot(const double *v, const RotTrig &g, double *B)
 VG_HD constexpr int frame_doubles(int L) { return 12 + 21 * L; }
 VG_HD constexpr int frame_stride(int L) { return (frame_doubles(L) + 1) & ~1; }
 
-// One chain walk producing the frame.  `member(l)` returns a pointer to the 6-vector of chain
-// member l.  Mirrors calib_cost_functions.cpp:32-46 (accumulation) and :76-92 (xi13 / xi23 pick);
-// the reference walks the chain twice with identical arithmetic, one walk is enough.
+// The chain walk, one member at a time.  Mirrors calib_cost_functions.cpp:32-46 (accumulation) and :76-92 (xi13 / xi23
+// pick); the reference walks the chain twice with identical arithmetic, one walk is enough.
+struct ChainState {
+    Transf acc;         // xiAcc
+    double Racc[9];     // R(xiAcc.rot) when racc_valid
+    bool racc_valid;
+};
+
+VG_HD void chain_state_init(ChainState &s)
+{
+    s.acc = {{0., 0., 0.}, {0., 0., 0.}};  // Transformation() = zeros  transformation.h:36
+    const double I0[9] = {1., -0., 0., 0., 1., -0., -0., 0., 1.};  // rotationMatrix(0) = I + hat(0)
+#pragma unroll
+    for (int i = 0; i < 9; i++) s.Racc[i] = I0[i];
+    s.racc_valid = true;
+}
+
+// Quaternion(xiAcc.rot): what every member's compose / composeInverse starts with (transformation.h:83,105)
+VG_HD Quat chain_acc_quat(const ChainState &s)
+{
+    const RotTrig gacc = rot_trig(s.acc.r, false, true);
+    return quat_from_rotvec(s.acc.r, gacc);
+}
+
+// one member: xi23 with its status, q1 = Quaternion(xiAcc.rot) of the state BEFORE it; out = [R12 (9) | M12 (9) | t13 (3)]
+VG_HD void chain_walk_member(ChainState &s, const Quat &q1, const double *xi23, bool inverted, double *out)
+{
+    Transf &acc = s.acc;
+    const double t23[3] = {xi23[0], xi23[1], xi23[2]};
+    const double r23[3] = {xi23[3], xi23[4], xi23[5]};
+    const RotTrig g23 = rot_trig(r23, true, true);
+    const Quat q2 = quat_from_rotvec(r23, g23);
+
+    double R13[9], t13[3];
+    if (!inverted) {
+        // xiAcc = xiAcc.compose(xi23); xi13 = xiAcc      transformation.h:80-88
+        double rt[3];
+        quat_rotate(q1, t23, rt);
+        const Quat qres = quat_mul(q1, q2);
+        acc.t[0] = rt[0] + acc.t[0];
+        acc.t[1] = rt[1] + acc.t[1];
+        acc.t[2] = rt[2] + acc.t[2];
+        quat_to_rotvec(qres, acc.r);
+        const RotTrig gn = rot_trig(acc.r, true, false);
+        rotation_matrix(acc.r, 1., gn, s.Racc);
+        s.racc_valid = true;
+#pragma unroll
+        for (int i = 0; i < 9; i++) R13[i] = s.Racc[i];
+        t13[0] = acc.t[0]; t13[1] = acc.t[1]; t13[2] = acc.t[2];
+    } else {
+        // xi13 = xiAcc; xiAcc = xiAcc.composeInverse(xi23)   transformation.h:101-110
+        if (!s.racc_valid) {
+            const RotTrig go = rot_trig(acc.r, true, false);
+            rotation_matrix(acc.r, 1., go, s.Racc);
+        }
+#pragma unroll
+        for (int i = 0; i < 9; i++) R13[i] = s.Racc[i];
+        t13[0] = acc.t[0]; t13[1] = acc.t[1]; t13[2] = acc.t[2];
+        const Quat q2inv = {-q2.x, -q2.y, -q2.z, q2.w};  // quaternion.h:100-103
+        const Quat qres = quat_mul(q1, q2inv);
+        double rt[3];
+        quat_rotate(qres, t23, rt);
+        acc.t[0] = acc.t[0] - rt[0];
+        acc.t[1] = acc.t[1] - rt[1];
+        acc.t[2] = acc.t[2] - rt[2];
+        quat_to_rotvec(qres, acc.r);
+        s.racc_valid = false;
+    }
+
+    // InterJacobian(camera, xi13, xi23, inverted)   jacobian.h:139-152
+    double Rb[9], M[9], R12[9], M12[9];
+    rotation_matrix(r23, -1., g23, Rb);  // xi23.rotMatInv()
+    mat3_mul(R13, Rb, R12);
+    inter_omega_rot(r23, g23, M);
+    mat3_mul(R12, M, M12);
+#pragma unroll
+    for (int i = 0; i < 9; i++) out[i] = inverted ? R12[i] * -1 : R12[i];
+#pragma unroll
+    for (int i = 0; i < 9; i++) out[9 + i] = inverted ? M12[i] * -1 : M12[i];
+    out[18] = t13[0]; out[19] = t13[1]; out[20] = t13[2];
+}
+
+// frame[0..11] = R(xiAcc.rot), xiAcc.trans of the finished chain
+VG_HD void chain_finish(ChainState &s, double *frame)
+{
+    if (!s.racc_valid) {
+        const RotTrig go = rot_trig(s.acc.r, true, false);
+        rotation_matrix(s.acc.r, 1., go, s.Racc);
+    }
+#pragma unroll
+    for (int i = 0; i < 9; i++) frame[i] = s.Racc[i];
+    frame[9] = s.acc.t[0]; frame[10] = s.acc.t[1]; frame[11] = s.acc.t[2];
+}
+
+// One chain walk producing the frame.  `member(l)` returns a pointer to the 6-vector of chain member l.
 template <typename MemberFn>
 VG_HD void build_frame(int L, const int *status, MemberFn member, double *frame)
 {
-    Transf acc = {{0., 0., 0.}, {0., 0., 0.}};  // Transformation() = zeros  transformation.h:36
-    double Racc[9] = {1., -0., 0., 0., 1., -0., -0., 0., 1.};  // rotationMatrix(0) = I + hat(0)
-    bool racc_valid = true;
-
+    ChainState s;
+    chain_state_init(s);
     for (int l = 0; l < L; l++) {
-        const double *xi23 = member(l);
-        const double t23[3] = {xi23[0], xi23[1], xi23[2]};
-        const double r23[3] = {xi23[3], xi23[4], xi23[5]};
-        const bool inverted = status[l] != 0;
-
-        const RotTrig g23 = rot_trig(r23, true, true);
-        const RotTrig gacc = rot_trig(acc.r, false, true);
-        const Quat q1 = quat_from_rotvec(acc.r, gacc);
-        const Quat q2 = quat_from_rotvec(r23, g23);
-
-        double R13[9], t13[3];
-        if (!inverted) {
-            // xiAcc = xiAcc.compose(xi23); xi13 = xiAcc      transformation.h:80-88
-            double rt[3];
-            quat_rotate(q1, t23, rt);
-            const Quat qres = quat_mul(q1, q2);
-            acc.t[0] = rt[0] + acc.t[0];
-            acc.t[1] = rt[1] + acc.t[1];
-            acc.t[2] = rt[2] + acc.t[2];
-            quat_to_rotvec(qres, acc.r);
-            const RotTrig gn = rot_trig(acc.r, true, false);
-            rotation_matrix(acc.r, 1., gn, Racc);
-            racc_valid = true;
-#pragma unroll
-            for (int i = 0; i < 9; i++) R13[i] = Racc[i];
-            t13[0] = acc.t[0]; t13[1] = acc.t[1]; t13[2] = acc.t[2];
-        } else {
-            // xi13 = xiAcc; xiAcc = xiAcc.composeInverse(xi23)   transformation.h:101-110
-            if (!racc_valid) {
-                const RotTrig go = rot_trig(acc.r, true, false);
-                rotation_matrix(acc.r, 1., go, Racc);
-            }
-#pragma unroll
-            for (int i = 0; i < 9; i++) R13[i] = Racc[i];
-            t13[0] = acc.t[0]; t13[1] = acc.t[1]; t13[2] = acc.t[2];
-            const Quat q2inv = {-q2.x, -q2.y, -q2.z, q2.w};  // quaternion.h:100-103
-            const Quat qres = quat_mul(q1, q2inv);
-            double rt[3];
-            quat_rotate(qres, t23, rt);
-            acc.t[0] = acc.t[0] - rt[0];
-            acc.t[1] = acc.t[1] - rt[1];
-            acc.t[2] = acc.t[2] - rt[2];
-            quat_to_rotvec(qres, acc.r);
-            racc_valid = false;
-        }
-
-        // InterJacobian(camera, xi13, xi23, inverted)   jacobian.h:139-152
-        double Rb[9], M[9], R12[9], M12[9];
-        rotation_matrix(r23, -1., g23, Rb);  // xi23.rotMatInv()
-        mat3_mul(R13, Rb, R12);
-        inter_omega_rot(r23, g23, M);
-        mat3_mul(R12, M, M12);
-        double *out = frame + 12 + 21 * l;
-#pragma unroll
-        for (int i = 0; i < 9; i++) out[i] = inverted ? R12[i] * -1 : R12[i];
-#pragma unroll
-        for (int i = 0; i < 9; i++) out[9 + i] = inverted ? M12[i] * -1 : M12[i];
-        out[18] = t13[0]; out[19] = t13[1]; out[20] = t13[2];
+        const Quat q1 = chain_acc_quat(s);
+        chain_walk_member(s, q1, member(l), status[l] != 0, frame + 12 + 21 * l);
     }
-    if (!racc_valid) {
-        const RotTrig go = rot_trig(acc.r, true, false);
-        rotation_matrix(acc.r, 1., go, Racc);
-    }
-#pragma unroll
-    for (int i = 0; i < 9; i++) frame[i] = Racc[i];
-    frame[9] = acc.t[0]; frame[10] = acc.t[1]; frame[11] = acc.t[2];
+    chain_finish(s, frame);
 }
 
 // The frame of a chain with ONE member used DIRECT (the mono calibration case): xiAcc = identity o xi23 = xi23.

@@ -224,7 +224,9 @@ __device__ __forceinline__ void emit_tile(const EmitArgs &a, const unsigned int 
         const unsigned int o_last = (o0 + kEmitThreads - 1 < a.n_obs) ? o0 + kEmitThreads - 1 : a.n_obs - 1;
         const unsigned int nf = o_last / a.N - b_first + 1;
         if (INLINE_CHAIN) {
-            for (unsigned int f = tid; f < nf; f += kEmitThreads) {
+            // a tile of 256 consecutive observations touches at most 256 images: at most one frame per thread (as a loop
+            // the walk was scheduled across iterations and cost 16 more VGPRs: 114 instead of 98)
+            if (const unsigned int f = tid; f < nf) {
                 const long long bi = (long long)b_first + f;
                 const long long si = a.seq_index ? (long long)a.seq_index[bi] : a.first_block + bi;
                 build_frame_single_direct(a.chain_params + a.chain_stride * si, fr_lds + f * a.frame_stride_d);
