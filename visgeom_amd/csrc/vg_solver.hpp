@@ -190,6 +190,88 @@ __global__ __launch_bounds__(256) void vg_schur_rows_kernel(SchurArgs a)
     for (int k = 0; k < 6; k++) out[k * C] = f.active ? y[k] : 0.;
 }
 
+// vg_schur_rows_kernel AND the Gram of the rows it produces, in one launch: a workgroup owns `poses_per_wg` whole poses per
+// batch (one lane per (pose, column), as above), keeps the batch's 6 x poses_per_wg rows in LDS next to writing them out, and
+// adds their outer products into its own C x C partial (entry-parallel, rows in increasing order: fixed order); `batches`
+// batches per workgroup keep the number of partials in the hundreds.  One strided fixed-order sum over the workgroup
+// partials then gives the Schur complement's Gram -- two launches where there were three (rows, MFMA Gram per 96 rows,
+// sum), and the rows are read back from LDS instead of from HBM.  Not for host-eliminated sequences (mode 2): their rows are
+// rewritten by the host before the Gram.
+constexpr int kSchurThreads = 256;
+
+__global__ __launch_bounds__(kSchurThreads) void vg_schur_rows_gram_kernel(SchurArgs a, int poses_per_wg, int batches,
+                                                                            double *__restrict__ partials /* [n_wg][C*C] */)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm_rows[];  // [batches * poses_per_wg * 6][C + 1] (odd-ish stride)
+    const int C = a.G + 1, CS = C + 1, tid = threadIdx.x;
+    if (gate_closed(a.gate, a.gate_expect)) return;
+    const int pl = tid / C, gcol = tid - pl * C;        // pose of the batch, column
+    const bool lane_on = pl < poses_per_wg;
+    for (int bt = 0; bt < batches; bt++) {
+        const int i = (blockIdx.x * batches + bt) * poses_per_wg + pl;
+        double y[6] = {0., 0., 0., 0., 0., 0.};
+        if (lane_on && i < a.n_poses) {
+            PoseFactor f;
+            pose_factor(a, i, f);
+            double w[6];
+            if (gcol < a.G) {
+#pragma unroll
+                for (int c = 0; c < 6; c++) w[c] = 0.;
+                const int r0 = a.ref_ptr[i], r1 = a.ref_ptr[i + 1];
+                for (int q = r0; q < r1; q++) {
+                    const int d = a.ref_ds[q];
+                    const int lc = a.inv[d * a.G + gcol];
+                    if (lc < 0) continue;
+                    const SolveDatasetDev D = a.ds[d];
+                    const double *Gb = D.gram + (size_t)a.ref_blk[q] * D.W * D.W;
+#pragma unroll
+                    for (int c = 0; c < 6; c++) w[c] += Gb[lc * D.W + D.pose_off + c];
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 6; c++) w[c] = f.gp[c];
+                double *rec = a.rec + (size_t)i * kPoseRec;
+#pragma unroll
+                for (int k = 0; k < 21; k++) rec[k] = f.L[k];
+#pragma unroll
+                for (int k = 0; k < 6; k++) {
+                    rec[21 + k] = f.gp[k];
+                    rec[27 + k] = f.vd[k];
+                }
+                rec[33] = f.active ? 1. : 0.;
+                if (f.mode == 0 && !f.pd && a.ref_ptr[i + 1] > a.ref_ptr[i]) atomicAdd(a.bad, 1.);
+            }
+            fwd6(f.L, w, y);
+            double *out = a.rows + (size_t)i * 6 * C + gcol;
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                y[k] = f.active ? y[k] : 0.;
+                out[k * C] = y[k];
+            }
+        }
+        if (lane_on) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) sm_rows[(size_t)((bt * poses_per_wg + pl) * 6 + k) * CS + gcol] = y[k];
+        }
+    }
+    __syncthreads();
+    // entry-parallel Gram of the workgroup's rows (rows in increasing order: a fixed order)
+    const int n_rows_wg = batches * poses_per_wg * 6, E = C * (C + 1) / 2;
+    double *P = partials + (size_t)blockIdx.x * C * C;
+    for (int e = tid; e < E; e += kSchurThreads) {
+        int r = 0, rem = e;
+        while (rem >= C - r) {
+            rem -= C - r;
+            r++;
+        }
+        const int c = r + rem;
+        double s = 0.;
+        for (int row = 0; row < n_rows_wg; row++) s += sm_rows[(size_t)row * CS + r] * sm_rows[(size_t)row * CS + c];
+        P[r * C + c] = s;
+        P[c * C + r] = s;
+    }
+}
+
 // ceres::SoftLOneLoss(a) on one residual block = one image: rho(s) = 2 a^2 (sqrt(1 + s / a^2) - 1), s = r^T r.
 // rho'' < 0, so Ceres' Corrector only scales residuals and Jacobian rows by sqrt(rho'): the block's Gram matrix
 // becomes rho' * G, and its last entry (r^T r, twice the cost term) becomes rho(s).  One wave per block; the wave
@@ -229,17 +311,17 @@ constexpr int kBsThreads = 256;
 constexpr int kBsPosesPerGroup = 2;
 constexpr int kBsPosesPerBlock = (kBsThreads / kBsGroup) * kBsPosesPerGroup;
 
+// dgv: the global step, in global memory (b.dg) or in the workgroup's LDS (the kernel that solves the reduced system itself)
 template <int kJ>
-__global__ __launch_bounds__(kBsThreads) void vg_backsub_kernel(BacksubArgs b)
+__device__ __forceinline__ void backsub_body(const BacksubArgs &b, const double *dgv)
 {
     const SchurArgs &a = b.s;
     const int t = blockIdx.x * kBsThreads + threadIdx.x;
-    if (gate_closed(a.gate, a.gate_expect)) return;
     if (t < a.G) {
         const long long gp = b.gcol_param[t];
-        b.delta[gp] = b.dg[t];
+        b.delta[gp] = dgv[t];
         b.xg[t] = b.x[gp];
-        b.x_new[gp] = clampd(b.x[gp] + b.dg[t], b.lo[t], b.hi[t]);
+        b.x_new[gp] = clampd(b.x[gp] + dgv[t], b.lo[t], b.hi[t]);
     }
     if ((int)(blockIdx.x * kBsPosesPerBlock) >= a.n_poses) return;  // workgroups that only carry global columns
     const int gl = threadIdx.x & (kBsGroup - 1), grp = threadIdx.x >> 4;
@@ -269,11 +351,11 @@ __global__ __launch_bounds__(kBsThreads) void vg_backsub_kernel(BacksubArgs b)
         const bool active = rec[33] != 0.;
         // G <= 16 kJ - 1: at most kJ columns per lane and row (kJ = 4 up to 63 global columns, 8 up to 127); all
         // 6 kJ loads are issued before the first use (a loop over a run-time G waits for every load in turn)
-        double dgv[kJ], rv[6][kJ];
+        double dgv_l[kJ], rv[6][kJ];
 #pragma unroll
         for (int j = 0; j < kJ; j++) {
             const int g = gl + kBsGroup * j;
-            dgv[j] = g < a.G ? b.dg[g] : 0.;
+            dgv_l[j] = g < a.G ? dgv[g] : 0.;
 #pragma unroll
             for (int k = 0; k < 6; k++) rv[k][j] = g < a.G ? rows[k * C + g] : 0.;
         }
@@ -281,7 +363,7 @@ __global__ __launch_bounds__(kBsThreads) void vg_backsub_kernel(BacksubArgs b)
         for (int k = 0; k < 6; k++) {
             double s = 0.;
 #pragma unroll
-            for (int j = 0; j < kJ; j++) s += rv[k][j] * dgv[j];
+            for (int j = 0; j < kJ; j++) s += rv[k][j] * dgv_l[j];
             y[k] = s;
         }
 #pragma unroll
@@ -338,6 +420,13 @@ __global__ __launch_bounds__(kBsThreads) void vg_backsub_kernel(BacksubArgs b)
         for (int w = 0; w < kBsThreads / kWave; w++) m = fmax(m, red[w][5]);
         atomicMax(b.gmax_bits, (unsigned long long)__double_as_longlong(m));  // order preserving for m >= 0
     }
+}
+
+template <int kJ>
+__global__ __launch_bounds__(kBsThreads) void vg_backsub_kernel(BacksubArgs b)
+{
+    if (gate_closed(b.s.gate, b.s.gate_expect)) return;
+    backsub_body<kJ>(b, b.dg);
 }
 
 // x_new = x + delta (pose parameters: unbounded)

@@ -43,9 +43,9 @@ constexpr int kLmThreads = 256;
 // Launched with ONE wave (64 threads) up to 64 columns -- the factorisation is a chain of G dependent column steps,
 // and a workgroup barrier per step costs more than the step: 64 us at G = 45 with 256 threads, most of it barriers --
 // and with 256 threads above.
-__device__ __forceinline__ void lm_sync()
+__device__ __forceinline__ void lm_sync(int n_threads)
 {
-    if (blockDim.x == kWave) {  // one wave: its DS operations execute in order, only the compiler needs fencing
+    if (n_threads == kWave) {  // one wave: its DS operations execute in order, only the compiler needs fencing
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -54,13 +54,12 @@ __device__ __forceinline__ void lm_sync()
     }
 }
 
-__global__ __launch_bounds__(kLmThreads) void vg_lm_reduced_solve_kernel(LmSolveArgs a)
+// The solve itself, by the first kT threads of a workgroup (kT = 64: one wave, wave-level fences; else the whole workgroup);
+// the step ends in LDS at sm + G * G + 2 * G (`x`); `publish`: also to a.dg / st->step_ok.
+__device__ __forceinline__ void lm_reduced_solve_body(const LmSolveArgs &a, double *sm, const int tid, const int kT, const bool publish)
 {
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int G = a.G, C = G + 1, tid = threadIdx.x;
-    const int kT = blockDim.x;
+    const int G = a.G, C = G + 1;
     LmState *st = a.st;
-    if (st->done || (a.gate_expect >= 0 && st->gate != a.gate_expect)) return;
     double *A = sm, *rhs = A + (size_t)G * G, *b = rhs + G, *x = b + G, *heldf = x + G, *flags = heldf + G;
     double *S = a.S ? a.S : flags + 2;  // the damped matrix survives the active-set passes: LDS when both fit
     const double mu = st->mu;
@@ -76,7 +75,7 @@ __global__ __launch_bounds__(kLmThreads) void vg_lm_reduced_solve_kernel(LmSolve
         heldf[r] = a.gfrozen[r] ? 1. : 0.;
     }
     if (tid == 0) flags[0] = 1.;  // step_ok
-    lm_sync();
+    lm_sync(kT);
     // Constant blocks, and the active set of the box bounds: a parameter ON a bound whose step points outwards is held
     // (row and column leave the reduced system); re-solved until the set is stable.
     for (int pass = 0; pass <= G; pass++) {
@@ -86,7 +85,7 @@ __global__ __launch_bounds__(kLmThreads) void vg_lm_reduced_solve_kernel(LmSolve
             A[i] = h ? (r == c ? 1. : 0.) : S[i];
         }
         for (int r = tid; r < G; r += kT) b[r] = heldf[r] != 0. ? 0. : rhs[r];
-        lm_sync();
+        lm_sync(kT);
         // Cholesky, lower triangle in place (right-looking; every entry sees its subtractions in increasing column
         // order, as the host's row-oriented version does)
         for (int j = 0; j < G; j++) {
@@ -95,33 +94,33 @@ __global__ __launch_bounds__(kLmThreads) void vg_lm_reduced_solve_kernel(LmSolve
                 if (!(d > 0.) || !isfinite(d)) flags[0] = 0.;
                 A[(size_t)j * G + j] = sqrt(d > 0. ? d : 1.);
             }
-            lm_sync();
+            lm_sync(kT);
             const double djj = A[(size_t)j * G + j];
             for (int i = j + 1 + tid; i < G; i += kT) A[(size_t)i * G + j] /= djj;
-            lm_sync();
+            lm_sync(kT);
             for (int i = j + 1 + tid; i < G; i += kT) {  // a row per lane: no index arithmetic, column j is a broadcast read
                 const double lij = A[(size_t)i * G + j];
                 for (int k = j + 1; k <= i; k++) A[(size_t)i * G + k] -= lij * A[(size_t)k * G + j];
             }
-            lm_sync();
+            lm_sync(kT);
         }
         // L y = b, L^T x = y
         for (int j = 0; j < G; j++) {
             if (tid == 0) b[j] = b[j] / A[(size_t)j * G + j];
-            lm_sync();
+            lm_sync(kT);
             const double yj = b[j];
             for (int i = j + 1 + tid; i < G; i += kT) b[i] -= A[(size_t)i * G + j] * yj;
-            lm_sync();
+            lm_sync(kT);
         }
         for (int j = G - 1; j >= 0; j--) {
             if (tid == 0) x[j] = b[j] / A[(size_t)j * G + j];
-            lm_sync();
+            lm_sync(kT);
             const double xj = x[j];
             for (int i = tid; i < j; i += kT) b[i] -= A[(size_t)j * G + i] * xj;
-            lm_sync();
+            lm_sync(kT);
         }
         if (tid == 0) flags[1] = 0.;  // changed
-        lm_sync();
+        lm_sync(kT);
         if (flags[0] != 0. && a.use_bounds)
             for (int r = tid; r < G; r += kT) {
                 if (heldf[r] != 0.) continue;
@@ -130,12 +129,41 @@ __global__ __launch_bounds__(kLmThreads) void vg_lm_reduced_solve_kernel(LmSolve
                     flags[1] = 1.;
                 }
             }
-        lm_sync();
+        lm_sync(kT);
         if (flags[1] == 0. || flags[0] == 0.) break;
-        lm_sync();
+        lm_sync(kT);
     }
-    for (int r = tid; r < G; r += kT) a.dg[r] = x[r];
-    if (tid == 0) st->step_ok = (G == 0 || flags[0] != 0.) ? 1 : 0;
+    if (publish) {
+        for (int r = tid; r < G; r += kT) a.dg[r] = x[r];
+        if (tid == 0) st->step_ok = (G == 0 || flags[0] != 0.) ? 1 : 0;
+    }
+}
+
+__global__ __launch_bounds__(kLmThreads) void vg_lm_reduced_solve_kernel(LmSolveArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    LmState *st = a.st;
+    if (st->done || (a.gate_expect >= 0 && st->gate != a.gate_expect)) return;
+    lm_reduced_solve_body(a, sm, threadIdx.x, blockDim.x, true);
+}
+
+// Narrow reduced systems (a mono or stereo calibration: G <= kFoldMaxG): EVERY workgroup of the back-substitution solves
+// the G x G system itself (its first wave, in LDS, the arithmetic of vg_lm_reduced_solve_kernel: every workgroup gets the
+// same bits) and goes on with the step in LDS -- one launch and one dependent round trip through HBM less per iteration; a
+// 6 x 6 .. 24 x 24 Cholesky is a few microseconds of one wave next to the launch it replaces.  Workgroup 0 publishes the
+// step and step_ok.
+constexpr int kFoldMaxG = 24;
+
+template <int kJ>
+__global__ __launch_bounds__(kBsThreads) void vg_backsub_solve_kernel(BacksubArgs b, LmSolveArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    LmState *st = a.st;
+    if (st->done || (a.gate_expect >= 0 && st->gate != a.gate_expect)) return;
+    if (gate_closed(b.s.gate, b.s.gate_expect)) return;
+    if (threadIdx.x < kWave) lm_reduced_solve_body(a, sm, threadIdx.x, kWave, blockIdx.x == 0);
+    __syncthreads();
+    backsub_body<kJ>(b, sm + (size_t)a.G * a.G + 2 * a.G);
 }
 
 struct LmAcceptArgs {

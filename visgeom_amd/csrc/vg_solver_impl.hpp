@@ -720,6 +720,14 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
     const unsigned int rows_per_group = 96;  // 16 poses per wave: enough waves to fill the chip at 5 k poses
     const unsigned int n_groups = n_rows ? (n_rows + rows_per_group - 1) / rows_per_group : 0;
     const unsigned int n_slabs = (n_groups + vg::kSlab - 1) / vg::kSlab;
+    // the fused rows + Gram launch (vg_schur_rows_gram_kernel): whole poses per workgroup, `sg_batches` batches of
+    // `sg_ppw` poses each so that the partials stay in the hundreds and the rows of a workgroup fit 48 KB of LDS
+    const int sg_ppw = vg::kSchurThreads / (G + 1);
+    int sg_batches = (int)((n_poses + (int64_t)sg_ppw * 512 - 1) / ((int64_t)sg_ppw * 512));
+    sg_batches = sg_batches < 1 ? 1 : sg_batches;
+    while (sg_batches > 1 && sizeof(double) * (size_t)sg_batches * sg_ppw * 6 * (G + 2) > 48 * 1024) sg_batches--;
+    const size_t sg_lds = sizeof(double) * (size_t)sg_batches * sg_ppw * 6 * (G + 2);
+    const unsigned int sg_wgs = (unsigned int)((n_poses + (int64_t)sg_ppw * sg_batches - 1) / ((int64_t)sg_ppw * sg_batches));
     // one device block + one pinned block for the whole solve (SolveArena); sizes: the buffers below, generously rounded
     size_t up_need = 64 * 1024 + (size_t)n_ds * 1024;
     up_need += sizeof(int) * (inv.size() + ref_ptr.size() + ref_ds.size() + ref_blk.size()) + (size_t)n_poses * (1 + sizeof(long long));
@@ -730,7 +738,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
         dev_need += 2 * sizeof(double) * ((size_t)p->dss[d].n_blocks * ww + 32) + sizeof(double) * ((size_t)p->dss[d].n_blocks / vg::kSlab + 2) * ww +
                     sizeof(double) * ((size_t)p->dss[d].n_blocks / vg::kValuImagesPerBlock + 2) * ww;  // slab / per-workgroup partial sums
     }
-    dev_need += sizeof(double) * (3 * (size_t)n_params + (size_t)n_poses * vg::kPoseRec + (size_t)n_rows * C + ((size_t)n_groups + n_slabs + 8) * C * C +
+    dev_need += sizeof(double) * (3 * (size_t)n_params + (size_t)n_poses * vg::kPoseRec + (size_t)n_rows * C + ((size_t)(n_groups > sg_wgs ? n_groups : sg_wgs) + n_slabs + 8) * C * C +
                                   (size_t)n_poses + 8 * (size_t)C * C);
     const size_t pin_need = up_need + (1u << 20) + sizeof(double) * ((size_t)n_ds * Wmax * Wmax + 4 * (size_t)C * C);
     VG_HIP(hipSetDevice(p->device));
@@ -770,7 +778,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
     VG_TRY(d_delta.alloc((size_t)n_params));
     VG_TRY(d_rec.alloc((size_t)n_poses * vg::kPoseRec));
     VG_TRY(d_rows.alloc((size_t)n_rows * C));
-    VG_TRY(d_rgroups.alloc((size_t)n_groups * C * C));
+    VG_TRY(d_rgroups.alloc((size_t)(n_groups > sg_wgs ? n_groups : sg_wgs) * C * C));
     // [Gram of the pose rows (C x C) | number of pose blocks that were not positive definite]: ONE buffer, so that the
     // count is summed over ranks by the same all-reduce and every rank takes the same accept / reject branch
     VG_TRY(d_rgram.alloc((size_t)C * C + 1));
@@ -1124,10 +1132,10 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             sa.gate = gate;
             sa.gate_expect = par;
             if (n_poses) {
-                hipLaunchKernelGGL(vg::vg_schur_rows_kernel, dim3((unsigned)((n_poses * C + 255) / 256)), dim3(256), 0, st, sa);
+                // rows of every pose + the Gram of the rows, one launch; then ONE fixed-order sum over the workgroups
+                hipLaunchKernelGGL(vg::vg_schur_rows_gram_kernel, dim3(sg_wgs), dim3(vg::kSchurThreads), sg_lds, st, sa, sg_ppw, sg_batches, d_rgroups.p);
                 VG_HIP(hipGetLastError());
-                VG_TRY(launch_dense_gram(st, d_rows.p, n_rows, C, rows_per_group, n_groups, d_rgroups.p));
-                vg::launch_strided_sum(st, d_rgroups.p, n_groups, C * C, d_rgram.p);
+                vg::launch_strided_sum(st, d_rgroups.p, sg_wgs, C * C, d_rgram.p);
                 VG_HIP(hipGetLastError());
             } else if (multi_rank) {
                 // a rank without poses still joins the sum: the buffer holds the cross-rank total of the previous iteration
@@ -1136,8 +1144,11 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             VG_TRY(vgc::allreduce_sum(comm, d_rgram.p, h_rgram.size(), st));  // Schur complement of the poses of all ranks
             vg::LmSolveArgs r2 = ra;
             r2.gate_expect = gated ? par : -1;
-            hipLaunchKernelGGL(vg::vg_lm_reduced_solve_kernel, dim3(1), dim3(G <= 64 ? vg::kWave : vg::kLmThreads), solve_lds, st, r2);
-            VG_HIP(hipGetLastError());
+            const bool fold_solve = G > 0 && G <= vg::kFoldMaxG;   // every back-substitution workgroup solves the reduced system itself
+            if (!fold_solve) {
+                hipLaunchKernelGGL(vg::vg_lm_reduced_solve_kernel, dim3(1), dim3(G <= 64 ? vg::kWave : vg::kLmThreads), solve_lds, st, r2);
+                VG_HIP(hipGetLastError());
+            }
             vg::BacksubArgs ba;
             ba.s = sa;
             ba.dg = d_dg.p;
@@ -1153,7 +1164,11 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             ba.x_new = xbuf[1 - par];   // the step is applied where it is computed: no separate launch
             if (n_poses || G) {
                 const unsigned int bs_grid = n_bs_groups ? n_bs_groups : 1u;
-                if (G < 64) hipLaunchKernelGGL(vg::vg_backsub_kernel<4>, dim3(bs_grid), dim3(vg::kBsThreads), 0, st, ba);
+                if (fold_solve) {
+                    r2.S = nullptr;  // the damped matrix in every workgroup's own LDS
+                    hipLaunchKernelGGL(vg::vg_backsub_solve_kernel<4>, dim3(bs_grid), dim3(vg::kBsThreads),
+                                       sizeof(double) * (2 * (size_t)G * G + 4 * (size_t)G + 2), st, ba, r2);
+                } else if (G < 64) hipLaunchKernelGGL(vg::vg_backsub_kernel<4>, dim3(bs_grid), dim3(vg::kBsThreads), 0, st, ba);
                 else hipLaunchKernelGGL(vg::vg_backsub_kernel<8>, dim3(bs_grid), dim3(vg::kBsThreads), 0, st, ba);
                 VG_HIP(hipGetLastError());
             }
@@ -1323,7 +1338,10 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
         bool coupled_ok = true;
         if (n_poses) {
             VG_HIP(hipMemsetAsync(d_bad, 0, sizeof(double), st));
-            hipLaunchKernelGGL(vg::vg_schur_rows_kernel, dim3((unsigned)((n_poses * C + 255) / 256)), dim3(256), 0, st, sa);
+            if (coupled.empty())
+                hipLaunchKernelGGL(vg::vg_schur_rows_gram_kernel, dim3(sg_wgs), dim3(vg::kSchurThreads), sg_lds, st, sa, sg_ppw, sg_batches, d_rgroups.p);
+            else
+                hipLaunchKernelGGL(vg::vg_schur_rows_kernel, dim3((unsigned)((n_poses * C + 255) / 256)), dim3(256), 0, st, sa);
             VG_HIP(hipGetLastError());
             // sequences coupled by odometry: raw V / g / W^T come back, the host eliminates the block-tridiagonal
             // system and puts its rows where the per-pose rows would be
@@ -1343,8 +1361,12 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
                                       hipMemcpyHostToDevice, st));
                 VG_HIP(hipStreamSynchronize(st));  // c2.Y may be rewritten before an async copy from pageable memory ends
             }
-            VG_TRY(launch_dense_gram(st, d_rows.p, n_rows, C, rows_per_group, n_groups, d_rgroups.p));
-            vg::launch_strided_sum(st, d_rgroups.p, n_groups, C * C, d_rgram.p);
+            if (coupled.empty()) {
+                vg::launch_strided_sum(st, d_rgroups.p, sg_wgs, C * C, d_rgram.p);
+            } else {
+                VG_TRY(launch_dense_gram(st, d_rows.p, n_rows, C, rows_per_group, n_groups, d_rgroups.p));
+                vg::launch_strided_sum(st, d_rgroups.p, n_groups, C * C, d_rgram.p);
+            }
             VG_HIP(hipGetLastError());
         } else if (comm && comm->n_ranks > 1) {
             VG_HIP(hipMemsetAsync(d_rgram.p, 0, sizeof(double) * h_rgram.size(), st));  // a rank without poses still joins the sum
