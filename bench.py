@@ -366,7 +366,7 @@ def main():
     roofline["measured_stream_copy_GBps"] = copy_gbs
 
     # ---- J^T J / J^T r build, ms per iteration (second half of BASELINE.json's metric) ----
-    # fused:    chain prep + evaluate-and-contract kernel (J stays on chip, FP64 MFMA) + fixed-order sum
+    # fused:    chain prep + evaluate-and-contract kernel (J stays on chip, FP64 vector pipe) + fixed-order sum
     # two-pass: chain prep + emit (J to HBM) + second pass over the materialised rows + sum
     # N > 1: every iteration ends with ONE all-reduce (RCCL) of the W x W summed block [J^T J | J^T r | r^T r].
     gram, gsum = p.alloc_gram(ds)

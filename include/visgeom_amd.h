@@ -263,8 +263,9 @@ int vg_dataset_failed_count(vg_problem *p, int dataset_id, int64_t *count);
  *    the block's own column order [intrinsics, chain member 0, ..., chain member L-1, residual].
  * ===================================================================================== */
 int vg_dataset_gram_width(const vg_problem *p, int dataset_id); /* W */
-/* fused: evaluates residuals and Jacobian rows in registers and contracts them on the matrix cores;
- * J is never written to HBM.  gram: device [n_blocks][W*W], row-major, full symmetric.  Needs
+/* fused: evaluates residuals and Jacobian rows in registers and contracts them there -- chains of one or two members on
+ * the FP64 vector pipe (products per lane, recursive-halving sum over the 32 lanes of an image), longer chains on the
+ * FP64 matrix cores; J is never written to HBM.  gram: device [n_blocks][W*W], row-major, full symmetric.  Needs
  * vg_problem_prepare at the current parameters, like vg_dataset_evaluate. */
 int vg_dataset_gram_fused(vg_problem *p, int dataset_id, double *gram);
 /* the same per-block matrices AND their fixed-order sum over the dataset's blocks (sum[W*W] device, full symmetric)
@@ -424,6 +425,19 @@ int vg_calibration_get_transform(vg_calibration *c, const char *name, int64_t in
 /* writeImageResidual(dataVec[dataset], path), :1186-1292.  sigma_out: one value per image of the dataset (NULL ok). */
 int vg_calibration_write_residuals(vg_calibration *c, int dataset, const char *path, double *sigma_out,
                                    int64_t *outliers_out);
+/* Host-only pieces of the pose initialisation, exported so that they can be checked block by block without a GPU (the
+ * front end calls the same code):
+ *   vg_reconstruct_point  ICamera::reconstructPoint (eucm.h:85-106, ucm.h:81-103, mei.h:90-112): uv[2] -> X[3] = (xn, yn, z);
+ *                         VG_ERR_NUMERIC where the reference returns false.
+ *   vg_initial_grid_pose  the 4-corner construction of estimateInitialGrid (unified_calibration.cpp:1066-1135), before its
+ *                         refinement: board4 [4][3] / corners4 [4][2] at idxUL, idxUR, idxBL, idxBR -> xi6.
+ *   vg_init_transform     getInitTransform (:311-348): chain_values [chain_len][6] = current value of every chain member
+ *                         (camera side first; the entry at init_index is not read), xi_camera = the camera-frame board pose
+ *                         -> the value of member init_index. */
+int vg_reconstruct_point(int model, const double *intrinsics, const double *uv, double *X);
+int vg_initial_grid_pose(int model, const double *intrinsics, const double *board4, const double *corners4, double *xi6);
+int vg_init_transform(int chain_len, const int *status, int init_index, const double *chain_values, const double *xi_camera,
+                      double *out6);
 /* transformFromData, include/json.h:36-67: 3 [x,y,theta] / 6 [t,rotvec] / 7 [t,qx,qy,qz,qw] / 12 row-major [R|t] */
 int vg_transform_from_values(int n, const double *values, double *out6);
 
@@ -476,6 +490,13 @@ void vg_reproject_destroy(vg_reproject_set *s);
  * of CameraJacobian::dpdxi (:75-96), dfdxi [n][6] of ::dfdxi (:99-113).  A point the camera cannot project gives zero rows. */
 int vg_camera_jacobian_evaluate(int device, void *hip_stream, int model, const double *intrinsics, const double *T12,
                                 const double *T23, int64_t n, const double *X2, const double *grad, double *dpdxi, double *dfdxi);
+
+/* ---- measurement / test hooks.  The library reads no environment variable to change what it computes or how; the A/B
+ * switches used by tests/ and tools/ are set here (process-wide, not thread safe): "inline_chain_max_bytes", "gram_force_mfma",
+ * "gram_ch1", "gram_no_merge", "max_obs_per_launch", "solver_timing", "solver_host_loop", "solver_device_loop",
+ * "solver_no_speculation"; value 0 restores the default.  A production build (without VG_DEBUG_HOOKS) has none of them and
+ * returns VG_ERR_STATE.  (VG_RCCL_LIBRARY, the path of the RCCL library to bind, is deployment configuration, not a hook.) */
+int vg_debug_set(const char *name, long long value);
 
 /* ---- measurement helpers (bench / profiling only): a pure streaming write / copy with the same
  * 16 B-per-lane access pattern as the emit kernel, to calibrate rocprofv3's WRITE_SIZE / FETCH_SIZE

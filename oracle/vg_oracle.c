@@ -1378,6 +1378,143 @@ void vgo_sparse_reproject(int model, const double *intr, const double xiBaseCam[
     free(xv2);
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Geometric pose initialisation: ICamera::reconstructPoint (eucm.h:85-106, ucm.h:81-103,
+ * mei.h:90-112), the 4-corner construction of estimateInitialGrid (src/calibration/unified_calibration.cpp:1066-1135),
+ * rotationVector (geometry_core.h:120-124 -> Quaternion(R), quaternion.h:52-59), getInitTransform (:311-348).
+ * ---------------------------------------------------------------------------------------- */
+int vgo_reconstruct_point(int model, const double *p, const double uv[2], double X[3])
+{
+    if (model == VGO_MODEL_EUCM) { /* eucm.h:85-106 */
+        const double alpha = p[0], beta = p[1], fu = p[2], fv = p[3], u0 = p[4], v0 = p[5];
+        double xn = (uv[0] - u0) / fu;
+        double yn = (uv[1] - v0) / fv;
+        double u2 = xn * xn + yn * yn;
+        double gamma = 1. - alpha;
+        double num = 1. - u2 * alpha * alpha * beta;
+        double det = 1 - (alpha - gamma) * beta * u2;
+        if (det < 0) return 0;
+        double denom = gamma + alpha * sqrt(det);
+        X[0] = xn; X[1] = yn; X[2] = num / denom;
+        return 1;
+    }
+    if (model != VGO_MODEL_UCM && model != VGO_MODEL_MEI) return 0;
+    /* ucm.h:81-103 and mei.h:90-112: the same formula (Mei ignores its distortion terms here) */
+    const double xi = p[0];
+    const double fu = model == VGO_MODEL_UCM ? p[1] : p[6], fv = model == VGO_MODEL_UCM ? p[2] : p[7];
+    const double u0 = model == VGO_MODEL_UCM ? p[3] : p[8], v0 = model == VGO_MODEL_UCM ? p[4] : p[9];
+    double xn = (uv[0] - u0) / fu;
+    double yn = (uv[1] - v0) / fv;
+    double u2 = xn * xn + yn * yn;
+    double gamma = sqrt(1. + u2 * (1 - xi * xi));
+    double etanum = -gamma - xi * u2;
+    double etadenom = xi * xi * u2 - 1;
+    X[0] = xn; X[1] = yn; X[2] = etadenom / (etadenom + xi * etanum);
+    return 1;
+}
+
+/* rotationVector(R): Quaternion(const Matrix3 &) quaternion.h:52-59, then toRotationVector */
+void vgo_rotation_vector(const double R[9], double rot[3])
+{
+    double q[4];
+    q[3] = sqrt(1.0 + (R[0] + R[4] + R[8])) / 2.0;
+    double w4 = (4.0 * q[3]);
+    q[0] = (R[7] - R[5]) / w4;
+    q[1] = (R[2] - R[6]) / w4;
+    q[2] = (R[3] - R[1]) / w4;
+    vgo_quat_to_rotvec(q, rot);
+}
+
+static void normalize3(double v[3])
+{
+    double n = norm3(v);
+    v[0] /= n; v[1] /= n; v[2] /= n;
+}
+
+static double dist3(const double a[3], const double b[3])
+{
+    double d[3] = {a[0] - b[0], a[1] - b[1], a[2] - b[2]};
+    return norm3(d);
+}
+
+/* estimateInitialGrid before its Ceres refinement (:1066-1135).  board4 / corners4: the board points and detected corners
+ * at idxUL, idxUR, idxBL, idxBR.  Returns 0 when a corner cannot be reconstructed (the reference ignores that return
+ * value and would go on with an uninitialised vector). */
+int vgo_initial_grid_pose(int model, const double *intr, const double board4[12], const double corners4[8], double xi[6])
+{
+    double XUL[3], XUR[3], XBL[3], XBR[3];
+    if (!vgo_reconstruct_point(model, intr, corners4 + 0, XUL)) return 0;
+    if (!vgo_reconstruct_point(model, intr, corners4 + 2, XUR)) return 0;
+    if (!vgo_reconstruct_point(model, intr, corners4 + 4, XBL)) return 0;
+    if (!vgo_reconstruct_point(model, intr, corners4 + 6, XBR)) return 0;
+    normalize3(XUL);
+    normalize3(XUR);
+    normalize3(XBR);
+    normalize3(XBL);
+    const double *bUL = board4, *bUR = board4 + 3, *bBL = board4 + 6, *bBR = board4 + 9;
+    double exModelU = dist3(bUR, bUL);
+    double exModelB = dist3(bBR, bBL);
+    double eyModelL = dist3(bBL, bUL);
+    double eyModelR = dist3(bBR, bUR);
+    double scaleXU = exModelU / dist3(XUR, XUL);
+    double scaleXB = exModelB / dist3(XBR, XBL);
+    double scaleYL = eyModelL / dist3(XBL, XUL);
+    double scaleYR = eyModelR / dist3(XBR, XUR);
+    double pos[3], posx[3], posy[3], ex[3], ey[3], ey2[3], ez[3];
+    const double s0 = scaleXU < scaleYL ? scaleXU : scaleYL; /* std::min */
+    const double s1 = scaleXU < scaleYR ? scaleXU : scaleYR;
+    const double s2 = scaleXB < scaleYL ? scaleXB : scaleYL;
+    for (int k = 0; k < 3; k++) {
+        pos[k] = XUL[k] * s0;
+        posx[k] = XUR[k] * s1;
+        posy[k] = XBL[k] * s2;
+        ex[k] = posx[k] - pos[k];
+        ey[k] = posy[k] - pos[k];
+    }
+    xi[0] = pos[0]; xi[1] = pos[1]; xi[2] = pos[2];
+    normalize3(ex);
+    /* ey = (Matrix3d::Identity() - ex * ex.transpose()) * ey : the matrix first, then its product with ey */
+    for (int i = 0; i < 3; i++) {
+        double m0 = (i == 0 ? 1. : 0.) - ex[i] * ex[0];
+        double m1 = (i == 1 ? 1. : 0.) - ex[i] * ex[1];
+        double m2 = (i == 2 ? 1. : 0.) - ex[i] * ex[2];
+        ey2[i] = m0 * ey[0] + m1 * ey[1] + m2 * ey[2];
+    }
+    normalize3(ey2);
+    ez[0] = ex[1] * ey2[2] - ex[2] * ey2[1]; /* ex.cross(ey) */
+    ez[1] = ex[2] * ey2[0] - ex[0] * ey2[2];
+    ez[2] = ex[0] * ey2[1] - ex[1] * ey2[0];
+    const double R[9] = {ex[0], ey2[0], ez[0], ex[1], ey2[1], ez[1], ex[2], ey2[2], ez[2]}; /* R << ex, ey, ez (columns) */
+    vgo_rotation_vector(R, xi + 3);
+    return 1;
+}
+
+/* getInitTransform (:311-348): peel the chain members before / after the one being initialised off a camera-frame pose.
+ * chain [n][6]: current value of every chain member (camera side first); init_index: the member to initialise. */
+void vgo_init_transform(int n, const int *status, int init_index, const double *chain, const double xi_in[6], double out[6])
+{
+    double xi[6], t[6];
+    memcpy(xi, xi_in, sizeof xi);
+    for (int i = 0; i < n; i++) {
+        if (i == init_index) break;
+        else if (status[i] == VGO_TRANSFORM_DIRECT) inverse_compose(chain + 6 * i, xi, t); /* getTransform(name).inverseCompose(xi) */
+        else compose_(chain + 6 * i, xi, t);                                              /* getTransform(name).compose(xi)        */
+        memcpy(xi, t, sizeof xi);
+    }
+    for (int i = n - 1; i >= 0; i--) {
+        if (i == init_index) {
+            if (status[i] == VGO_TRANSFORM_INVERSE) {
+                inverse_(xi, t);
+                memcpy(xi, t, sizeof xi);
+            }
+            break;
+        } else if (status[i] == VGO_TRANSFORM_DIRECT) vgo_compose_inverse(xi, chain + 6 * i, t); /* xi.composeInverse(getTransform) */
+        else compose_(xi, chain + 6 * i, t);                                                    /* xi.compose(getTransform)        */
+        memcpy(xi, t, sizeof xi);
+    }
+    memcpy(out, xi, sizeof xi);
+}
+
 int vgo_max_threads(void)
 {
 #ifdef _OPENMP

@@ -134,6 +134,14 @@ void vgo_mono_reproject(int model, const double *intr, const double xiBaseCam[6]
 void vgo_sparse_reproject(int model, const double *intr, const double xiBaseCam[6], int n, const double *x1, const double *x2,
                           const double *p2, const double *size, const double xiOdom[6], double *residual, double *jac);
 
+/* ---- geometric pose initialisation ---- */
+int vgo_reconstruct_point(int model, const double *intr, const double uv[2], double X[3]); /* eucm.h:85-106, ucm.h:81-103, mei.h:90-112 */
+void vgo_rotation_vector(const double R[9], double rot[3]);                               /* geometry_core.h:120-124, quaternion.h:52-59 */
+/* estimateInitialGrid's 4-corner construction (unified_calibration.cpp:1066-1135); board4 / corners4 in the order UL, UR, BL, BR */
+int vgo_initial_grid_pose(int model, const double *intr, const double board4[12], const double corners4[8], double xi[6]);
+/* getInitTransform (unified_calibration.cpp:311-348) */
+void vgo_init_transform(int n, const int *status, int init_index, const double *chain, const double xi_in[6], double out[6]);
+
 int vgo_max_threads(void);
 
 #ifdef __cplusplus

@@ -93,6 +93,14 @@ def lib():
         L.vgo_mono_reproject.argtypes = [ctypes.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
         L.vgo_sparse_reproject.restype = None
         L.vgo_sparse_reproject.argtypes = [ctypes.c_int, _dp, _dp, ctypes.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
+        L.vgo_reconstruct_point.restype = ctypes.c_int
+        L.vgo_reconstruct_point.argtypes = [ctypes.c_int, _dp, _dp, _dp]
+        L.vgo_rotation_vector.restype = None
+        L.vgo_rotation_vector.argtypes = [_dp, _dp]
+        L.vgo_initial_grid_pose.restype = ctypes.c_int
+        L.vgo_initial_grid_pose.argtypes = [ctypes.c_int, _dp, _dp, _dp, _dp]
+        L.vgo_init_transform.restype = None
+        L.vgo_init_transform.argtypes = [ctypes.c_int, _ip, ctypes.c_int, _dp, _dp, _dp]
         _lib = L
     return _lib
 
@@ -322,6 +330,34 @@ def sparse_reproject(model, intr, xi_base_cam, x1, x2, p2, size, xi_odom, want_j
     lib().vgo_sparse_reproject(model, _ptr(intr), _ptr(xb), n, _ptr(x1), _ptr(x2), _ptr(p2), _ptr(size), _ptr(xo), _ptr(r),
                                _ptr(J) if want_jac else None)
     return r, J
+
+
+# ---- geometric pose initialisation ----
+def reconstruct_point(model, intr, uv):
+    intr, uv, X = _c(intr), _c(uv), np.full(3, np.nan)
+    ok = lib().vgo_reconstruct_point(model, _ptr(intr), _ptr(uv), _ptr(X))
+    return bool(ok), X
+
+
+def rotation_vector(R):
+    R, r = _c(np.asarray(R, float).ravel()), np.empty(3)
+    lib().vgo_rotation_vector(_ptr(R), _ptr(r))
+    return r
+
+
+def initial_grid_pose(model, intr, board4, corners4):
+    """estimateInitialGrid's 4-corner construction; board4 [4, 3] / corners4 [4, 2] in the order UL, UR, BL, BR"""
+    intr, b, c, xi = _c(intr), _c(board4).reshape(12), _c(corners4).reshape(8), np.full(6, np.nan)
+    ok = lib().vgo_initial_grid_pose(model, _ptr(intr), _ptr(b), _ptr(c), _ptr(xi))
+    return bool(ok), xi
+
+
+def init_transform(status, init_index, chain, xi):
+    """getInitTransform: chain [n, 6] current values of the members, xi the camera-frame pose"""
+    chain, xi, out = _c(chain).reshape(-1, 6), _c(xi), np.empty(6)
+    st = (ctypes.c_int * max(len(status), 1))(*[int(s) for s in status])
+    lib().vgo_init_transform(chain.shape[0], st, int(init_index), _ptr(chain), _ptr(xi), _ptr(out))
+    return out
 
 
 def max_threads():

@@ -189,15 +189,18 @@ def test_full_size_10k_gram_properties(vg):
     p.close()
 
 
-def test_matrix_core_kernels_for_narrow_blocks():
-    """VG_GRAM_FORCE_MFMA=1 (read once per process) sends the single-member chains to vg_gram_fused_kernel as well --
-    one 16 x 16 tile for W <= 16, the RCOL variant (16 Jacobian columns in the tile, residual column on the lanes) for
-    Mei's W = 17: the same cases, the same bars, in a process of their own."""
-    import os
-    import subprocess
-    import sys
+def test_matrix_core_kernels_for_narrow_blocks(vg):
+    """vg_debug_set("gram_force_mfma", 1) sends the single-member chains to vg_gram_fused_kernel as well -- one 16 x 16 tile
+    for W <= 16, the RCOL variant (16 Jacobian columns in the tile, residual column on the lanes) for Mei's W = 17: the same
+    cases, the same bars"""
+    from visgeom_amd import capi
 
-    env = dict(os.environ, VG_GRAM_FORCE_MFMA="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k",
-                        "test_gram_fused_two_pass_and_sum or failed_projections"], env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    capi.debug_set("gram_force_mfma", 1)
+    try:
+        for c in CASES:
+            test_gram_fused_two_pass_and_sum(vg, *c)
+        test_gram_with_failed_projections_matches_ceres_semantics(vg)
+    finally:
+        capi.debug_set("gram_force_mfma", 0)
+    with pytest.raises(capi.VisgeomError):
+        capi.debug_set("no_such_hook", 1)

@@ -381,7 +381,7 @@ def test_evaluate_to_host_delivers_the_same_rows(vg, S):
 
 def test_chunked_launches_for_huge_datasets(vg, S, monkeypatch):
     """datasets beyond 2^30 observations are evaluated in several launches of whole images; the chunking is
-    exercised here by lowering the per-launch limit (VG_MAX_OBS_PER_LAUNCH) instead of allocating 240 GB"""
+    exercised here by lowering the per-launch limit (vg_debug_set("max_obs_per_launch")) instead of allocating 240 GB"""
     import torch
 
     d = S.make_mono("eucm", 37, 2)
@@ -395,9 +395,14 @@ def test_chunked_launches_for_huge_datasets(vg, S, monkeypatch):
     p.prepare()
     p.evaluate_dataset(ds, *ref)
     p.synchronize()
-    monkeypatch.setenv("VG_MAX_OBS_PER_LAUNCH", str(5 * 96 + 17))   # 5 images per launch -> 8 launches
-    p.evaluate_dataset(ds, *out)
-    p.synchronize()
+    from visgeom_amd import capi
+
+    capi.debug_set("max_obs_per_launch", 5 * 96 + 17)   # 5 images per launch -> 8 launches
+    try:
+        p.evaluate_dataset(ds, *out)
+        p.synchronize()
+    finally:
+        capi.debug_set("max_obs_per_launch", 0)
     assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1]) and torch.equal(out[2][0], ref[2][0])
     p.close()
 

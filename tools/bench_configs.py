@@ -21,6 +21,9 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from visgeom_amd import CalibrationProblem, synthetic  # noqa: E402
+from visgeom_amd import capi as _capi  # noqa: E402
+
+_capi.hooks_from_env()  # legacy VG_* switches -> vg_debug_set
 
 _args = [a for a in sys.argv[1:]]
 ONLY_CONFIG = int(_args[_args.index("--config") + 1]) if "--config" in _args else None

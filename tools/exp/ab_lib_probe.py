@@ -3,6 +3,9 @@ import os, sys, time, torch
 root = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 sys.path.insert(0, root)
 from visgeom_amd import _build
+from visgeom_amd import capi as _capi  # noqa: E402
+
+_capi.hooks_from_env()  # legacy VG_* switches -> vg_debug_set
 if os.environ.get("AB_LIB"):
     _build.LIB = os.path.join(root, os.environ["AB_LIB"])
 from visgeom_amd import CalibrationProblem, synthetic

@@ -3,6 +3,9 @@ import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np
 from visgeom_amd import GenericProjectionJac, synthetic
+from visgeom_amd import capi as _capi  # noqa: E402
+
+_capi.hooks_from_env()  # legacy VG_* switches -> vg_debug_set
 d = synthetic.make_mono("eucm", 4, 2)
 cases = (([0], [d["init_intrinsics"], d["init_poses"][0]]),
          ([1, 0], [d["init_intrinsics"], np.array([0.1, 0, 0, 0.01, 0, 0.0]), d["init_poses"][0]]))

@@ -1,6 +1,9 @@
 import os, sys, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from visgeom_amd import CalibrationProblem, synthetic
+from visgeom_amd import capi as _capi  # noqa: E402
+
+_capi.hooks_from_env()  # legacy VG_* switches -> vg_debug_set
 for model in ("mei", "eucm"):
   for cfg in (1, 4):
     d = synthetic.make_mono(model, 10000, cfg)

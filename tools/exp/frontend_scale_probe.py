@@ -2,6 +2,9 @@ import os, sys, time, tempfile
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np
 from visgeom_amd import synthetic as S
+from visgeom_amd import capi as _capi  # noqa: E402
+
+_capi.hooks_from_env()  # legacy VG_* switches -> vg_debug_set
 from visgeom_amd.calibration import GenericCameraCalibration
 n = int(sys.argv[1])
 d = S.make_mono("eucm", n, 0, sigma=0.1)

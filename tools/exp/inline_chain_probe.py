@@ -2,6 +2,9 @@
 import os, sys, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from visgeom_amd import CalibrationProblem, synthetic
+from visgeom_amd import capi as _capi  # noqa: E402
+
+_capi.hooks_from_env()  # legacy VG_* switches -> vg_debug_set
 n = int(sys.argv[1])
 model = sys.argv[2] if len(sys.argv) > 2 else "eucm"
 d = synthetic.make_mono(model, n, 1)

@@ -1,6 +1,9 @@
 import os, sys, time, torch, numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from visgeom_amd import CalibrationProblem, synthetic
+from visgeom_amd import capi as _capi  # noqa: E402
+
+_capi.hooks_from_env()  # legacy VG_* switches -> vg_debug_set
 model = sys.argv[1] if len(sys.argv) > 1 else "eucm"
 d = synthetic.make_mono(model, 10000, 1)
 p = CalibrationProblem(0)

@@ -7,6 +7,9 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 import numpy as np
 
 from visgeom_amd import synthetic as S
+from visgeom_amd import capi as _capi  # noqa: E402
+
+_capi.hooks_from_env()  # legacy VG_* switches -> vg_debug_set
 from visgeom_amd.problem import CalibrationProblem
 
 model = sys.argv[1] if len(sys.argv) > 1 else "eucm"

@@ -1,6 +1,9 @@
 import os, sys
 sys.path.insert(0, "/root/repo")
 from visgeom_amd import synthetic as S
+from visgeom_amd import capi as _capi  # noqa: E402
+
+_capi.hooks_from_env()  # legacy VG_* switches -> vg_debug_set
 from visgeom_amd.problem import CalibrationProblem
 model = sys.argv[1]; n = int(sys.argv[2])
 d = S.make_mono(model, n, 1 if model == "eucm" else 4)

@@ -1,6 +1,9 @@
 import os, sys, time, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from visgeom_amd import CalibrationProblem, synthetic
+from visgeom_amd import capi as _capi  # noqa: E402
+
+_capi.hooks_from_env()  # legacy VG_* switches -> vg_debug_set
 d = synthetic.make_mono("eucm", 10000, 1)
 p = CalibrationProblem(0)
 cam = p.add_camera("eucm", d["init_intrinsics"]); seq = p.add_transform(False, d["init_poses"])

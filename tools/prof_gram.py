@@ -7,6 +7,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
 from visgeom_amd import CalibrationProblem, synthetic  # noqa: E402
+from visgeom_amd import capi as _capi  # noqa: E402
+
+_capi.hooks_from_env()  # legacy VG_* switches -> vg_debug_set
 
 model = sys.argv[1] if len(sys.argv) > 1 else "eucm"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 10000

@@ -16,6 +16,9 @@ LIB = os.path.join(LIB_DIR, "libvisgeom_amd.so")
 # kernel is HBM bound, the extra VALU instructions are not on the critical path.
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
                "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+# the A/B and test switches behind vg_debug_set(); VG_PRODUCTION=1 builds the library without them
+if not os.environ.get("VG_PRODUCTION"):
+    HIPCC_FLAGS.append("-DVG_DEBUG_HOOKS")
 
 
 def sources():
@@ -31,11 +34,27 @@ def _deps():
     return out
 
 
+STAMP = os.path.join(LIB_DIR, "libvisgeom_amd.sources.sha256")
+
+
+def sources_digest():
+    """sha256 over the compiler flags and the CONTENT of every source / header the library is built from (a snapshot copied
+    to another machine has fresh mtimes everywhere: modification times say nothing about what a library was built from)"""
+    import hashlib
+
+    h = hashlib.sha256(" ".join(HIPCC_FLAGS).encode())
+    for f in sorted(_deps()):
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def up_to_date():
-    if not os.path.exists(LIB) or not os.path.exists(os.path.join(PKG, "bin", "calib")):
+    if not os.path.exists(LIB) or not os.path.exists(os.path.join(PKG, "bin", "calib")) or not os.path.exists(STAMP):
         return False
-    t = os.path.getmtime(LIB)
-    return all(os.path.getmtime(f) <= t for f in _deps())
+    with open(STAMP) as fh:
+        return fh.read().strip() == sources_digest()
 
 
 def build(force=False, verbose=False):
@@ -50,6 +69,8 @@ def build(force=False, verbose=False):
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
     build_cli(verbose)
+    with open(STAMP, "w") as fh:
+        fh.write(sources_digest() + "\n")
     return LIB
 
 

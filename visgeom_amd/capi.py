@@ -144,6 +144,9 @@ SIGNATURES = {
     "vg_calibration_get_intrinsics": (ctypes.c_int, [_vp, ctypes.c_char_p, _dp, _ip]),
     "vg_calibration_get_transform": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_int64, _dp, _i64p]),
     "vg_calibration_write_residuals": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_char_p, _dp, _i64p]),
+    "vg_reconstruct_point": (ctypes.c_int, [ctypes.c_int, _dp, _dp, _dp]),
+    "vg_initial_grid_pose": (ctypes.c_int, [ctypes.c_int, _dp, _dp, _dp, _dp]),
+    "vg_init_transform": (ctypes.c_int, [ctypes.c_int, _ip, ctypes.c_int, _dp, _dp, _dp]),
     "vg_transform_from_values": (ctypes.c_int, [ctypes.c_int, _dp, _dp]),
     "vg_sparse_reproject_create": (ctypes.c_int, [_vpp, ctypes.c_int, _vp, ctypes.c_int, _dp, _dp, ctypes.c_int64, _i64p, _dp, _dp, _dp, _dp]),
     "vg_mono_reproject_create": (ctypes.c_int, [_vpp, ctypes.c_int, _vp, ctypes.c_int, _dp, _dp, ctypes.c_int64, _dp, _dp]),
@@ -157,6 +160,7 @@ SIGNATURES = {
     "vg_reproject_synchronize": (ctypes.c_int, [_vp]),
     "vg_reproject_destroy": (None, [_vp]),
     "vg_camera_jacobian_evaluate": (ctypes.c_int, [ctypes.c_int, _vp, ctypes.c_int, _dp, _dp, _dp, ctypes.c_int64, _vp, _vp, _vp, _vp]),
+    "vg_debug_set": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_longlong]),
     "vg_calib_stream_write": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_double]),
     "vg_calib_stream_copy": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64]),
 }
@@ -203,3 +207,21 @@ def load():
 def check(code):
     if code != OK:
         raise VisgeomError(code, load().vg_last_error().decode("utf-8", "replace"))
+
+
+def debug_set(name, value):
+    """measurement / test hook of the library (vg_debug_set): value 0 restores the default"""
+    check(load().vg_debug_set(name.encode(), int(value)))
+
+
+def hooks_from_env():
+    """tools/exp probes only: the A/B switches used to be environment variables of the library (VG_GRAM_FORCE_MFMA=1 ...);
+    the library no longer reads any, this maps the old names onto vg_debug_set so that the probes still run"""
+    legacy = {"VG_INLINE_CHAIN_MAX_BYTES": "inline_chain_max_bytes", "VG_GRAM_FORCE_MFMA": "gram_force_mfma", "VG_GRAM_CH1": "gram_ch1",
+              "VG_GRAM_NO_MERGE": "gram_no_merge", "VG_MAX_OBS_PER_LAUNCH": "max_obs_per_launch", "VG_SOLVER_TIMING": "solver_timing",
+              "VG_SOLVER_HOST_LOOP": "solver_host_loop", "VG_SOLVER_DEVICE_LOOP": "solver_device_loop",
+              "VG_SOLVER_NO_SPECULATION": "solver_no_speculation"}
+    for env, name in legacy.items():
+        if env in os.environ:
+            v = os.environ[env]
+            debug_set(name, int(v) if v.lstrip("-").isdigit() else 1)

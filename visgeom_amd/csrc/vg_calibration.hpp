@@ -248,37 +248,28 @@ inline void refine_on_gpu(vg_calibration *c, const ImageData &data, const std::v
     vg_problem_destroy(p);
 }
 
-// geometric part of estimateInitialGrid  unified_calibration.cpp:1066-1135
-inline Array6d estimate_initial_grid_geometric(vg_calibration *c, const ImageData &data, int gridIdx)
+// geometric part of estimateInitialGrid  unified_calibration.cpp:1066-1135, on plain arrays: b* / c* = board point and
+// detected corner at idxUL / idxUR / idxBL / idxBR.  Returns the index (0..3) of a corner that cannot be reconstructed, -1 on
+// success.  (Also behind the host-only C entry vg_initial_grid_pose, so the construction can be checked without a GPU.)
+inline int initial_grid_pose(int model, const double *intr, const double *bUL, const double *bUR, const double *bBL, const double *bBR,
+                             const double *cUL, const double *cUR, const double *cBL, const double *cBR, double *xi)
 {
-    const std::vector<double> &cv = data.detectedCornersVec[(size_t)gridIdx];
-    const int model = c->cameraModelMap[data.cameraName];
-    const double *intr = c->intrinsicMap[data.cameraName].data();
-    auto recon = [&](int idx, double *X) {
-        // the reference ignores reconstructPoint's return value (:1081-1084) and would go on with an uninitialised
-        // vector; a corner outside the model's valid image region at the initial intrinsics is reported instead
-        if (!reconstruct_point(model, intr, &cv[2 * (size_t)idx], X))
-            throw Error{VG_ERR_INVALID_ARGUMENT, "image " + std::to_string(gridIdx) + ": corner " + std::to_string(idx) +
-                                                     " cannot be reconstructed with the initial intrinsics of " + data.cameraName +
-                                                     " (outside the model's image region); cannot initialise the pose"};
+    double XUL[3], XUR[3], XBL[3], XBR[3];
+    const double *cs[4] = {cUL, cUR, cBL, cBR};
+    double *Xs[4] = {XUL, XUR, XBL, XBR};
+    for (int q = 0; q < 4; q++) {
+        if (!reconstruct_point(model, intr, cs[q], Xs[q])) return q;
+        double *X = Xs[q];
         const double n = std::sqrt(X[0] * X[0] + X[1] * X[1] + X[2] * X[2]);
         for (int k = 0; k < 3; k++) X[k] /= n;
-    };
-    double XUL[3], XUR[3], XBL[3], XBR[3];
-    recon(data.idxUL, XUL);
-    recon(data.idxUR, XUR);
-    recon(data.idxBL, XBL);
-    recon(data.idxBR, XBR);
+    }
     auto dist3 = [](const double *a, const double *b) {
         return std::sqrt((a[0] - b[0]) * (a[0] - b[0]) + (a[1] - b[1]) * (a[1] - b[1]) + (a[2] - b[2]) * (a[2] - b[2]));
     };
-    const double *bUL = data.board[(size_t)data.idxUL].data(), *bUR = data.board[(size_t)data.idxUR].data();
-    const double *bBL = data.board[(size_t)data.idxBL].data(), *bBR = data.board[(size_t)data.idxBR].data();
     const double scaleXU = dist3(bUR, bUL) / dist3(XUR, XUL);
     const double scaleXB = dist3(bBR, bBL) / dist3(XBR, XBL);
     const double scaleYL = dist3(bBL, bUL) / dist3(XBL, XUL);
     const double scaleYR = dist3(bBR, bUR) / dist3(XBR, XUR);
-    Array6d xi = {0, 0, 1, 0, 0, 0};
     double pos[3], posx[3], posy[3], ex[3], ey[3], ez[3];
     for (int k = 0; k < 3; k++) {
         pos[k] = XUL[k] * std::min(scaleXU, scaleYL);
@@ -298,29 +289,59 @@ inline Array6d estimate_initial_grid_geometric(vg_calibration *c, const ImageDat
     ez[1] = ex[2] * ey[0] - ex[0] * ey[2];
     ez[2] = ex[0] * ey[1] - ex[1] * ey[0];
     const double R[9] = {ex[0], ey[0], ez[0], ex[1], ey[1], ez[1], ex[2], ey[2], ez[2]};  // R << ex, ey, ez (columns)
-    rotvec_from_matrix(R, xi.data() + 3);
+    rotvec_from_matrix(R, xi + 3);
+    return -1;
+}
+
+inline Array6d estimate_initial_grid_geometric(vg_calibration *c, const ImageData &data, int gridIdx)
+{
+    const std::vector<double> &cv = data.detectedCornersVec[(size_t)gridIdx];
+    const int model = c->cameraModelMap[data.cameraName];
+    const double *intr = c->intrinsicMap[data.cameraName].data();
+    const int idx[4] = {data.idxUL, data.idxUR, data.idxBL, data.idxBR};
+    Array6d xi = {0, 0, 1, 0, 0, 0};
+    const int bad = initial_grid_pose(model, intr, data.board[(size_t)idx[0]].data(), data.board[(size_t)idx[1]].data(),
+                                      data.board[(size_t)idx[2]].data(), data.board[(size_t)idx[3]].data(), &cv[2 * (size_t)idx[0]],
+                                      &cv[2 * (size_t)idx[1]], &cv[2 * (size_t)idx[2]], &cv[2 * (size_t)idx[3]], xi.data());
+    // the reference ignores reconstructPoint's return value (:1081-1084) and would go on with an uninitialised vector; a
+    // corner outside the model's valid image region at the initial intrinsics is reported instead
+    if (bad >= 0)
+        throw Error{VG_ERR_INVALID_ARGUMENT, "image " + std::to_string(gridIdx) + ": corner " + std::to_string(idx[bad]) +
+                                                 " cannot be reconstructed with the initial intrinsics of " + data.cameraName +
+                                                 " (outside the model's image region); cannot initialise the pose"};
     return xi;
 }
 
-// getInitTransform  unified_calibration.cpp:311-348 : peel the other chain members off the camera-frame pose
+// getInitTransform  unified_calibration.cpp:311-348 on plain arrays: peel the other chain members (current values
+// chain[i], statuses status[i]) off the camera-frame pose xi; init_index = the member being initialised
+inline Array6d init_transform(int n, const int *status, int init_index, const Array6d *chain, Array6d xi)
+{
+    for (int i = 0; i < n; i++) {
+        if (i == init_index) break;
+        else if (status[i] == VG_TRANSFORM_DIRECT) xi = inverse_compose(chain[i], xi);
+        else xi = compose(chain[i], xi);
+    }
+    for (int i = n - 1; i >= 0; i--) {
+        if (i == init_index) {
+            if (status[i] == VG_TRANSFORM_INVERSE) xi = inverse(xi);
+            break;
+        } else if (status[i] == VG_TRANSFORM_DIRECT) xi = compose_inverse(xi, chain[i]);
+        else xi = compose(xi, chain[i]);
+    }
+    return xi;
+}
+
 inline Array6d get_init_transform(vg_calibration *c, Array6d xi, const std::string &initName, const ImageData &data,
                                   int transfIdx)
 {
-    for (size_t i = 0; i < data.transNameVec.size(); i++) {
-        const std::string &name = data.transNameVec[i];
-        if (name == initName) break;
-        else if (data.transStatusVec[i] == VG_TRANSFORM_DIRECT) xi = inverse_compose(c->getTransformData(name, transfIdx), xi);
-        else xi = compose(c->getTransformData(name, transfIdx), xi);
+    const int n = (int)data.transNameVec.size();
+    std::vector<Array6d> chain((size_t)n);
+    int init_index = n;  // a name that is not in the chain: every member is peeled off by the first loop, as in the reference
+    for (int i = 0; i < n; i++) {
+        if (data.transNameVec[(size_t)i] == initName && init_index == n) init_index = i;
+        else chain[(size_t)i] = c->getTransformData(data.transNameVec[(size_t)i], transfIdx);
     }
-    for (int i = (int)data.transNameVec.size() - 1; i >= 0; i--) {
-        const std::string &name = data.transNameVec[(size_t)i];
-        if (name == initName) {
-            if (data.transStatusVec[(size_t)i] == VG_TRANSFORM_INVERSE) xi = inverse(xi);
-            break;
-        } else if (data.transStatusVec[(size_t)i] == VG_TRANSFORM_DIRECT) xi = compose_inverse(xi, c->getTransformData(name, transfIdx));
-        else xi = compose(xi, c->getTransformData(name, transfIdx));
-    }
-    return xi;
+    return init_transform(n, data.transStatusVec.data(), init_index, chain.data(), xi);
 }
 
 // estimateInitialGrid for a set of images at once: geometric estimate, then (unless do_not_solve) the refinement of
@@ -696,6 +717,32 @@ int vg_transform_from_values(int n, const double *values, double *out6)
     std::string err;
     if (!vgcal::transform_from_values(std::vector<double>(values, values + n), x, err)) return vgi::fail(VG_ERR_INVALID_ARGUMENT, err);
     std::memcpy(out6, x.data(), sizeof(double) * 6);
+    return VG_OK;
+}
+
+int vg_reconstruct_point(int model, const double *intrinsics, const double *uv, double *X)
+{
+    if (vg::num_intrinsics(model) < 0 || !intrinsics || !uv || !X) return vgi::fail(VG_ERR_INVALID_ARGUMENT, "bad arguments");
+    return vgcal::reconstruct_point(model, intrinsics, uv, X) ? VG_OK : vgi::fail(VG_ERR_NUMERIC, "the point is outside the model's image region");
+}
+
+int vg_initial_grid_pose(int model, const double *intrinsics, const double *board4, const double *corners4, double *xi6)
+{
+    if (vg::num_intrinsics(model) < 0 || !intrinsics || !board4 || !corners4 || !xi6) return vgi::fail(VG_ERR_INVALID_ARGUMENT, "bad arguments");
+    const int bad = vgcal::initial_grid_pose(model, intrinsics, board4, board4 + 3, board4 + 6, board4 + 9, corners4, corners4 + 2, corners4 + 4,
+                                             corners4 + 6, xi6);
+    return bad < 0 ? VG_OK : vgi::fail(VG_ERR_NUMERIC, "corner " + std::to_string(bad) + " of the four cannot be reconstructed with these intrinsics");
+}
+
+int vg_init_transform(int chain_len, const int *status, int init_index, const double *chain_values, const double *xi_camera, double *out6)
+{
+    if (chain_len < 0 || chain_len > VG_MAX_CHAIN || (chain_len && (!status || !chain_values)) || !xi_camera || !out6)
+        return vgi::fail(VG_ERR_INVALID_ARGUMENT, "bad arguments");
+    vgcal::Array6d chain[VG_MAX_CHAIN], xi;
+    for (int i = 0; i < chain_len; i++) std::memcpy(chain[i].data(), chain_values + 6 * i, sizeof(double) * 6);
+    std::memcpy(xi.data(), xi_camera, sizeof(double) * 6);
+    const vgcal::Array6d r = vgcal::init_transform(chain_len, status, init_index, chain, xi);
+    std::memcpy(out6, r.data(), sizeof(double) * 6);
     return VG_OK;
 }
 

@@ -83,11 +83,8 @@ size_t emit_lds_bytes(bool want_jac, bool frames_lds, int N, int frame_stride)
 // tools/exp/inline_chain_probe.py
 int64_t inline_chain_max_bytes()
 {
-    static const int64_t v = [] {
-        const char *e = getenv("VG_INLINE_CHAIN_MAX_BYTES");  // measurement hook
-        return e ? (int64_t)atoll(e) : (int64_t)288000000;
-    }();
-    return v;
+    const long long h = vgi::debug_hook(vgi::kHookInlineChainMaxBytes);
+    return h ? (int64_t)h : (int64_t)288000000;
 }
 
 bool emit_frames_in_lds(int N, int frame_stride)
@@ -220,7 +217,7 @@ int launch_gram_fused(hipStream_t stream, const vg::GramArgs &a)
 // DIRECT member is walked in-kernel.  Both are pure functions of the problem (never of call history).
 bool gram_uses_valu(const vg_problem *p, const Dataset &d)
 {
-    static const bool force_mfma = getenv("VG_GRAM_FORCE_MFMA") != nullptr;  // measurement hook (A/B of the two kernels)
+    const bool force_mfma = vgi::debug_hook(vgi::kHookGramForceMfma) != 0;  // measurement hook (A/B of the two kernels)
     return !force_mfma && d.L <= 2 && p->cams[d.camera].K + 6 * d.L + 1 <= vg::kValuMaxW;
 }
 
@@ -249,7 +246,7 @@ int launch_gram_valu_lch(hipStream_t stream, const vg::GramValuArgs &a, bool inl
 template <int MODEL, int L>
 int launch_gram_valu_l(hipStream_t stream, const vg::GramValuArgs &a, bool inline_chain)
 {
-    static const bool force_ch1 = getenv("VG_GRAM_CH1") != nullptr;  // measurement hook
+    const bool force_ch1 = vgi::debug_hook(vgi::kHookGramCh1) != 0;  // measurement hook
     constexpr int W = vg::CameraTraits<MODEL>::K + 6 * L + 1;
     constexpr int kMain = W <= 13 ? 3 : (W <= 19 ? 2 : 1);
     if constexpr (kMain > 1)
@@ -267,7 +264,32 @@ int launch_gram_valu(hipStream_t stream, const vg::GramValuArgs &a, int L, bool 
 
 }  // namespace
 
+#ifdef VG_DEBUG_HOOKS
+namespace {
+long long g_debug_hooks[vgi::kHookCount] = {0};
+const char *const kDebugHookNames[vgi::kHookCount] = {"inline_chain_max_bytes", "gram_force_mfma", "gram_ch1", "gram_no_merge", "max_obs_per_launch",
+                                                      "solver_timing", "solver_host_loop", "solver_device_loop", "solver_no_speculation"};
+}  // namespace
+long long vgi::debug_hook(vgi::DebugHook h) { return g_debug_hooks[h]; }
+#endif
+
 extern "C" {
+
+int vg_debug_set(const char *name, long long value)
+{
+    if (!name) return fail(VG_ERR_INVALID_ARGUMENT, "name is NULL");
+#ifdef VG_DEBUG_HOOKS
+    for (int k = 0; k < vgi::kHookCount; k++)
+        if (std::strcmp(name, kDebugHookNames[k]) == 0) {
+            g_debug_hooks[k] = value;
+            return VG_OK;
+        }
+    return fail(VG_ERR_INVALID_ARGUMENT, std::string("unknown debug hook: ") + name);
+#else
+    (void)value;
+    return fail(VG_ERR_STATE, "this build has no debug hooks (built without VG_DEBUG_HOOKS)");
+#endif
+}
 
 int vg_abi_version(void) { return VG_ABI_VERSION; }
 
@@ -705,7 +727,7 @@ int vg_dataset_evaluate(vg_problem *p, int dataset_id, double *residuals, double
 
     // 32-bit observation indices inside a launch: chunk very large datasets by whole images
     int64_t max_obs = (int64_t)1 << 30;
-    if (const char *e = getenv("VG_MAX_OBS_PER_LAUNCH")) max_obs = atoll(e) > 0 ? atoll(e) : max_obs;  // test hook for the chunked path
+    if (const long long h = vgi::debug_hook(vgi::kHookMaxObsPerLaunch)) max_obs = h > 0 ? h : max_obs;  // test hook for the chunked path
     const int64_t max_blocks_per_launch = max_obs / d.N > 0 ? max_obs / d.N : 1;
     for (int64_t b0 = 0; b0 < d.n_blocks; b0 += max_blocks_per_launch) {
         const int64_t nb = d.n_blocks - b0 < max_blocks_per_launch ? d.n_blocks - b0 : max_blocks_per_launch;
@@ -897,7 +919,7 @@ int vgi::gram_fused_at(vg_problem *p, int dataset_id, const double *d_params, do
 
 bool vgi::gram_merge_covers_all(const vg_problem *p)
 {
-    if (getenv("VG_GRAM_NO_MERGE") || getenv("VG_GRAM_CH1")) return false;
+    if (vgi::debug_hook(vgi::kHookGramNoMerge) || vgi::debug_hook(vgi::kHookGramCh1)) return false;
     int n = 0;
     for (const Dataset &d : p->dss) {
         if (!d.n_blocks) continue;
@@ -910,7 +932,7 @@ bool vgi::gram_merge_covers_all(const vg_problem *p)
 int vgi::gram_fused_merged_at(vg_problem *p, const double *d_params, double *const *grams, std::vector<char> &taken,
                               double *const *partials)
 {
-    static const bool off = getenv("VG_GRAM_NO_MERGE") != nullptr || getenv("VG_GRAM_CH1") != nullptr;  // measurement hooks
+    const bool off = vgi::debug_hook(vgi::kHookGramNoMerge) != 0 || vgi::debug_hook(vgi::kHookGramCh1) != 0;  // measurement hooks
     const int n_ds = (int)p->dss.size();
     taken.assign((size_t)n_ds, 0);
     std::vector<int> ids;

@@ -16,6 +16,28 @@ namespace vgi {
 
 int fail(int code, const std::string &msg);
 
+// Measurement / test hooks (A/B switches of the kernels, the chunked-launch test): a process-wide table set through
+// vg_debug_set() -- the library reads NO environment variable for them.  Built without VG_DEBUG_HOOKS (a production build:
+// VG_PRODUCTION=1 python -m visgeom_amd._build) the table does not exist, every hook is its default at compile time and
+// vg_debug_set() fails.
+enum DebugHook {
+    kHookInlineChainMaxBytes = 0,  // largest evaluation (bytes) whose single-member chain is walked in the emit kernel
+    kHookGramForceMfma,            // single-member chains on the matrix-core Gram kernel as well
+    kHookGramCh1,                  // one corner per lane in the vector-pipe Gram kernel
+    kHookGramNoMerge,              // one Gram launch per dataset
+    kHookMaxObsPerLaunch,          // chunk size of the emit launches (the chunked path without a 240 GB problem)
+    kHookSolverTiming,             // print where the solver's set-up time goes
+    kHookSolverHostLoop,           // force the host-driven LM loop
+    kHookSolverDeviceLoop,         // force the device-resident LM loop
+    kHookSolverNoSpeculation,      // queue one LM iteration at a time
+    kHookCount
+};
+#ifdef VG_DEBUG_HOOKS
+long long debug_hook(DebugHook h);  // 0 = unset
+#else
+constexpr long long debug_hook(DebugHook) { return 0; }
+#endif
+
 #define VG_HIP(expr)                                                                              \
     do {                                                                                          \
         hipError_t e_ = (expr);                                                                   \

@@ -556,7 +556,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
     hipStream_t st = p->stream;
     const double t_start = now_s();
     double t_eval = 0., t_schur = 0., t_host = 0.;
-    static const bool trace_setup = getenv("VG_SOLVER_TIMING") != nullptr;  // measurement hook: where the set-up time goes
+    const bool trace_setup = vgi::debug_hook(vgi::kHookSolverTiming) != 0;  // measurement hook: where the set-up time goes
     double t_mark = t_start;
     auto mark = [&](const char *what) {
         if (!trace_setup) return;
@@ -986,9 +986,9 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
     // Measured (tools/exp/solve_probe.py, tools/prof_solve.py, one MI355X): 10 k EUCM images 0.110 ms per iteration
     // against 0.21 for the host-driven loop, Mei 0.118; the 45-column rig 0.338 against 0.293 -- there the one-workgroup
     // factorisation of the reduced system costs more than the host's round trip, so wide systems keep the host loop.
-    // VG_SOLVER_HOST_LOOP / VG_SOLVER_DEVICE_LOOP force a side.
-    static const bool force_host_loop = getenv("VG_SOLVER_HOST_LOOP") != nullptr;      // measurement / A-B hooks
-    static const bool force_device_loop = getenv("VG_SOLVER_DEVICE_LOOP") != nullptr;
+    // vg_debug_set("solver_host_loop" / "solver_device_loop") force a side.
+    const bool force_host_loop = vgi::debug_hook(vgi::kHookSolverHostLoop) != 0;      // measurement / A-B hooks (vg_debug_set)
+    const bool force_device_loop = vgi::debug_hook(vgi::kHookSolverDeviceLoop) != 0;
     if (coupled.empty() && p->priors.empty() && !opt.allreduce && !force_host_loop && (G <= 32 || force_device_loop)) {
         DevBuf<vg::LmState> d_state;
         DevBuf<double> d_U, d_gvec, d_S, d_xcur;
@@ -1080,8 +1080,8 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
         // MEASURED (tools/exp/solve_probe.py, 10 k images, state published by the accept kernel itself): EUCM 0.111 vs
         // 0.115 ms per iteration, Mei 0.119 vs 0.126 -- the iteration is bound by its eight dependent launches on the GPU.
         // Replaying the gated iteration as a hipGraph (one per parity) was slower than queueing its launches: 0.120 /
-        // 0.126 ms (profiles/NOTES.md).  VG_SOLVER_NO_SPECULATION=1 queues one iteration at a time.
-        const bool speculate = opt.soft_l1_scale <= 0. && !multi_rank && getenv("VG_SOLVER_NO_SPECULATION") == nullptr;
+        // 0.126 ms (profiles/NOTES.md).  vg_debug_set("solver_no_speculation", 1) queues one iteration at a time.
+        const bool speculate = opt.soft_l1_scale <= 0. && !multi_rank && !vgi::debug_hook(vgi::kHookSolverNoSpeculation);
         DevBuf<double> *gset[2] = {gramA, gramB};
         vg::SolveDatasetDev *dset[2] = {d_dsA.p, d_dsB.p};
         double *xbuf[2] = {d_x.p, d_xc.p};
