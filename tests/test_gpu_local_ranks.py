@@ -216,3 +216,50 @@ def test_nan_observations_fail_the_host_driven_loop_too(vg):
     assert s["termination"] == "FAILURE" and s["num_iterations"] == 0 and "not finite" in s["message"], s
     assert np.array_equal(p.get_parameters(), x0)
     p.close()
+
+
+@pytest.mark.parametrize("lam,cuts", [(0.05, (0, 7, 12)), (1.0, (0, 4, 4, 12))])
+def test_odometry_coupled_sequence_across_ranks(vg, lam, cuts):
+    """data type "odometry" (src/calibration/unified_calibration.cpp:743-807) in a sharded solve: the hand-eye set of
+    test_gpu_solve.py -- chain [xiBaseCam I, xiOdomBase_i I, xiOdomBoard D], OdometryPrior blocks between consecutive
+    elements, element 0 anchored -- with the IMAGES split over ranks and the coupled sequence (its values and its odometry
+    blocks) replicated on every rank.  Each rank's GPU sums the raw pose blocks of its own images, one all-reduce per coupled
+    sequence completes them, every rank eliminates the same block-tridiagonal system: the result must be the one-rank solve."""
+    from visgeom_amd import synthetic as S
+
+    n = cuts[-1]
+    d = S.make_handeye(n, sigma=0.1)
+    errV, errW = 0.05, 0.05
+
+    def build(lo, hi):
+        def make():
+            p = vg.CalibrationProblem(0)
+            cam = p.add_camera("eucm", d["init_intrinsics"])
+            bc = p.add_transform(True, d["init_xi_base_cam"])
+            ob = p.add_transform(True, d["init_xi_odom_board"])
+            seq = p.add_transform(False, d["odometry"])                      # the whole sequence on every rank
+            p.add_dataset(cam, [(bc, 1), (seq, 1), (ob, 0)], d["board"], d["corners"][lo:hi],
+                          image_index=np.arange(lo, hi, dtype=np.int32))     # this rank's images
+            for i in range(n - 1):
+                p.add_odometry_prior(seq, i, errV, errW, lam, d["odometry"][i], d["odometry"][i + 1])
+            p.set_pose_constant(seq, 0)
+            p.finalize()
+            return p
+        return make
+
+    p = build(0, n)()
+    s_ref = p.solve(max_num_iterations=300, use_bounds=0)
+    x_ref = p.get_parameters()
+    p.close()
+    res = run_ranks([build(cuts[r], cuts[r + 1]) for r in range(len(cuts) - 1)], max_num_iterations=300, use_bounds=0)
+    s0, x0 = res[0]
+    assert s_ref["termination"].startswith("CONVERGENCE")
+    for s, x in res:
+        assert s["termination"] == s0["termination"] and s["num_iterations"] == s0["num_iterations"]
+        assert s["termination"].startswith("CONVERGENCE")
+        assert np.array_equal(x, x0)                     # everything is replicated here: identical on every rank
+        assert s["final_cost"] == s0["final_cost"]
+    assert abs(s0["initial_cost"] - s_ref["initial_cost"]) <= 1e-12 * s_ref["initial_cost"]
+    assert abs(s0["final_cost"] - s_ref["final_cost"]) <= 1e-8 * s_ref["final_cost"]
+    assert rel(x0, x_ref) < 1e-6
+    assert np.array_equal(x0[18:24], d["odometry"][0])   # the anchor did not move

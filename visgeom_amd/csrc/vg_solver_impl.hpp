@@ -663,8 +663,15 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
     const bool multi_rank = opt.allreduce != nullptr || (comm && comm->n_ranks > 1);
     if (opt.allreduce && comm && comm->n_ranks > 1)
         return fail(VG_ERR_INVALID_ARGUMENT, "give either an RCCL communicator or a host all-reduce callback, not both");
-    if (!coupled.empty() && multi_rank)
-        return fail(VG_ERR_INVALID_ARGUMENT, "OdometryPrior blocks and priors on sequence elements are not supported together with a multi-rank all-reduce");
+    // Sequences coupled by odometry blocks across ranks: the sequence transform is REPLICATED (every rank holds all of its
+    // elements and all of its odometry / prior blocks), only the images that reference it are sharded.  Every rank's GPU then
+    // produces the raw V_i, g_i, W_i^T of every element from ITS images, one in-place all-reduce per coupled sequence sums
+    // them, and every rank runs the same block-tridiagonal elimination on the same numbers (a few hundred poses; the
+    // reference solves them in the same globalProblem, src/calibration/unified_calibration.cpp:53 with the blocks of
+    // :661-807).  Only through a device communicator: the host-callback path packs its scalars before the sum.
+    if (!coupled.empty() && opt.allreduce)
+        return fail(VG_ERR_INVALID_ARGUMENT, "odometry-coupled sequences need a device communicator (vg_solve_options.comm) for a multi-rank solve, not the host all-reduce callback");
+    const bool coupled_multi = !coupled.empty() && multi_rank;
 
     // per dataset: local -> global column map, pose column offset, pose references
     std::vector<std::vector<int>> lmap(n_ds);
@@ -1347,6 +1354,10 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             // system and puts its rows where the per-pose rows would be
             for (auto &c2 : coupled) {
                 std::vector<double> hrec((size_t)c2.n * vg::kPoseRec), hraw((size_t)c2.n * 6 * C);
+                if (coupled_multi) {  // raw normal-equation pieces of the replicated sequence, summed over the ranks' images
+                    VG_TRY(vgc::allreduce_sum(comm, d_rec.p + (size_t)c2.pb * vg::kPoseRec, hrec.size(), st));
+                    VG_TRY(vgc::allreduce_sum(comm, d_rows.p + (size_t)c2.pb * 6 * C, hraw.size(), st));
+                }
                 VG_HIP(hipMemcpyAsync(hrec.data(), d_rec.p + (size_t)c2.pb * vg::kPoseRec, sizeof(double) * hrec.size(),
                                       hipMemcpyDeviceToHost, st));
                 VG_HIP(hipMemcpyAsync(hraw.data(), d_rows.p + (size_t)c2.pb * 6 * C, sizeof(double) * hraw.size(),
@@ -1357,8 +1368,13 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
                     std::fill(c2.Y.begin(), c2.Y.end(), 0.);
                     c2.Y.resize((size_t)c2.n * 6 * C, 0.);
                 }
-                VG_HIP(hipMemcpyAsync(d_rows.p + (size_t)c2.pb * 6 * C, c2.Y.data(), sizeof(double) * c2.Y.size(),
-                                      hipMemcpyHostToDevice, st));
+                // the rows enter the Schur complement ONCE: every rank has the same ones, rank 0 contributes them
+                if (coupled_multi && comm->rank != 0) {
+                    VG_HIP(hipMemsetAsync(d_rows.p + (size_t)c2.pb * 6 * C, 0, sizeof(double) * c2.Y.size(), st));
+                } else {
+                    VG_HIP(hipMemcpyAsync(d_rows.p + (size_t)c2.pb * 6 * C, c2.Y.data(), sizeof(double) * c2.Y.size(),
+                                          hipMemcpyHostToDevice, st));
+                }
                 VG_HIP(hipStreamSynchronize(st));  // c2.Y may be rewritten before an async copy from pageable memory ends
             }
             if (coupled.empty()) {
@@ -1504,6 +1520,11 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             for (auto &c2 : coupled) {
                 VG_HIP(hipMemcpy(c2.xc.data(), d_xc.p + c2.param_off, sizeof(double) * c2.xc.size(), hipMemcpyDeviceToHost));
                 cost2_c += c2.cost2(c2.xc, xg_c.data());
+                if (coupled_multi) {  // the replicated poses entered the summed |x|^2 once per rank
+                    double x2 = 0.;
+                    for (double v : c2.x) x2 += v * v;
+                    xp2 -= (double)(comm->n_ranks - 1) * x2;
+                }
             }
             {
                 std::vector<double> pack(Uc);
