@@ -16,7 +16,9 @@ Inputs are resident in HBM before the timed region.  Multi-GPU: images are shard
 (weak scaling, no data-path collective in this pass).  The normal-equation build that needs the exchange step is
 reported under "jtj" (same weak-scaled set) and under "sharded_mei" (BASELINE.json config 4: Mei, 10 000 images x 96
 corners in TOTAL, split over the N ranks -- strong scaling; one iteration = fused J^T J + ONE packed in-place RCCL
-all-reduce of [H | g | cost | n_failed] on the device buffer through the native vg_comm entry).
+all-reduce of [H | g | cost | n_failed] on the device buffer through the native vg_comm entry), and the full LM solves
+of sharded problems under "sharded_solve" (Mei 10 k and EUCM 100 k images in total: two collectives per iteration on the
+critical path).
 
 Prints ONE JSON line (rank 0).
 """
@@ -44,6 +46,8 @@ def parse():
     ap.add_argument("--images", type=int, default=10000, help="images per GPU")
     ap.add_argument("--model", default="eucm", choices=["eucm", "ucm", "mei"])
     ap.add_argument("--sharded-images", type=int, default=10000, help="total images of the sharded Mei case (config 4)")
+    ap.add_argument("--sharded-solve-images", type=int, default=100000,
+                    help="total images of the large sharded LM solve (0: skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU-baseline budget per leg")
     return ap.parse_args()
@@ -521,6 +525,54 @@ def main():
     except Exception as e:  # the solve leg must never take the headline measurement down
         solve = {"error": repr(e)}
 
+    # ---- full LM solves of problems whose images are SHARDED over the ranks (strong scaling): the collective of the path
+    # -- one in-place all-reduce of the summed normal-equation blocks per evaluation, one of the Schur complement per linear
+    # solve -- is on the critical path of every iteration here.  (a) BASELINE.json config 4, Mei 10 000 images in total;
+    # (b) EUCM, 100 000 images in total: the size from which sharding is expected to pay.  With one
+    # rank these are plain solves; the communicator is passed whenever one exists.
+    sharded_solve = {}
+    try:
+        from visgeom_amd import distributed as vdist
+
+        for key, model_s, n_total, cfg_s in (("mei_10k", "mei", a.sharded_images, 4), ("eucm_100k", "eucm", a.sharded_solve_images, 1)):
+            if n_total <= 0:
+                continue
+            lo, hi = vdist.shard_range(n_total, rank, world)
+            dsh = synthetic.make_mono(model_s, hi - lo, cfg_s, first_image=lo)
+            runs, summ = [], None
+            for rep in range(2):
+                psh = CalibrationProblem(local_rank)
+                csh = psh.add_camera(model_s, dsh["init_intrinsics"])
+                ssh = psh.add_transform(False, dsh["init_poses"])
+                psh.add_dataset(csh, [(ssh, 0)], dsh["board"], dsh["corners"])
+                psh.finalize()
+                fence()
+                t0 = time.perf_counter()
+                summ = psh.solve(comm=comm, allreduce=vdist.make_allreduce() if (dist is not None and comm is None) else None,
+                                 max_num_iterations=100)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                fence()
+                if dist is not None:
+                    tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+                    all_reduce_(tt, op=dist.ReduceOp.MAX)
+                    dt = float(tt.item())
+                runs.append(dt * 1e3)
+                xsh = psh.get_parameters()
+                psh.close()
+            Ksh = dsh["init_intrinsics"].size
+            sharded_solve[key] = {
+                "workload": "%s mono, %d images x %d corners in total over %d rank(s), full LM solve" % (model_s.upper(), n_total, N, world),
+                "scaling": "strong", "images_total": n_total, "images_this_rank": hi - lo, "n_ranks": world,
+                "collectives_per_iteration": 0 if world == 1 else 2,
+                "iterations": summ["num_iterations"], "termination": summ["termination"], "final_cost": summ["final_cost"],
+                "solve_ms_max_over_ranks": runs[-1], "first_solve_ms": runs[0],
+                "ms_per_iteration": runs[-1] / max(1, summ["num_iterations"]),
+                "max_rel_intrinsics_error_vs_generating": float(np.max(np.abs(xsh[:Ksh] - dsh["gt_intrinsics"]) /
+                                                                       np.maximum(np.abs(dsh["gt_intrinsics"]), 1.0)))}
+    except Exception as e:  # never take the headline down
+        sharded_solve["error"] = repr(e)
+
     out = {
         "metric": "corner residual+Jacobian evals/sec",
         "value": value,
@@ -542,6 +594,7 @@ def main():
         "roofline": roofline,
         "jtj": jtj,
         "sharded_mei": sharded,
+        "sharded_solve": sharded_solve,
         "solve": solve,
         "pcie_inclusive": pcie,
     }
