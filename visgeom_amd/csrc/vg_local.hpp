@@ -290,22 +290,19 @@ struct SparseArgs {
     unsigned int n_points;     // count
 };
 
+// one point of a SparseReprojectCost block; f = the block's frame (a wave-uniform or a per-lane address)
 template <int MODEL>
-__global__ __launch_bounds__(kEmitThreads) void vg_sparse_reproject_kernel(SparseArgs a)
+__device__ __forceinline__ void sparse_point(const SparseArgs &a, const double *__restrict__ f, const long long pt, const unsigned int o,
+                                             const bool active, const unsigned int o0, double *stage, const int wave, const int lane)
 {
     constexpr int K = CameraTraits<MODEL>::K;
     using d2 = HIP_vector_type<double, 2>;
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
-    const unsigned int o0 = blockIdx.x * (unsigned)kEmitThreads, o = o0 + tid;
-    const bool active = o < a.n_points;
-    const long long pt = a.first_point + (active ? o : a.n_points - 1);
-    const double *f = a.frames + (long long)a.point_block[pt] * kSparseFrame;
     const double *x1 = a.x1 + pt * 3, *x2 = a.x2 + pt * 3;
     const double *t12 = f, *Rt = f + 3, *R21 = f + 12;
     const bool want_jac = a.jac != nullptr;
     double jv[6];
-    const double lam = triangulate_regular(Rt, t12, 1e-3, x1, x2, want_jac ? jv : nullptr);   // Triangulator(xi12): eps = 1e-3
+    // Triangulator(xi12): eps = 1e-3.  (Two calls: a pointer chosen at run time would put jv into scratch memory.)
+    const double lam = want_jac ? triangulate_regular(Rt, t12, 1e-3, x1, x2, jv) : triangulate_regular(Rt, t12, 1e-3, x1, x2, nullptr);
     // xVec2 = xVec1 * lambda; xi12.inverseTransform: R(-r) * (x - t)   (:303-308)
     const double d[3] = {x1[0] * lam - t12[0], x1[1] * lam - t12[1], x1[2] * lam - t12[2]};
     double X[3];
@@ -352,8 +349,27 @@ __global__ __launch_bounds__(kEmitThreads) void vg_sparse_reproject_kernel(Spars
         const unsigned int ow = o0 + wave * kWave;
         int n_valid = 0;
         if (ow < a.n_points) n_valid = (a.n_points - ow < (unsigned)kWave) ? (int)(a.n_points - ow) : kWave;
-        wave_store_rows<6>(smem + wave * (2 * kWave * 6), rows, a.jac + (size_t)ow * 12, n_valid, lane);
+        wave_store_rows<6>(stage, rows, a.jac + (size_t)ow * 12, n_valid, lane);
     }
+}
+
+template <int MODEL>
+__global__ __launch_bounds__(kEmitThreads) void vg_sparse_reproject_kernel(SparseArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+    const unsigned int o0 = blockIdx.x * (unsigned)kEmitThreads, o = o0 + tid;
+    const bool active = o < a.n_points;
+    const long long pt = a.first_point + (active ? o : a.n_points - 1);
+    double *stage = smem + wave * (2 * kWave * 6);
+    // The 69 doubles of the block's frame: when all 64 points of the wave belong to ONE block (blocks of hundreds of
+    // inliers) the frame address is wave-uniform and its loads are scalar -- one fetch for the wave instead of 69 vector
+    // loads of the same address in every lane; a wave that straddles blocks (RANSAC hypotheses of a few points each) reads
+    // per lane.  Same arithmetic on both paths.
+    const int blk = a.point_block[pt];
+    const int blk0 = __builtin_amdgcn_readfirstlane(blk);
+    if (__builtin_amdgcn_ballot_w64(blk != blk0) == 0) sparse_point<MODEL>(a, a.frames + (long long)blk0 * kSparseFrame, pt, o, active, o0, stage, wave, lane);
+    else sparse_point<MODEL>(a, a.frames + (long long)blk * kSparseFrame, pt, o, active, o0, stage, wave, lane);
 }
 
 // CameraJacobian: L11 | L12 | L22 (jacobian.h:54-71), computed on the host once per call
