@@ -218,7 +218,8 @@ int launch_gram_fused(hipStream_t stream, const vg::GramArgs &a)
 bool gram_uses_valu(const vg_problem *p, const Dataset &d)
 {
     const bool force_mfma = vgi::debug_hook(vgi::kHookGramForceMfma) != 0;  // measurement hook (A/B of the two kernels)
-    return !force_mfma && d.L <= 2 && p->cams[d.camera].K + 6 * d.L + 1 <= vg::kValuMaxW;
+    (void)p;
+    return !force_mfma && d.L <= vg::kMaxChain;  // one member: the direct form; two or more: the factored form (vg_gram_valu_z_kernel)
 }
 
 bool gram_inline_chain(const vg_problem *p, const Dataset &d)
@@ -259,7 +260,20 @@ int launch_gram_valu(hipStream_t stream, const vg::GramValuArgs &a, int L, bool 
 {
     if (L == 0) return launch_gram_valu_l<MODEL, 0>(stream, a, false);
     if (L == 1) return launch_gram_valu_l<MODEL, 1>(stream, a, inline_chain);
-    return launch_gram_valu_l<MODEL, 2>(stream, a, false);
+    // two or more members: the factored form -- rows of K + 7 columns whatever L is
+    constexpr int K = vg::CameraTraits<MODEL>::K;
+    constexpr int CH = K + 7 <= 13 ? 3 : 2;
+    const size_t lds = vg::gram_valu_z_lds_bytes(K, L);
+    const bool small_board = a.g.N <= (unsigned)vg::kValuLanesPerImage || vgi::debug_hook(vgi::kHookGramCh1) != 0;
+    if (lds > 48 * 1024) {  // chains of four or five members: more than the default dynamic LDS limit
+        const void *fn = small_board ? reinterpret_cast<const void *>(vg::vg_gram_valu_z_kernel<MODEL, 1>)
+                                     : reinterpret_cast<const void *>(vg::vg_gram_valu_z_kernel<MODEL, CH>);
+        VG_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    if (small_board) hipLaunchKernelGGL((vg::vg_gram_valu_z_kernel<MODEL, 1>), dim3(a.n_wg), dim3(vg::kValuThreads), lds, stream, a);
+    else hipLaunchKernelGGL((vg::vg_gram_valu_z_kernel<MODEL, CH>), dim3(a.n_wg), dim3(vg::kValuThreads), lds, stream, a);
+    VG_HIP(hipGetLastError());
+    return VG_OK;
 }
 
 }  // namespace
@@ -923,7 +937,7 @@ bool vgi::gram_merge_covers_all(const vg_problem *p)
     int n = 0;
     for (const Dataset &d : p->dss) {
         if (!d.n_blocks) continue;
-        if (!(d.n_blocks <= 0x7fffffff && gram_uses_valu(p, d) && (d.L == 1 || d.L == 2) && d.N > vg::kValuLanesPerImage)) return false;
+        if (!(d.n_blocks <= 0x7fffffff && gram_uses_valu(p, d) && d.L >= 1 && d.N > vg::kValuLanesPerImage)) return false;
         n++;
     }
     return n >= 2 && n % vg::kGramMultiMax != 1;  // a lone leftover group would go the ordinary way
@@ -938,8 +952,7 @@ int vgi::gram_fused_merged_at(vg_problem *p, const double *d_params, double *con
     std::vector<int> ids;
     for (int i = 0; i < n_ds && !off; i++) {
         const Dataset &d = p->dss[i];
-        if (d.n_blocks > 0 && d.n_blocks <= 0x7fffffff && grams[i] && gram_uses_valu(p, d) && (d.L == 1 || d.L == 2) &&
-            d.N > vg::kValuLanesPerImage)
+        if (d.n_blocks > 0 && d.n_blocks <= 0x7fffffff && grams[i] && gram_uses_valu(p, d) && d.L >= 1 && d.N > vg::kValuLanesPerImage)
             ids.push_back(i);
     }
     if (ids.size() < 2) return VG_OK;
@@ -959,14 +972,16 @@ int vgi::gram_fused_merged_at(vg_problem *p, const double *d_params, double *con
             a.seq_index = d.seq_identity ? nullptr : d.d_seq;
             a.n_wg = (unsigned int)((d.n_blocks + vg::kValuImagesPerBlock - 1) / vg::kValuImagesPerBlock);
             a.partials = partials ? partials[ids[g0 + k]] : nullptr;
-            m.kind[k] = 3 * cam.model + (d.L == 2 ? 2 : (gram_inline_chain(p, d) ? 0 : 1));
+            m.kind[k] = 3 * cam.model + (d.L >= 2 ? 2 : (gram_inline_chain(p, d) ? 0 : 1));
             m.first_wg[k] = wgs;
             wgs += a.n_wg;
-            const size_t need = vg::gram_valu_lds_bytes(cam.K + 6 * d.L + 1, d.L);
+            const size_t need = d.L >= 2 ? vg::gram_valu_z_lds_bytes(cam.K, d.L) : vg::gram_valu_lds_bytes(cam.K + 6 * d.L + 1, d.L);
             lds = need > lds ? need : lds;
             taken[(size_t)ids[g0 + k]] = 1;
         }
         for (int k = m.n; k <= vg::kGramMultiMax; k++) m.first_wg[k] = wgs;
+        if (lds > 48 * 1024)
+            VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(vg::vg_gram_valu_multi_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(vg::vg_gram_valu_multi_kernel, dim3(wgs), dim3(vg::kValuThreads), lds, p->stream, m);
         VG_HIP(hipGetLastError());
     }

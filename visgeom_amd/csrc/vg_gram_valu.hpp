@@ -394,6 +394,265 @@ __global__ __launch_bounds__(kValuThreads, 2) void vg_gram_valu_kernel(GramValuA
     gram_valu_body<MODEL, L, INLINE, CH>(a, blockIdx.x, valu_lds);
 }
 
+// ------------------------------------------------------------------------------------------
+// Chains of TWO OR MORE members: the factored form.  InterJacobian::dpdxi (jacobian.h:155-171) gives for member l and a
+// corner with projection Jacobian row p and camera-frame point X
+//     J_l = [ p R12_l | ((-p) hat(X - t13_l)) M12_l ] = [ p | p hat(X) ] F_l ,   F_l = [ R12_l   hat(t13_l) M12_l ]   (6 x 6)
+//                                                                                     [   0        -M12_l        ]
+// -- the corner enters only through z = [p | p hat(X)] (2 x 6 per corner), the SAME for every member; F_l is a per-image
+// constant.  So the image's W x W Gram block (W = K + 6 L + 1) is a congruence of the Gram of the 2 x (K + 7) row block
+// [J_intr | z | r]:   J_l^T J_m = F_l^T (sum z^T z) F_m,   J_intr^T J_l = (sum J_intr^T z) F_l,   J_l^T r = F_l^T (sum z^T r).
+// The per-corner work and the cross-lane sum are those of a SINGLE-member chain, whatever L is (EUCM: 13-wide rows, three
+// corners per lane, one pass of the halving tree -- instead of 19-wide rows at two corners per lane with spills for L = 2,
+// or the matrix-core kernel for L >= 3); the congruence is ~100 .. 1 000 FMAs per lane and image, from LDS.  Frames come
+// from the chain-prep launch.  The direct form's flop count (2 (P + 1)(P + 2) per corner) stays the algorithmic measure.
+// ------------------------------------------------------------------------------------------
+template <int MODEL, int CC, int kOut>
+__device__ __forceinline__ void valu_chunk_z(const double *__restrict__ intr, const double *fr, const ValuChunkIn<CC> &in, int sl,
+                                             double (&out)[kOut])
+{
+    using Rows = ValuRows<MODEL, 1, CC>;   // K + 6 + 1 columns: [J_intr | z | r]
+    constexpr int K = Rows::K, W = Rows::W;
+    Rows R;
+#pragma unroll
+    for (int s = 0; s < 5; s++) R.bit[s] = (sl >> (4 - s)) & 1;
+#pragma unroll
+    for (int j = 0; j < CC; j++) {
+#pragma clang fp contract(fast)
+        const double g0 = in.gb[j][0], g1 = in.gb[j][1], g2 = in.gb[j][2];
+        const double X0 = (fr[0] * g0 + fr[1] * g1 + fr[2] * g2) + fr[9];
+        const double X1 = (fr[3] * g0 + fr[4] * g1 + fr[5] * g2) + fr[10];
+        const double X2 = (fr[6] * g0 + fr[7] * g1 + fr[8] * g2) + fr[11];
+        CornerEval<K> e;
+        eval_corner_fast<MODEL>(intr, X0, X1, X2, e);
+#pragma unroll
+        for (int i = 0; i < K; i++) {
+            R.rw[j][0][i] = e.Ju[i];
+            R.rw[j][1][i] = e.Jv[i];
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const double p0 = e.P[3 * h], p1 = e.P[3 * h + 1], p2 = e.P[3 * h + 2];
+            R.rw[j][h][K + 0] = p0;
+            R.rw[j][h][K + 1] = p1;
+            R.rw[j][h][K + 2] = p2;
+            R.rw[j][h][K + 3] = p1 * X2 - p2 * X1;   // p hat(X)
+            R.rw[j][h][K + 4] = p2 * X0 - p0 * X2;
+            R.rw[j][h][K + 5] = p0 * X1 - p1 * X0;
+        }
+        R.rw[j][0][W - 1] = e.ok ? e.u - in.ob[j].x : kDoubleBig;
+        R.rw[j][1][W - 1] = e.ok ? e.v - in.ob[j].y : kDoubleBig;
+    }
+    bool any_ragged = false;
+#pragma unroll
+    for (int j = 0; j < CC; j++) any_ragged |= in.ragged[j];
+    if (__builtin_amdgcn_ballot_w64(any_ragged)) {
+        double zero = 0.;
+        asm volatile("; ragged chunk" : "+v"(zero));
+#pragma unroll
+        for (int j = 0; j < CC; j++)
+#pragma unroll
+            for (int i = 0; i < W; i++) {
+                R.rw[j][0][i] = in.ragged[j] ? zero : R.rw[j][0][i];
+                R.rw[j][1][i] = in.ragged[j] ? zero : R.rw[j][1][i];
+            }
+    }
+    double t[kOut];
+    valu_tree_all(R, t, std::make_integer_sequence<int, kOut>{});
+#pragma unroll
+    for (int k = 0; k < kOut; k++) out[k] += t[k];
+}
+
+// dynamic LDS of a workgroup of the factored kernel:
+//   frames [8][frame_stride(L)] | D [8][(K+7)^2] dense Gram of [J_intr | z | r] | F [8][L][36] | T [8][L][36] = (sum z^T z) F_m
+//   | red [4][E] | entry table (r, c) [E] as 16-bit pairs
+__host__ __device__ constexpr size_t gram_valu_z_lds_bytes(int K, int L)
+{
+    const int W = K + 6 * L + 1, E = W * (W + 1) / 2, W13 = K + 7;
+    return sizeof(double) * (size_t)(kValuImagesPerBlock * (frame_stride(L) + W13 * W13 + 72 * L) + (kValuThreads / kWave) * E + (E + 3) / 4 + 2);
+}
+
+template <int MODEL, int CH>
+__device__ __forceinline__ void gram_valu_z_body(const GramValuArgs &a, const double *intr, const unsigned int block, double *lds)
+{
+    using Rows = ValuRows<MODEL, 1, CH>;
+    constexpr int K = Rows::K, W13 = Rows::W, E13 = Rows::E, kOut = halved(E13, 5);
+    const int L = a.g.L, W = a.g.W, E = W * (W + 1) / 2, FS = a.g.frame_stride_d;
+    double *fr_lds = lds, *d_lds = fr_lds + kValuImagesPerBlock * FS, *f_lds = d_lds + kValuImagesPerBlock * W13 * W13;
+    double *t_lds = f_lds + kValuImagesPerBlock * 36 * L, *red = t_lds + kValuImagesPerBlock * 36 * L;
+    unsigned short *rc_tab = reinterpret_cast<unsigned short *>(red + (kValuThreads / kWave) * E);
+    if (gate_closed(a.g.gate, a.g.gate_expect)) return;
+
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+    const int sl = lane & (kValuLanesPerImage - 1), img = tid / kValuLanesPerImage;
+    const unsigned int b0 = block * kValuImagesPerBlock;
+    const unsigned int b = b0 + (unsigned)img;
+    const bool bvalid = b < a.g.n_blocks;
+
+    constexpr unsigned int kFull = kValuLanesPerImage * CH;
+    const unsigned int n_full = a.g.N / kFull;
+    ValuChunkIn<CH> in_full;
+    ValuChunkIn<1> in_one;
+    if (n_full) in_full.load(a.g, b, b0, bvalid, sl, 0);
+    else in_one.load(a.g, b, b0, bvalid, sl, 0);
+
+    // (row, column) of every entry of the W x W upper triangle, once per workgroup (W is a run-time value here)
+    for (int e = tid; e < E; e += kValuThreads) {
+        int r = 0, rem = e;
+        while (rem >= W - r) {
+            rem -= W - r;
+            r++;
+        }
+        rc_tab[e] = (unsigned short)(r | ((r + rem) << 8));
+    }
+    __syncthreads();  // the table is the workgroup's; here, where the waves still run together, the barrier costs nothing --
+                      // behind the corner loop it would re-align waves that have drifted apart to cover each other's latencies
+    double *fr_mine = fr_lds + img * FS;
+    if (bvalid) {
+        const double *src = a.g.frames + (size_t)b * FS;
+        for (int i = sl; i < FS; i += kValuLanesPerImage) fr_mine[i] = src[i];
+    }
+    wave_lds_fence();
+    const double *fr = fr_mine;
+    // F_l of this image, dense 6 x 6: [[R12, hat(t13) M12], [0, -M12]]
+    double *f_mine = f_lds + img * 36 * L;
+    for (int idx = sl; idx < 36 * L; idx += kValuLanesPerImage) {
+#pragma clang fp contract(fast)
+        const int l = idx / 36, e36 = idx - 36 * l, sr = e36 / 6, q = e36 - 6 * sr, i = sr % 3, j = q % 3;
+        const double *fm = fr + 12 + 21 * l, *M12 = fm + 9, *t13 = fm + 18;
+        double v;
+        if (sr < 3 && q < 3) v = fm[3 * i + j];
+        else if (sr >= 3 && q < 3) v = 0.;
+        else if (sr >= 3) v = -M12[3 * i + j];
+        else {  // (hat(t13) M12)[i][j], hat(t) = [[0, -t2, t1], [t2, 0, -t0], [-t1, t0, 0]]
+            const double h0 = i == 0 ? 0. : (i == 1 ? t13[2] : -t13[1]);
+            const double h1 = i == 0 ? -t13[2] : (i == 1 ? 0. : t13[0]);
+            const double h2 = i == 0 ? t13[1] : (i == 1 ? -t13[0] : 0.);
+            v = h0 * M12[j] + h1 * M12[3 + j] + h2 * M12[6 + j];
+        }
+        f_mine[idx] = bvalid ? v : 0.;
+    }
+
+    double out[kOut];
+#pragma unroll
+    for (int k = 0; k < kOut; k++) out[k] = 0.;
+    unsigned int c0 = 0;
+    for (unsigned int m = 0; m < n_full; m++) {
+        valu_chunk_z<MODEL, CH, kOut>(intr, fr, in_full, sl, out);
+        c0 += kFull;
+        if (m + 1 < n_full) in_full.load(a.g, b, b0, bvalid, sl, c0);
+    }
+    if constexpr (CH > 1) {
+        if (c0 < a.g.N) {
+            if (n_full) in_one.load(a.g, b, b0, bvalid, sl, c0);
+            for (;;) {
+                valu_chunk_z<MODEL, 1, kOut>(intr, fr, in_one, sl, out);
+                c0 += kValuLanesPerImage;
+                if (c0 >= a.g.N) break;
+                in_one.load(a.g, b, b0, bvalid, sl, c0);
+            }
+        }
+    } else {
+        if (c0 < a.g.N) {
+            if (n_full) in_full.load(a.g, b, b0, bvalid, sl, c0);
+            else in_full = in_one;
+            valu_chunk_z<MODEL, 1, kOut>(intr, fr, in_full, sl, out);
+        }
+    }
+    // the lane's entries [base, base + real) of the (K + 7)-wide Gram go to LDS
+    int base = 0, real = E13;
+    {
+        int n = E13;
+#pragma unroll
+        for (int s = 0; s < 5; s++) {
+            const int H = (n + 1) / 2;
+            const bool bit = (sl >> (4 - s)) & 1;
+            base += bit ? H : 0;
+            real = bit ? (real - H > 0 ? real - H : 0) : (real < H ? real : H);
+            n = H;
+        }
+    }
+    // the lane's entries of the (K + 7)-wide Gram go to LDS as a dense symmetric matrix D
+    double *D = d_lds + img * W13 * W13;
+#pragma unroll
+    for (int k = 0; k < kOut; k++) {
+        const int e13 = base + k;
+        if (k < real) {
+            const int r = kTriTable<W13>.r[e13], c = kTriTable<W13>.c[e13];
+            D[r * W13 + c] = out[k];
+            D[c * W13 + r] = out[k];
+        }
+    }
+    wave_lds_fence();
+    // T_m = (sum z^T z) F_m, 6 x 6 per member
+    double *t_mine = t_lds + img * 36 * L;
+    for (int idx = sl; idx < 36 * L; idx += kValuLanesPerImage) {
+#pragma clang fp contract(fast)
+        const int m = idx / 36, e36 = idx - 36 * m, sr = e36 / 6, q = e36 - 6 * sr;
+        const double *Dz = D + (K + sr) * W13 + K, *F = f_mine + 36 * m + q;
+        double v = Dz[0] * F[0];
+#pragma unroll
+        for (int t2 = 1; t2 < 6; t2++) v += Dz[t2] * F[6 * t2];
+        t_mine[idx] = v;
+    }
+    wave_lds_fence();
+
+    // ---- the congruence: entry (r, c), r <= c, of the W x W block
+    double *G = a.g.gram + (size_t)(bvalid ? b : 0) * ((size_t)W * W);
+    for (int e = sl; e < E; e += kValuLanesPerImage) {
+#pragma clang fp contract(fast)
+        const int r = rc_tab[e] & 0xff, c = rc_tab[e] >> 8;
+        const bool r_in = r < K, c_in = c < K, c_res = c == W - 1, r_res = r == W - 1;
+        double v;
+        if (r_in && c_in) v = D[r * W13 + c];
+        else if (r_in && c_res) v = D[r * W13 + W13 - 1];
+        else if (r_res) v = D[W13 * W13 - 1];
+        else if (r_in) {  // intrinsic row, member column: (sum J_intr^T z) F_l
+            const int l = (c - K) / 6, q = (c - K) - 6 * l;
+            const double *Dz = D + r * W13 + K, *F = f_mine + 36 * l + q;
+            v = Dz[0] * F[0];
+#pragma unroll
+            for (int s2 = 1; s2 < 6; s2++) v += Dz[s2] * F[6 * s2];
+        } else if (c_res) {  // member row, residual column: F_l^T (sum z^T r)
+            const int l = (r - K) / 6, q = (r - K) - 6 * l;
+            const double *F = f_mine + 36 * l + q, *Dr = D + K * W13 + W13 - 1;
+            v = F[0] * Dr[0];
+#pragma unroll
+            for (int s2 = 1; s2 < 6; s2++) v += F[6 * s2] * Dr[s2 * W13];
+        } else {  // member row, member column: F_l^T T_m
+            const int l = (r - K) / 6, q = (r - K) - 6 * l, m = (c - K) / 6, q2 = (c - K) - 6 * m;
+            const double *F = f_mine + 36 * l + q, *Tm = t_mine + 36 * m + q2;
+            v = F[0] * Tm[0];
+#pragma unroll
+            for (int s2 = 1; s2 < 6; s2++) v += F[6 * s2] * Tm[6 * s2];
+        }
+        if (bvalid) {
+            G[(size_t)r * W + c] = v;
+            G[(size_t)c * W + r] = v;
+        }
+        if (a.partials) {  // both images of the wave: the other half-wave holds the same entry of its image
+            const double tot = (bvalid ? v : 0.) + __shfl_xor(bvalid ? v : 0., 32, kWave);
+            if (lane < kValuLanesPerImage) red[wave * E + e] = tot;
+        }
+    }
+    if (a.partials) {
+        __syncthreads();
+        for (int e = tid; e < E; e += kValuThreads) {
+            double s2 = red[e];
+#pragma unroll
+            for (int w = 1; w < kValuThreads / kWave; w++) s2 += red[w * E + e];  // fixed order
+            a.partials[(size_t)e * a.n_wg + block] = s2;
+        }
+    }
+}
+
+template <int MODEL, int CH>
+__global__ __launch_bounds__(kValuThreads, 2) void vg_gram_valu_z_kernel(GramValuArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double valu_lds[];
+    gram_valu_z_body<MODEL, CH>(a, a.g.intr, blockIdx.x, valu_lds);
+}
+
 // Several datasets of a problem in ONE launch (stereo pair, rig): 5 000 images are 625 workgroups on 512 resident slots,
 // i.e. a launch of its own runs two rounds with the second one a fifth full; four such launches waste most of four
 // rounds.  The workgroups of all datasets form one range; each finds its dataset and runs that dataset's body (full-chunk
@@ -403,7 +662,7 @@ constexpr int kGramMultiMax = 6;
 struct GramValuMultiArgs {
     GramValuArgs ds[kGramMultiMax];
     unsigned int first_wg[kGramMultiMax + 1];
-    int kind[kGramMultiMax];  // 3 * model + {0: one member walked in the kernel, 1: one member on prepared frames, 2: two members}
+    int kind[kGramMultiMax];  // 3 * model + {0: one member walked in the kernel, 1: one member on prepared frames, 2: two or more members (factored form)}
     int n;
 };
 
@@ -417,13 +676,13 @@ __global__ __launch_bounds__(kValuThreads, 2) void vg_gram_valu_multi_kernel(Gra
     switch (m.kind[d]) {
     case 3 * kEUCM + 0: gram_valu_body<kEUCM, 1, true, 3>(a, block, valu_lds); break;
     case 3 * kEUCM + 1: gram_valu_body<kEUCM, 1, false, 3>(a, block, valu_lds); break;
-    case 3 * kEUCM + 2: gram_valu_body<kEUCM, 2, false, 2>(a, block, valu_lds); break;
+    case 3 * kEUCM + 2: gram_valu_z_body<kEUCM, 3>(a, a.g.intr, block, valu_lds); break;
     case 3 * kUCM + 0: gram_valu_body<kUCM, 1, true, 3>(a, block, valu_lds); break;
     case 3 * kUCM + 1: gram_valu_body<kUCM, 1, false, 3>(a, block, valu_lds); break;
-    case 3 * kUCM + 2: gram_valu_body<kUCM, 2, false, 2>(a, block, valu_lds); break;
+    case 3 * kUCM + 2: gram_valu_z_body<kUCM, 3>(a, a.g.intr, block, valu_lds); break;
     case 3 * kMEI + 0: gram_valu_body<kMEI, 1, true, 2>(a, block, valu_lds); break;
     case 3 * kMEI + 1: gram_valu_body<kMEI, 1, false, 2>(a, block, valu_lds); break;
-    default: gram_valu_body<kMEI, 2, false, 1>(a, block, valu_lds); break;
+    default: gram_valu_z_body<kMEI, 2>(a, a.g.intr, block, valu_lds); break;
     }
 }
 
