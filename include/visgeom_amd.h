@@ -263,9 +263,10 @@ int vg_dataset_failed_count(vg_problem *p, int dataset_id, int64_t *count);
  *    the block's own column order [intrinsics, chain member 0, ..., chain member L-1, residual].
  * ===================================================================================== */
 int vg_dataset_gram_width(const vg_problem *p, int dataset_id); /* W */
-/* fused: evaluates residuals and Jacobian rows in registers and contracts them there -- chains of one or two members on
- * the FP64 vector pipe (products per lane, recursive-halving sum over the 32 lanes of an image), longer chains on the
- * FP64 matrix cores; J is never written to HBM.  gram: device [n_blocks][W*W], row-major, full symmetric.  Needs
+/* fused: evaluates residuals and Jacobian rows in registers and contracts them there, on the FP64 vector pipe (products per
+ * lane, recursive-halving sum over the 32 lanes of an image; chains of two or more members through the factored form
+ * J_l = [p | p hat(X)] F_l: the per-corner rows stay K + 7 wide, the W x W block is a per-image congruence); J is never
+ * written to HBM.  gram: device [n_blocks][W*W], row-major, full symmetric.  Needs
  * vg_problem_prepare at the current parameters, like vg_dataset_evaluate. */
 int vg_dataset_gram_fused(vg_problem *p, int dataset_id, double *gram);
 /* the same per-block matrices AND their fixed-order sum over the dataset's blocks (sum[W*W] device, full symmetric)
@@ -275,7 +276,7 @@ int vg_dataset_gram_fused(vg_problem *p, int dataset_id, double *gram);
  * order) and is run-to-run reproducible. */
 int vg_dataset_gram_fused_sum(vg_problem *p, int dataset_id, double *gram, double *sum);
 /* vg_dataset_gram_fused for EVERY dataset of the problem (grams[d]: device [n_blocks][W*W], may be NULL for an empty
- * dataset): the datasets the vector-pipe kernel handles (chains of one or two members) share ONE launch -- a stereo pair
+ * dataset): the datasets (chains of one to five members, boards of more than 32 points) share ONE launch -- a stereo pair
  * or a rig is several launches of a few hundred workgroups otherwise, each ending in a nearly empty round. */
 int vg_problem_gram_fused(vg_problem *p, double *const *grams);
 /* two-pass: the same Gram matrices from rows already materialised by vg_dataset_evaluate

@@ -1,7 +1,7 @@
-// vg_gram_valu.hpp -- fused evaluate + Gram for the row blocks of chains with at most TWO members (W = K + 6L + 1 <= 23:
-// EUCM / UCM / Mei mono -- the headline workload and config 4 -- and the second camera of a stereo pair or rig), entirely
-// on the FP64 vector pipe: "J^T J / J^T r block
-// reductions with wavefront shuffles".
+// vg_gram_valu.hpp -- fused evaluate + Gram entirely on the FP64 vector pipe: "J^T J / J^T r block reductions with
+// wavefront shuffles".  Chains of ONE member (EUCM / UCM / Mei mono -- the headline workload and config 4) in the direct
+// form: rows of W = K + 7 columns; chains of TWO OR MORE members (the second camera of a stereo pair, the cameras of a rig,
+// up to five members) in the factored form further down: the same K + 7-wide rows per corner and a per-image congruence.
 //
 // Why not the matrix cores here: on gfx950 v_mfma_f64_16x16x4_f64 runs at the FP64 VECTOR rate and shares its datapath
 // (profiles/r01d_fp64_pipes_probe.txt), so its only merit is the built-in cross-lane sum -- and a 16 x 16 tile spends
@@ -28,7 +28,7 @@ namespace vg {
 constexpr int kValuThreads = 256;
 constexpr int kValuLanesPerImage = 32;
 constexpr int kValuImagesPerBlock = kValuThreads / kValuLanesPerImage;
-constexpr int kValuMaxW = 23;
+constexpr int kValuMaxW = 17;  // direct form: Mei with one member
 
 struct GramValuArgs {
     GramArgs g;                  // frames (prepared route), board, obs, intr, gram, n_blocks, N, (L, W, stride: template)
@@ -280,7 +280,7 @@ __host__ __device__ constexpr size_t gram_valu_lds_bytes(int W, int L)
 template <int MODEL, int L, bool INLINE, int CH>
 __device__ __forceinline__ void gram_valu_body(const GramValuArgs &a, const unsigned int block, double *lds)
 {
-    static_assert(L >= 0 && L <= 2 && (!INLINE || L == 1), "chains of at most two members; the in-kernel walk is the single DIRECT member's");
+    static_assert(L >= 0 && L <= 1 && (!INLINE || L == 1), "the direct form is the single-member chain's (longer chains: gram_valu_z_body); the in-kernel walk is the DIRECT member's");
     using Rows = ValuRows<MODEL, L, CH>;
     constexpr int W = Rows::W, E = Rows::E, FS = frame_stride(L);
     static_assert(W <= kValuMaxW && (W <= 13 || CH <= 2) && (W <= 19 || CH == 1), "the rows of a chunk must fit the register file");
