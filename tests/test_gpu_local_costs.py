@@ -340,6 +340,38 @@ def test_a_ransac_sized_and_a_large_set(loc):
     st.close()
 
 
+def test_many_tiny_blocks_take_the_frame_launch(loc):
+    """a workgroup's 256 points spread over more blocks than the in-kernel frame table holds (300 one- and two-point blocks,
+    some empty): the two-launch route on a small grid; equal to the per-block entry (one block per launch: frames computed
+    in the kernel) bit for bit, and to the oracle"""
+    import torch
+
+    rng = np.random.default_rng(18)
+    nb = 300
+    counts = rng.integers(0, 3, nb)
+    blocks, xos = [], []
+    for b in range(nb):
+        xo = odom(rng)
+        _, x1, x2, p2, size = scene(rng, int(counts[b]), XB, xo)
+        blocks.append((x1, x2, p2, size))
+        xos.append(xo)
+    st = loc.ReprojectSet("ucm", INTR["ucm"], XB, blocks, sparse=True)
+    res, jac = st.evaluate(torch.tensor(np.array(xos), device="cuda"))
+    st.synchronize()
+    res, jac = res.cpu().numpy(), jac.cpu().numpy()
+    for b in range(nb):
+        lo, hi = st.offsets[b], st.offsets[b + 1]
+        if hi == lo:
+            continue
+        r, J = st.evaluate_block(b, [xos[b]])
+        assert np.array_equal(r, res[lo:hi].ravel()) and np.array_equal(J[0], jac[lo:hi].reshape(-1, 6)), b
+        if b % 10 == 0:
+            rr, Jr = vgo.sparse_reproject(MODELS["ucm"], INTR["ucm"], XB, *blocks[b], xos[b])
+            assert_sparse_parity(res[lo:hi], jac[lo:hi], rr, Jr, blocks[b][2], blocks[b][3], "tiny block %d" % b,
+                                 sens=hard_geometry_sensitivity(rng, "ucm", XB, *blocks[b], xos[b]))
+    st.close()
+
+
 def test_argument_errors(loc):
     from visgeom_amd import capi
 

@@ -10,7 +10,8 @@ the HBM fraction they amount to.  tools only -- bench.py stays the driver's cont
 
 Algorithmic bytes per feature (what one evaluation has to move): sparse 48 (x1, x2) + 16 (p2) + 8 (size) + 4 (block index)
 read, 16 (residual pair) + 96 (2 x 6 Jacobian) written = 188 B; mono 24 + 16 + 8 (length) read, 16 + 96 + 80 (2 x 5 length
-rows) written = 240 B.  The per-block frame (70 / 34 doubles) is amortised over the block's points.
+rows) written = 240 B (+ 9.6 B of the block's odometry parameter).  The per-block frame (70 / 34 doubles) is computed in the
+point kernel for mono sets and for sparse launches of at most 256 workgroups; large sparse sets amortise a frame launch.
 
 usage: python tools/bench_local.py [reps]
 """
@@ -96,7 +97,7 @@ def main():
     for r in rows:
         print(json.dumps(r))
     print()
-    print("| case | model | features | evaluation us (frame + point launch) | features/s | algorithmic GB/s | fraction of 8 TB/s |")
+    print("| case | model | features | evaluation us (all launches) | features/s | algorithmic GB/s | fraction of 8 TB/s |")
     print("|---|---|---|---|---|---|---|")
     for r in rows:
         print("| %s | %s | %d | %.1f | %.3e | %.0f | %.3f |" % (r["case"], r["model"], r["features"], r["evaluation_us"], r["features_per_s"], r["GBps"],

@@ -7,10 +7,11 @@
 //
 // In the reference these run one block at a time inside ceres::Solve; SparseOdometry::ransacNPoints
 // (src/localization/sparse_odom.cpp:511-606) solves 200 independent few-point problems per frame pair and then one
-// problem on all inliers.  Here a SET of blocks is resident in HBM and evaluated in two launches: a frame kernel (one lane
-// per block: the transform chain, the InterJacobian constructor, the matrices of the depth Jacobian) and a point kernel
-// (one lane per feature: triangulate, transform, project, 2 x 6 rows), rows streamed out through the same wave tile as
-// the calibration emit kernel.  Arithmetic in the reference's order (-ffp-contract=off); parity tests:
+// problem on all inliers.  Here a SET of blocks is resident in HBM and evaluated per launch: the block frames (the
+// transform chain, the InterJacobian constructor, the matrices of the depth Jacobian: one lane per block) and the points (one
+// lane per feature: triangulate, transform, project, 2 x 6 rows), rows streamed out through the same wave tile as the
+// calibration emit kernel.  Five-point blocks (mono) and small sparse launches compute their frames inside the point kernel
+// (LDS); large sparse sets keep a frame launch of their own (hundreds of points share a frame).  Arithmetic in the reference's order (-ffp-contract=off); parity tests:
 // tests/test_gpu_local_costs.py (<= 1e-10).
 #pragma once
 
@@ -215,7 +216,8 @@ __global__ __launch_bounds__(64) void vg_local_frame_kernel(const double *__rest
 }
 
 struct MonoArgs {
-    const double *frames;   // [n_blocks][kMonoFrame]
+    const double *xb;       // xiBaseCam [6]
+    const double *xi_odom;  // rows of this launch: [count][6]
     const double *intr;
     const double *x1;       // [n_blocks][5][3]
     const double *p2;       // [n_blocks][5][2]
@@ -227,21 +229,45 @@ struct MonoArgs {
     unsigned int n_points;  // count * 5
 };
 
+// A workgroup owns 64 five-point blocks = 320 points: their frames are computed IN the kernel (first wave, one lane per
+// block, into LDS) -- with 5 points per 34-double frame a frame launch of its own writes and re-reads 45 % of the algorithmic bytes
+// on top (1 M features: 103 us in two launches, see profiles/NOTES.md).  The inputs of the point phase are requested before
+// the frame phase, so their latency hides behind it.
+constexpr int kMonoThreads = kEmitThreads;
+constexpr int kMonoWgBlocks = (kMonoThreads + kMonoPoints - 1) / kMonoPoints + 2;
+constexpr int kMonoLdsDoubles = (kMonoThreads / kWave) * 2 * kWave * 6 + kMonoWgBlocks * kMonoFrame;
+
 template <int MODEL>
-__global__ __launch_bounds__(kEmitThreads) void vg_mono_reproject_kernel(MonoArgs a)
+__global__ __launch_bounds__(kMonoThreads) void vg_mono_reproject_kernel(MonoArgs a)
 {
     constexpr int K = CameraTraits<MODEL>::K;
     using d2 = HIP_vector_type<double, 2>;
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *lds_frames = smem + (kMonoThreads / kWave) * 2 * kWave * 6;
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
-    const unsigned int o0 = blockIdx.x * (unsigned)kEmitThreads, o = o0 + tid;
+    const unsigned int o0 = blockIdx.x * (unsigned)kMonoThreads, o = o0 + tid;
     const bool active = o < a.n_points;
     const unsigned int oc = active ? o : a.n_points - 1;
     const unsigned int bl = oc / kMonoPoints, i = oc - bl * kMonoPoints;   // block of this launch, point of the block
     const long long b = a.first_block + bl;
-    const double *f = a.frames + b * kMonoFrame;
-    const double *x1 = a.x1 + (b * kMonoPoints + i) * 3;
+    // frames of the workgroup's blocks
+    const unsigned int bl0 = o0 / kMonoPoints;
+    {
+        const unsigned int last = (o0 + kMonoThreads - 1 < a.n_points ? o0 + kMonoThreads - 1 : a.n_points - 1) / kMonoPoints;
+        if ((unsigned)tid <= last - bl0) {
+            double fr[kMonoFrame];
+            mono_frame(a.xb, a.xi_odom + 6 * (size_t)(bl0 + tid), fr);
+            fr[kMonoFrame - 1] = 0.;
+#pragma unroll
+            for (int k = 0; k < kMonoFrame; k++) lds_frames[tid * kMonoFrame + k] = fr[k];
+        }
+    }
+    __syncthreads();
+    const double *f = lds_frames + (bl - bl0) * kMonoFrame;
+    const double *x1p = a.x1 + (b * kMonoPoints + i) * 3;
+    const double x1[3] = {x1p[0], x1p[1], x1p[2]};
     const double len = a.lengths[(size_t)bl * kMonoPoints + i];
+    const d2 ob = reinterpret_cast<const d2 *>(a.p2)[b * kMonoPoints + i];
     // xVec2[i] = _xVec1[i] * params[1][i]; xi21.transform: R * x + t   (:224-229)
     const double s[3] = {x1[0] * len, x1[1] * len, x1[2] * len};
     double rx[3];
@@ -249,31 +275,32 @@ __global__ __launch_bounds__(kEmitThreads) void vg_mono_reproject_kernel(MonoArg
     const double X0 = rx[0] + f[0], X1 = rx[1] + f[1], X2 = rx[2] + f[2];
     CornerEval<K> e;
     eval_corner<MODEL, true, false>(a.intr, X0, X1, X2, e);
-    const d2 ob = reinterpret_cast<const d2 *>(a.p2)[b * kMonoPoints + i];
     d2 r;
     r.x = e.ok ? e.u - ob.x : kDoubleBig;   // :232-244
     r.y = e.ok ? e.v - ob.y : kDoubleBig;
     if (active) reinterpret_cast<d2 *>(a.res)[o] = r;
-    if (a.jac_len && active) {
-        // rows 2i / 2i + 1 of the [10 x 5] block: zero but for column i  (:262-275)
+    const unsigned int ow = o0 + wave * kWave;
+    int n_valid = 0;
+    if (ow < a.n_points) n_valid = (a.n_points - ow < (unsigned)kWave) ? (int)(a.n_points - ow) : kWave;
+    double *stage = smem + wave * (2 * kWave * 6);
+    if (a.jac_len) {
+        // rows 2i / 2i + 1 of the [10 x 5] block: zero but for column i  (:262-275); streamed out through the wave's tile
         double n2[3];
         mat3_vec(f + 3, x1, n2);
         const double du = e.P[0] * n2[0] + e.P[1] * n2[1] + e.P[2] * n2[2];
         const double dv = e.P[3] * n2[0] + e.P[4] * n2[1] + e.P[5] * n2[2];
-        double *row = a.jac_len + (size_t)o * 10;
+        double row[2 * kMonoPoints];
 #pragma unroll
         for (int c = 0; c < kMonoPoints; c++) {
             row[c] = c == (int)i ? du : 0.;
-            row[5 + c] = c == (int)i ? dv : 0.;
+            row[kMonoPoints + c] = c == (int)i ? dv : 0.;
         }
+        wave_store_rows<kMonoPoints>(stage, row, a.jac_len + (size_t)ow * 2 * kMonoPoints, n_valid, lane);
     }
     if (a.jac_odom) {
         double rows[12];
         pose_rows(e.P, X0, X1, X2, f + 12, rows);   // InterJacobian::dpdxi, failed EUCM points: P = 0 -> zero rows
-        const unsigned int ow = o0 + wave * kWave;
-        int n_valid = 0;
-        if (ow < a.n_points) n_valid = (a.n_points - ow < (unsigned)kWave) ? (int)(a.n_points - ow) : kWave;
-        wave_store_rows<6>(smem + wave * (2 * kWave * 6), rows, a.jac_odom + (size_t)ow * 12, n_valid, lane);
+        wave_store_rows<6>(stage, rows, a.jac_odom + (size_t)ow * 12, n_valid, lane);
     }
 }
 
@@ -284,6 +311,9 @@ struct SparseArgs {
     const double *p2;          // [total][2]
     const double *size;        // [total]
     const int *point_block;    // [total] block of every point
+    const double *xb;          // xiBaseCam [6]                      } the FUSED kernel computes the frames itself
+    const double *xi_odom;     // rows of this launch: [n_blocks][6] }
+    long long first_block;     // block of row 0 of xi_odom
     double *res;               // rows of this launch: [count][2]
     double *jac;               // [count][2][6] or NULL
     long long first_point;
@@ -353,7 +383,13 @@ __device__ __forceinline__ void sparse_point(const SparseArgs &a, const double *
     }
 }
 
-template <int MODEL>
+// FUSED: the frames of the blocks this workgroup's points belong to are computed in the kernel (one lane per block, into
+// LDS behind the store tiles) -- for the launches the reference actually makes per frame pair (200 RANSAC hypotheses of a few
+// points, then one block of all inliers: a handful of workgroups) the frame launch is half of the evaluation's latency.
+// The host takes this route when the grid is small and no workgroup touches more than kSparseWgBlocks blocks.
+constexpr int kSparseWgBlocks = 40;
+
+template <int MODEL, bool FUSED>
 __global__ __launch_bounds__(kEmitThreads) void vg_sparse_reproject_kernel(SparseArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -362,14 +398,23 @@ __global__ __launch_bounds__(kEmitThreads) void vg_sparse_reproject_kernel(Spars
     const bool active = o < a.n_points;
     const long long pt = a.first_point + (active ? o : a.n_points - 1);
     double *stage = smem + wave * (2 * kWave * 6);
-    // The 69 doubles of the block's frame: when all 64 points of the wave belong to ONE block (blocks of hundreds of
-    // inliers) the frame address is wave-uniform and its loads are scalar -- one fetch for the wave instead of 69 vector
-    // loads of the same address in every lane; a wave that straddles blocks (RANSAC hypotheses of a few points each) reads
-    // per lane.  Same arithmetic on both paths.
     const int blk = a.point_block[pt];
-    const int blk0 = __builtin_amdgcn_readfirstlane(blk);
-    if (__builtin_amdgcn_ballot_w64(blk != blk0) == 0) sparse_point<MODEL>(a, a.frames + (long long)blk0 * kSparseFrame, pt, o, active, o0, stage, wave, lane);
-    else sparse_point<MODEL>(a, a.frames + (long long)blk * kSparseFrame, pt, o, active, o0, stage, wave, lane);
+    if constexpr (FUSED) {
+        double *lds_frames = smem + (kEmitThreads / kWave) * 2 * kWave * 6;
+        const unsigned int o_last = o0 + kEmitThreads - 1 < a.n_points ? o0 + kEmitThreads - 1 : a.n_points - 1;
+        const int b_first = a.point_block[a.first_point + o0], b_last = a.point_block[a.first_point + o_last];
+        if (tid <= b_last - b_first)   // blocks without points in between cost a lane each and are never read
+            sparse_frame(a.xb, a.xi_odom + 6 * (size_t)(b_first + tid - a.first_block), lds_frames + tid * kSparseFrame);
+        __syncthreads();
+        sparse_point<MODEL>(a, lds_frames + (blk - b_first) * kSparseFrame, pt, o, active, o0, stage, wave, lane);
+    } else {
+        // The 69 doubles of the block's frame: when all 64 points of the wave belong to ONE block (blocks of hundreds of
+        // inliers) the frame address is wave-uniform and its loads are scalar -- one fetch for the wave instead of 69 vector
+        // loads of the same address in every lane; a wave that straddles blocks reads per lane.  Same arithmetic on both paths.
+        const int blk0 = __builtin_amdgcn_readfirstlane(blk);
+        if (__builtin_amdgcn_ballot_w64(blk != blk0) == 0) sparse_point<MODEL>(a, a.frames + (long long)blk0 * kSparseFrame, pt, o, active, o0, stage, wave, lane);
+        else sparse_point<MODEL>(a, a.frames + (long long)blk * kSparseFrame, pt, o, active, o0, stage, wave, lane);
+    }
 }
 
 // CameraJacobian: L11 | L12 | L22 (jacobian.h:54-71), computed on the host once per call

@@ -19,6 +19,8 @@ struct vg_reproject_set {
     // per-block host entry: parameters in, rows out, through one pinned block and one device block
     int64_t max_points = 0;
     double *h_pin = nullptr, *d_io = nullptr;
+    // sparse: the most blocks any aligned run of kEmitThreads points of the set touches (counting empty blocks in between)
+    int64_t max_wg_span = 0;
 };
 
 namespace vgl {
@@ -121,10 +123,16 @@ inline int create(vg_reproject_set **out, int device, void *hip_stream, int mode
         std::vector<int> pb(T ? T : 1, 0);
         for (int64_t b = 0; b < n_blocks; b++)
             for (int64_t i = s->offsets[(size_t)b]; i < s->offsets[(size_t)b + 1]; i++) pb[(size_t)i] = (int)b;
+        // windows of kEmitThreads points starting at ANY point (a launch may start at any block's first point)
+        for (size_t i = 0, j = 0; i < T; i++) {
+            while (j + 1 < T && j + 1 < i + vg::kEmitThreads) j++;
+            const int64_t span = (int64_t)pb[j] - pb[i] + 1;
+            s->max_wg_span = span > s->max_wg_span ? span : s->max_wg_span;
+        }
         if ((e = hipMalloc(reinterpret_cast<void **>(&s->d_point_block), sizeof(int) * pb.size())) != hipSuccess) { hip_fail(e, "hipMalloc"); destroy(s); return rc; }
         if ((e = hipMemcpy(s->d_point_block, pb.data(), sizeof(int) * pb.size(), hipMemcpyHostToDevice)) != hipSuccess) { hip_fail(e, "hipMemcpy"); destroy(s); return rc; }
     }
-    const size_t fr = (size_t)(n_blocks ? n_blocks : 1) * (sparse ? vg::kSparseFrame : vg::kMonoFrame);
+    const size_t fr = sparse ? (size_t)(n_blocks ? n_blocks : 1) * vg::kSparseFrame : 2;   // mono frames live in LDS only
     if ((e = hipMalloc(reinterpret_cast<void **>(&s->d_frames), sizeof(double) * fr)) != hipSuccess) { hip_fail(e, "hipMalloc"); destroy(s); return rc; }
     const size_t io = io_doubles(s);
     if ((e = hipMalloc(reinterpret_cast<void **>(&s->d_io), sizeof(double) * io)) != hipSuccess) { hip_fail(e, "hipMalloc"); destroy(s); return rc; }
@@ -134,6 +142,7 @@ inline int create(vg_reproject_set **out, int device, void *hip_stream, int mode
 }
 
 constexpr size_t kLocalLds = sizeof(double) * (vg::kEmitThreads / vg::kWave) * 2 * vg::kWave * 6;
+constexpr unsigned int kFusedMaxGrid = 256;   // one workgroup per CU: beyond that the frame work per workgroup is not hidden
 
 // frames of blocks [b0, b0 + nb) from xi_odom (row r = block b0 + r), then the points [p0, p0 + np)
 inline int launch(vg_reproject_set *s, int64_t b0, int64_t nb, const double *xi_odom, const double *lengths, double *res, double *jac0,
@@ -141,12 +150,16 @@ inline int launch(vg_reproject_set *s, int64_t b0, int64_t nb, const double *xi_
 {
     if (!nb) return VG_OK;
     VG_HIP(hipSetDevice(s->device));
-    hipLaunchKernelGGL(vg::vg_local_frame_kernel, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, s->stream, (const double *)s->d_xb, xi_odom,
-                       (long long)b0, (long long)nb, s->sparse ? 1 : 0, s->d_frames);
-    VG_HIP(hipGetLastError());
     const int64_t p0 = s->offsets[(size_t)b0], np = s->offsets[(size_t)(b0 + nb)] - p0;
-    if (!np) return VG_OK;
     const dim3 grid((unsigned)((np + vg::kEmitThreads - 1) / vg::kEmitThreads)), blk(vg::kEmitThreads);
+    // few workgroups: each computes the frames of its own blocks (one launch, no frame round trip through HBM)
+    const bool fused = s->sparse && grid.x <= kFusedMaxGrid && s->max_wg_span <= vg::kSparseWgBlocks;
+    if (s->sparse && !fused) {
+        hipLaunchKernelGGL(vg::vg_local_frame_kernel, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, s->stream, (const double *)s->d_xb, xi_odom,
+                           (long long)b0, (long long)nb, 1, s->d_frames);
+        VG_HIP(hipGetLastError());
+    }
+    if (!np) return VG_OK;
     if (s->sparse) {
         vg::SparseArgs a;
         a.frames = s->d_frames;
@@ -156,18 +169,32 @@ inline int launch(vg_reproject_set *s, int64_t b0, int64_t nb, const double *xi_
         a.p2 = s->d_p2;
         a.size = s->d_size;
         a.point_block = s->d_point_block;
+        a.xb = s->d_xb;
+        a.xi_odom = xi_odom;
+        a.first_block = b0;
         a.res = res;
         a.jac = jac0;
         a.first_point = p0;
         a.n_points = (unsigned)np;
-        switch (s->model) {
-        case vg::kEUCM: hipLaunchKernelGGL((vg::vg_sparse_reproject_kernel<vg::kEUCM>), grid, blk, kLocalLds, s->stream, a); break;
-        case vg::kUCM: hipLaunchKernelGGL((vg::vg_sparse_reproject_kernel<vg::kUCM>), grid, blk, kLocalLds, s->stream, a); break;
-        default: hipLaunchKernelGGL((vg::vg_sparse_reproject_kernel<vg::kMEI>), grid, blk, kLocalLds, s->stream, a); break;
+        if (fused) {
+            const size_t lds = kLocalLds + sizeof(double) * vg::kSparseWgBlocks * vg::kSparseFrame;
+            switch (s->model) {
+            case vg::kEUCM: hipLaunchKernelGGL((vg::vg_sparse_reproject_kernel<vg::kEUCM, true>), grid, blk, lds, s->stream, a); break;
+            case vg::kUCM: hipLaunchKernelGGL((vg::vg_sparse_reproject_kernel<vg::kUCM, true>), grid, blk, lds, s->stream, a); break;
+            default: hipLaunchKernelGGL((vg::vg_sparse_reproject_kernel<vg::kMEI, true>), grid, blk, lds, s->stream, a); break;
+            }
+        } else {
+            switch (s->model) {
+            case vg::kEUCM: hipLaunchKernelGGL((vg::vg_sparse_reproject_kernel<vg::kEUCM, false>), grid, blk, kLocalLds, s->stream, a); break;
+            case vg::kUCM: hipLaunchKernelGGL((vg::vg_sparse_reproject_kernel<vg::kUCM, false>), grid, blk, kLocalLds, s->stream, a); break;
+            default: hipLaunchKernelGGL((vg::vg_sparse_reproject_kernel<vg::kMEI, false>), grid, blk, kLocalLds, s->stream, a); break;
+            }
         }
     } else {
         vg::MonoArgs a;
-        a.frames = s->d_frames;
+        const dim3 mgrid((unsigned)((np + vg::kMonoThreads - 1) / vg::kMonoThreads)), mblk(vg::kMonoThreads);
+        a.xb = s->d_xb;
+        a.xi_odom = xi_odom;
         a.intr = s->d_intr;
         a.x1 = s->d_x1;
         a.p2 = s->d_p2;
@@ -178,9 +205,9 @@ inline int launch(vg_reproject_set *s, int64_t b0, int64_t nb, const double *xi_
         a.first_block = b0;
         a.n_points = (unsigned)np;
         switch (s->model) {
-        case vg::kEUCM: hipLaunchKernelGGL((vg::vg_mono_reproject_kernel<vg::kEUCM>), grid, blk, kLocalLds, s->stream, a); break;
-        case vg::kUCM: hipLaunchKernelGGL((vg::vg_mono_reproject_kernel<vg::kUCM>), grid, blk, kLocalLds, s->stream, a); break;
-        default: hipLaunchKernelGGL((vg::vg_mono_reproject_kernel<vg::kMEI>), grid, blk, kLocalLds, s->stream, a); break;
+        case vg::kEUCM: hipLaunchKernelGGL((vg::vg_mono_reproject_kernel<vg::kEUCM>), mgrid, mblk, sizeof(double) * vg::kMonoLdsDoubles, s->stream, a); break;
+        case vg::kUCM: hipLaunchKernelGGL((vg::vg_mono_reproject_kernel<vg::kUCM>), mgrid, mblk, sizeof(double) * vg::kMonoLdsDoubles, s->stream, a); break;
+        default: hipLaunchKernelGGL((vg::vg_mono_reproject_kernel<vg::kMEI>), mgrid, mblk, sizeof(double) * vg::kMonoLdsDoubles, s->stream, a); break;
         }
     }
     VG_HIP(hipGetLastError());
