@@ -431,6 +431,16 @@ __global__ __launch_bounds__(256) void vg_gram_final_sum_kernel(const double *__
     gram_final_sum_body(in, n_items, entries, out, blockIdx.x);
 }
 
+// The five scalar sums of an LM step (per-workgroup partials of the back-substitution -> out[5], the final-sum order) and,
+// with them, the step's max |g_pose| (a bit pattern kept by atomicMax) copied to `gmax_out`: the host-driven loop points both
+// outputs at pinned host memory -- a store at the end of a kernel instead of a copy command behind it.
+__global__ __launch_bounds__(256) void vg_step_scalars_kernel(const double *__restrict__ in, unsigned int n_items, double *__restrict__ out,
+                                                               const unsigned long long *__restrict__ gmax_bits, unsigned long long *gmax_out)
+{
+    gram_final_sum_body(in, n_items, 5, out, blockIdx.x);
+    if (blockIdx.x == 1 && threadIdx.x == 0 && gmax_out) *gmax_out = *gmax_bits;
+}
+
 // The same two stages for SEVERAL datasets in one launch each (a rig has one Gram array per camera; their sums are
 // launch-latency bound, so four datasets cost two launches instead of eight).  Identical arithmetic and order per
 // dataset as the single-dataset kernels.

@@ -71,6 +71,8 @@ struct SchurArgs {
                            // Schur Gram (rgram[(G+1)^2]), so that it is summed over ranks by that buffer's all-reduce
     const int *gate;       // speculative launches of the device loop: run only if *gate == gate_expect (NULL: always)
     int gate_expect;
+    unsigned long long *zero_u64 = nullptr;  // vg_schur_rows_gram_kernel clears this word (the max |g_pose| of the step that
+                                             // follows): no memset command between two kernels of the host-driven loop
 };
 
 // The elimination of pose i: V_i, g_i gathered from the Gram blocks of every dataset that references the pose, damping,
@@ -192,19 +194,28 @@ __global__ __launch_bounds__(256) void vg_schur_rows_kernel(SchurArgs a)
 
 // vg_schur_rows_kernel AND the Gram of the rows it produces, in one launch: a workgroup owns `poses_per_wg` whole poses per
 // batch (one lane per (pose, column), as above), keeps the batch's 6 x poses_per_wg rows in LDS next to writing them out, and
-// adds their outer products into its own C x C partial (entry-parallel, rows in increasing order: fixed order); `batches`
-// batches per workgroup keep the number of partials in the hundreds.  One strided fixed-order sum over the workgroup
-// partials then gives the Schur complement's Gram -- two launches where there were three (rows, MFMA Gram per 96 rows,
+// adds their outer products into its own C x C partial (entry-parallel, rows in increasing order: fixed order; entry C * C
+// of the partial = the workgroup's count of blocks that were not positive definite); `batches` batches per workgroup keep the
+// number of partials in the hundreds.  One strided fixed-order sum over the C * C + 1 entries of the workgroup partials then
+// gives the Schur complement's Gram and the count -- two launches where there were three (rows, MFMA Gram per 96 rows,
 // sum), and the rows are read back from LDS instead of from HBM.  Not for host-eliminated sequences (mode 2): their rows are
 // rewritten by the host before the Gram.
 constexpr int kSchurThreads = 256;
 
 __global__ __launch_bounds__(kSchurThreads) void vg_schur_rows_gram_kernel(SchurArgs a, int poses_per_wg, int batches,
-                                                                            double *__restrict__ partials /* [n_wg][C*C] */)
+                                                                            double *__restrict__ partials /* [n_wg][C*C + 1] */)
 {
     extern __shared__ __attribute__((aligned(16))) double sm_rows[];  // [batches * poses_per_wg * 6][C + 1] (odd-ish stride)
     const int C = a.G + 1, CS = C + 1, tid = threadIdx.x;
     if (gate_closed(a.gate, a.gate_expect)) return;
+    // poses of this workgroup whose damped block was not positive definite: the last entry of the workgroup's partial, so
+    // that the fixed-order sum over the workgroups delivers the count next to the Gram (no atomic, no counter to clear)
+    __shared__ int s_bad;
+    if (tid == 0) {
+        s_bad = 0;
+        if (a.zero_u64 && blockIdx.x == 0) *a.zero_u64 = 0ull;
+    }
+    __syncthreads();
     const int pl = tid / C, gcol = tid - pl * C;        // pose of the batch, column
     const bool lane_on = pl < poses_per_wg;
     for (int bt = 0; bt < batches; bt++) {
@@ -239,7 +250,7 @@ __global__ __launch_bounds__(kSchurThreads) void vg_schur_rows_gram_kernel(Schur
                     rec[27 + k] = f.vd[k];
                 }
                 rec[33] = f.active ? 1. : 0.;
-                if (f.mode == 0 && !f.pd && a.ref_ptr[i + 1] > a.ref_ptr[i]) atomicAdd(a.bad, 1.);
+                if (f.mode == 0 && !f.pd && a.ref_ptr[i + 1] > a.ref_ptr[i]) atomicAdd(&s_bad, 1);
             }
             fwd6(f.L, w, y);
             double *out = a.rows + (size_t)i * 6 * C + gcol;
@@ -257,7 +268,8 @@ __global__ __launch_bounds__(kSchurThreads) void vg_schur_rows_gram_kernel(Schur
     __syncthreads();
     // entry-parallel Gram of the workgroup's rows (rows in increasing order: a fixed order)
     const int n_rows_wg = batches * poses_per_wg * 6, E = C * (C + 1) / 2;
-    double *P = partials + (size_t)blockIdx.x * C * C;
+    double *P = partials + (size_t)blockIdx.x * (C * C + 1);
+    if (tid == 0) P[C * C] = (double)s_bad;
     for (int e = tid; e < E; e += kSchurThreads) {
         int r = 0, rem = e;
         while (rem >= C - r) {

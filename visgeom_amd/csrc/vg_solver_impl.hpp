@@ -672,6 +672,15 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
     if (!coupled.empty() && opt.allreduce)
         return fail(VG_ERR_INVALID_ARGUMENT, "odometry-coupled sequences need a device communicator (vg_solve_options.comm) for a multi-rank solve, not the host all-reduce callback");
     const bool coupled_multi = !coupled.empty() && multi_rank;
+    // which loop drives the iterations (see "device loop" below); measurement / A-B hooks (vg_debug_set) force a side
+    const bool force_host_loop = vgi::debug_hook(vgi::kHookSolverHostLoop) != 0;
+    const bool force_device_loop = vgi::debug_hook(vgi::kHookSolverDeviceLoop) != 0;
+    const bool device_loop = coupled.empty() && p->priors.empty() && !opt.allreduce && !force_host_loop && (G <= 32 || force_device_loop);
+    // Host-driven loop on one rank without host-eliminated sequences: what the host reads every iteration (the Schur Gram,
+    // the summed Gram blocks, the step's scalars) is WRITTEN INTO PINNED HOST MEMORY by the kernels that produce it, and
+    // the reduced step is read from pinned memory by the back-substitution -- no copy or memset command between two kernels
+    // (each one is an engine hand-over of ~10 us on this stack; the rig's iteration has six of them otherwise).
+    const bool host_direct = !device_loop && !comm && !opt.allreduce && coupled.empty();
 
     // per dataset: local -> global column map, pose column offset, pose references
     std::vector<std::vector<int>> lmap(n_ds);
@@ -745,7 +754,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
         dev_need += 2 * sizeof(double) * ((size_t)p->dss[d].n_blocks * ww + 32) + sizeof(double) * ((size_t)p->dss[d].n_blocks / vg::kSlab + 2) * ww +
                     sizeof(double) * ((size_t)p->dss[d].n_blocks / vg::kValuImagesPerBlock + 2) * ww;  // slab / per-workgroup partial sums
     }
-    dev_need += sizeof(double) * (3 * (size_t)n_params + (size_t)n_poses * vg::kPoseRec + (size_t)n_rows * C + ((size_t)(n_groups > sg_wgs ? n_groups : sg_wgs) + n_slabs + 8) * C * C +
+    dev_need += sizeof(double) * (3 * (size_t)n_params + (size_t)n_poses * vg::kPoseRec + (size_t)n_rows * C + ((size_t)(n_groups > sg_wgs ? n_groups : sg_wgs) + n_slabs + 8) * (C * C + 1) +
                                   (size_t)n_poses + 8 * (size_t)C * C);
     const size_t pin_need = up_need + (1u << 20) + sizeof(double) * ((size_t)n_ds * Wmax * Wmax + 4 * (size_t)C * C);
     VG_HIP(hipSetDevice(p->device));
@@ -785,7 +794,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
     VG_TRY(d_delta.alloc((size_t)n_params));
     VG_TRY(d_rec.alloc((size_t)n_poses * vg::kPoseRec));
     VG_TRY(d_rows.alloc((size_t)n_rows * C));
-    VG_TRY(d_rgroups.alloc((size_t)(n_groups > sg_wgs ? n_groups : sg_wgs) * C * C));
+    VG_TRY(d_rgroups.alloc((size_t)(n_groups > sg_wgs ? n_groups : sg_wgs) * (C * C + 1)));  // fused rows + Gram: C * C + 1 per workgroup
     // [Gram of the pose rows (C x C) | number of pose blocks that were not positive definite]: ONE buffer, so that the
     // count is summed over ranks by the same all-reduce and every rank takes the same accept / reject branch
     VG_TRY(d_rgram.alloc((size_t)C * C + 1));
@@ -803,7 +812,6 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
     VG_TRY(d_small.alloc((size_t)1 + (size_t)(G ? G : 1)));
     VG_HIP(hipMemsetAsync(d_small.p, 0, sizeof(double) * (1 + (size_t)(G ? G : 1)), st));
     VG_HIP(hipMemsetAsync(d_sums.p, 0, sizeof(double) * n_pack, st));
-    d_scal_sum.p = d_sums.p + n_sums;
     d_gmax.p = reinterpret_cast<unsigned long long *>(d_small.p);
     d_xg.p = d_small.p + 1;
     VG_HIP(hipMemsetAsync(d_delta.p, 0, sizeof(double) * (size_t)(n_params ? n_params : 1), st));
@@ -817,6 +825,14 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
     VG_TRY(pin_sums.alloc(h_sums.size()));
     VG_TRY(pin_rgram.alloc(h_rgram.size()));
     VG_TRY(pin_small.alloc((size_t)2 * G + 2));
+    // where the sum kernels deliver [summed Gram blocks | 5 step scalars]: the device buffer (all-reduced / read by the accept
+    // kernel), or straight into the pinned block the host reads
+    double *const sums_out = host_direct ? pin_sums.p : d_sums.p;
+    if (host_direct) {
+        std::memset(pin_sums.p, 0, sizeof(double) * h_sums.size());
+        std::memset(pin_small.p, 0, sizeof(double) * ((size_t)2 * G + 2));
+    }
+    d_scal_sum.p = sums_out + n_sums;
 
     mark("scratch + pinned allocation");
     // several datasets: their fixed-order sums run as ONE slab launch and ONE final launch (descriptor tables for
@@ -835,7 +851,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             sd.entries = Wd[d] * Wd[d];
             VG_TRY(sum_partials[d].alloc((size_t)sd.n_slabs * sd.entries));
             sd.partials = sum_partials[d].p;
-            sd.out = d_sums.p + (size_t)d * Wmax * Wmax;
+            sd.out = sums_out + (size_t)d * Wmax * Wmax;
             sd.first_slab_block = sum_slab_blocks;
             sd.first_final_block = sum_final_blocks;
             sum_slab_blocks += sd.n_slabs;
@@ -867,7 +883,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             VG_TRY(wg_partials[(size_t)d].alloc((size_t)E * pd.n_wg));
             wg_partials_ptr[(size_t)d] = wg_partials[(size_t)d].p;
             pd.partials = wg_partials[(size_t)d].p;
-            pd.out = d_sums.p + (size_t)d * Wmax * Wmax;
+            pd.out = sums_out + (size_t)d * Wmax * Wmax;
             pd.first_block = psum_blocks;
             psum_blocks += (unsigned int)E;
             tab.push_back(pd);
@@ -888,7 +904,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             if ((r = vgi::gram_fused_merged_at(p, x_dev, gp.data(), merged, use_partials ? wg_partials_ptr.data() : nullptr)) != VG_OK) return r;
         }
         for (int d = 0; d < n_ds; d++) {
-            double *sum_d = d_sums.p + (size_t)d * Wmax * Wmax;
+            double *sum_d = sums_out + (size_t)d * Wmax * Wmax;
             const bool robust = opt.soft_l1_scale > 0. && p->dss[d].n_blocks;
             // single dataset, no loss function: Gram blocks and their sum in two launches
             const bool fused_sum = !sum_slab_blocks && !robust;
@@ -925,6 +941,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
                 if (!p->dss[d].n_blocks) VG_HIP(hipMemsetAsync(d_sums.p + (size_t)d * Wmax * Wmax, 0, sizeof(double) * Wmax * Wmax, st));
             if (!n_bs_groups) VG_HIP(hipMemsetAsync(d_sums.p + n_sums, 0, sizeof(double) * 5, st));
         }
+        if (host_direct) return VG_OK;  // one rank, the sums are already where the host reads them
         return vgc::allreduce_sum(comm, d_sums.p, n_pack, st);
     };
     // evaluate at a device parameter buffer and assemble U / gg / cost on the host
@@ -933,7 +950,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
         const double t0 = now_s();
         int r;
         if ((r = enqueue_evaluate(x_dev, set)) != VG_OK) return r;
-        VG_HIP(hipMemcpyAsync(pin_sums.p, d_sums.p, sizeof(double) * h_sums.size(), hipMemcpyDeviceToHost, st));
+        if (!host_direct) VG_HIP(hipMemcpyAsync(pin_sums.p, d_sums.p, sizeof(double) * h_sums.size(), hipMemcpyDeviceToHost, st));
         VG_HIP(hipStreamSynchronize(st));
         std::memcpy(h_sums.data(), pin_sums.p, sizeof(double) * h_sums.size());
         std::fill(Uo.begin(), Uo.end(), 0.);
@@ -994,9 +1011,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
     // against 0.21 for the host-driven loop, Mei 0.118; the 45-column rig 0.338 against 0.293 -- there the one-workgroup
     // factorisation of the reduced system costs more than the host's round trip, so wide systems keep the host loop.
     // vg_debug_set("solver_host_loop" / "solver_device_loop") force a side.
-    const bool force_host_loop = vgi::debug_hook(vgi::kHookSolverHostLoop) != 0;      // measurement / A-B hooks (vg_debug_set)
-    const bool force_device_loop = vgi::debug_hook(vgi::kHookSolverDeviceLoop) != 0;
-    if (coupled.empty() && p->priors.empty() && !opt.allreduce && !force_host_loop && (G <= 32 || force_device_loop)) {
+    if (device_loop) {
         DevBuf<vg::LmState> d_state;
         DevBuf<double> d_U, d_gvec, d_S, d_xcur;
         DevBuf<int> d_Wd;
@@ -1142,7 +1157,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
                 // rows of every pose + the Gram of the rows, one launch; then ONE fixed-order sum over the workgroups
                 hipLaunchKernelGGL(vg::vg_schur_rows_gram_kernel, dim3(sg_wgs), dim3(vg::kSchurThreads), sg_lds, st, sa, sg_ppw, sg_batches, d_rgroups.p);
                 VG_HIP(hipGetLastError());
-                vg::launch_strided_sum(st, d_rgroups.p, sg_wgs, C * C, d_rgram.p);
+                vg::launch_strided_sum(st, d_rgroups.p, sg_wgs, C * C + 1, d_rgram.p);  // the Gram and the count of bad pose blocks
                 VG_HIP(hipGetLastError());
             } else if (multi_rank) {
                 // a rank without poses still joins the sum: the buffer holds the cross-rank total of the previous iteration
@@ -1344,11 +1359,13 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
         std::fill(h_rgram.begin(), h_rgram.end(), 0.);
         bool coupled_ok = true;
         if (n_poses) {
-            VG_HIP(hipMemsetAsync(d_bad, 0, sizeof(double), st));
-            if (coupled.empty())
+            if (coupled.empty()) {
+                sa.zero_u64 = d_gmax.p;  // the step's max |g_pose|, cleared here instead of by a memset in front of the back-substitution
                 hipLaunchKernelGGL(vg::vg_schur_rows_gram_kernel, dim3(sg_wgs), dim3(vg::kSchurThreads), sg_lds, st, sa, sg_ppw, sg_batches, d_rgroups.p);
-            else
+            } else {
+                VG_HIP(hipMemsetAsync(d_bad, 0, sizeof(double), st));
                 hipLaunchKernelGGL(vg::vg_schur_rows_kernel, dim3((unsigned)((n_poses * C + 255) / 256)), dim3(256), 0, st, sa);
+            }
             VG_HIP(hipGetLastError());
             // sequences coupled by odometry: raw V / g / W^T come back, the host eliminates the block-tridiagonal
             // system and puts its rows where the per-pose rows would be
@@ -1378,7 +1395,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
                 VG_HIP(hipStreamSynchronize(st));  // c2.Y may be rewritten before an async copy from pageable memory ends
             }
             if (coupled.empty()) {
-                vg::launch_strided_sum(st, d_rgroups.p, sg_wgs, C * C, d_rgram.p);
+                vg::launch_strided_sum(st, d_rgroups.p, sg_wgs, C * C + 1, host_direct ? pin_rgram.p : d_rgram.p);
             } else {
                 VG_TRY(launch_dense_gram(st, d_rows.p, n_rows, C, rows_per_group, n_groups, d_rgroups.p));
                 vg::launch_strided_sum(st, d_rgroups.p, n_groups, C * C, d_rgram.p);
@@ -1388,8 +1405,10 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             VG_HIP(hipMemsetAsync(d_rgram.p, 0, sizeof(double) * h_rgram.size(), st));  // a rank without poses still joins the sum
         }
         if (n_poses || (comm && comm->n_ranks > 1)) {
-            VG_TRY(vgc::allreduce_sum(comm, d_rgram.p, h_rgram.size(), st));  // Schur complement of the poses of all ranks
-            VG_HIP(hipMemcpyAsync(pin_rgram.p, d_rgram.p, sizeof(double) * h_rgram.size(), hipMemcpyDeviceToHost, st));
+            if (!host_direct) {
+                VG_TRY(vgc::allreduce_sum(comm, d_rgram.p, h_rgram.size(), st));  // Schur complement of the poses of all ranks
+                VG_HIP(hipMemcpyAsync(pin_rgram.p, d_rgram.p, sizeof(double) * h_rgram.size(), hipMemcpyDeviceToHost, st));
+            }
             VG_HIP(hipStreamSynchronize(st));
             std::memcpy(h_rgram.data(), pin_rgram.p, sizeof(double) * h_rgram.size());
         }
@@ -1449,19 +1468,20 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             t0 = now_s();
             if (G) {
                 std::memcpy(pin_small.p, dg.data(), sizeof(double) * G);
-                VG_HIP(hipMemcpyAsync(d_dg.p, pin_small.p, sizeof(double) * G, hipMemcpyHostToDevice, st));
+                if (!host_direct) VG_HIP(hipMemcpyAsync(d_dg.p, pin_small.p, sizeof(double) * G, hipMemcpyHostToDevice, st));
             }
-            VG_HIP(hipMemsetAsync(d_gmax.p, 0, sizeof(unsigned long long), st));
+            if (!(n_poses && coupled.empty())) VG_HIP(hipMemsetAsync(d_gmax.p, 0, sizeof(unsigned long long), st));  // else: cleared by the rows kernel
             vg::BacksubArgs ba;
             ba.s = sa;
-            ba.dg = d_dg.p;
+            ba.dg = host_direct ? pin_small.p : d_dg.p;   // the reduced step: read where the host wrote it
             ba.pose_param = d_pose_param.p;
             ba.gcol_param = d_gcol_param.p;
             ba.delta = d_delta.p;
             ba.scal = d_scal.p;
             ba.gmax_bits = d_gmax.p;
             ba.x = d_x.p;
-            ba.xg = d_xg.p;
+            double *ps = pin_small.p + G;  // [gmax 1 | xg G]
+            ba.xg = host_direct ? ps + 1 : d_xg.p;   // current values of the global columns, for the host
             ba.lo = d_glo.p;
             ba.hi = d_ghi.p;
             ba.x_new = d_xc.p;   // host-eliminated sequences overwrite their poses below
@@ -1471,9 +1491,9 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
                 else hipLaunchKernelGGL(vg::vg_backsub_kernel<8>, dim3(bs_grid), dim3(vg::kBsThreads), 0, st, ba);
                 VG_HIP(hipGetLastError());
             }
-            if (n_bs_groups) {  // fixed-order sum of the per-workgroup partials
-                hipLaunchKernelGGL(vg::vg_gram_final_sum_kernel, dim3(2), dim3(256), 0, st, (const double *)d_scal.p, n_bs_groups, 5,
-                                   d_scal_sum.p);
+            if (n_bs_groups) {  // fixed-order sum of the per-workgroup partials (and, host_direct, max |g_pose| to the host)
+                hipLaunchKernelGGL(vg::vg_step_scalars_kernel, dim3(2), dim3(256), 0, st, (const double *)d_scal.p, n_bs_groups, d_scal_sum.p,
+                                   (const unsigned long long *)d_gmax.p, host_direct ? reinterpret_cast<unsigned long long *>(ps) : nullptr);
                 VG_HIP(hipGetLastError());
             }
             double host_scal[5] = {0., 0., 0., 0., 0.};
@@ -1495,9 +1515,9 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
                                    d_xc.p + c2.param_off);
                 VG_HIP(hipGetLastError());
             }
-            double *ps = pin_small.p + G;  // [gmax 1 | xg G]
-            // without poses the five scalar sums (tail of d_sums) stay at the zeros they were initialised with
-            VG_HIP(hipMemcpyAsync(ps, d_small.p, sizeof(double) * (1 + (size_t)G), hipMemcpyDeviceToHost, st));
+            // without poses the five scalar sums (tail of the sums block) stay at the zeros they were initialised with, and so
+            // does max |g_pose|
+            if (!host_direct) VG_HIP(hipMemcpyAsync(ps, d_small.p, sizeof(double) * (1 + (size_t)G), hipMemcpyDeviceToHost, st));
             t_schur += now_s() - t0;
             // No wait here: the candidate evaluation does not depend on these scalars, it is queued right behind the
             // step on the same stream, and its own read-back synchronises once for both (one host round trip per
