@@ -495,7 +495,7 @@ int vg_camera_jacobian_evaluate(int device, void *hip_stream, int model, const d
 /* ---- measurement / test hooks.  The library reads no environment variable to change what it computes or how; the A/B
  * switches used by tests/ and tools/ are set here (process-wide, not thread safe): "inline_chain_max_bytes", "gram_force_mfma",
  * "gram_ch1", "gram_no_merge", "max_obs_per_launch", "solver_timing", "solver_host_loop", "solver_device_loop",
- * "solver_no_speculation"; value 0 restores the default.  A production build (without VG_DEBUG_HOOKS) has none of them and
+ * "solver_no_speculation", "emit_equal_tiles"; value 0 restores the default.  A production build (without VG_DEBUG_HOOKS) has none of them and
  * returns VG_ERR_STATE.  (VG_RCCL_LIBRARY, the path of the RCCL library to bind, is deployment configuration, not a hook.) */
 int vg_debug_set(const char *name, long long value);
 

@@ -30,6 +30,7 @@ enum DebugHook {
     kHookSolverHostLoop,           // force the host-driven LM loop
     kHookSolverDeviceLoop,         // force the device-resident LM loop
     kHookSolverNoSpeculation,      // queue one LM iteration at a time
+    kHookEmitEqualTiles,           // merged emit launch: 1 = equal tile counts per XCD, 2 = equal bytes, whatever the size
     kHookCount
 };
 #ifdef VG_DEBUG_HOOKS
