@@ -279,6 +279,11 @@ int vg_dataset_gram_fused_sum(vg_problem *p, int dataset_id, double *gram, doubl
  * dataset): the datasets (chains of one to five members, boards of more than 32 points) share ONE launch -- a stereo pair
  * or a rig is several launches of a few hundred workgroups otherwise, each ending in a nearly empty round. */
 int vg_problem_gram_fused(vg_problem *p, double *const *grams);
+/* vg_problem_gram_fused AND the fixed-order sum of every dataset's blocks (sums[d]: device [W*W], required for every
+ * dataset; an empty dataset's sum is zero): the merged launch leaves per-workgroup partial sums and ONE more launch adds
+ * them for all datasets -- a normal-equation build of a stereo pair or a rig is chain prep + two launches.  Each sum is
+ * bit-identical to vg_dataset_gram_fused_sum's. */
+int vg_problem_gram_fused_sum(vg_problem *p, double *const *grams, double *const *sums);
 /* two-pass: the same Gram matrices from rows already materialised by vg_dataset_evaluate
  * (all of residuals, jac_intr and every jac_member[l] are required). */
 int vg_dataset_gram_from_rows(vg_problem *p, int dataset_id, const double *residuals, const double *jac_intr,

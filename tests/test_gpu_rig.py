@@ -191,6 +191,20 @@ def test_all_gram_blocks_in_one_launch_equal_the_per_dataset_entry(vg, n):
         p.synchronize()
         for k, (a, b) in enumerate(zip(ref, got)):
             assert torch.equal(a, b), "dataset %d, forced frames %s" % (k, forced)
+        # vg_problem_gram_fused_sum: the same blocks, and every dataset's fixed-order sum from ONE more launch -- bit for bit
+        # the sums of the per-dataset entry
+        ref_s = [p.alloc_gram(ds)[1] for ds in dss]
+        got_b = [torch.full_like(g, float("nan")) for g in ref]
+        got_s = [torch.full_like(t, float("nan")) for t in ref_s]
+        p.prepare()
+        for ds, g, t in zip(dss, ref, ref_s):
+            p.gram_fused_sum(ds, g, t)
+        p.prepare()
+        p.gram_fused_sum_all(got_b, got_s)
+        p.synchronize()
+        for k in range(len(dss)):
+            assert torch.equal(ref[k], got_b[k]) and torch.equal(ref_s[k], got_s[k]), "dataset %d, forced frames %s" % (k, forced)
+            assert torch.allclose(got_s[k], got_b[k].sum(0), rtol=1e-12, atol=0)
     p.close()
 
 
@@ -228,6 +242,17 @@ def test_merged_gram_launch_with_datasets_it_cannot_take(vg):
     p.synchronize()
     for k, (a, b) in enumerate(zip(ref, got)):
         assert torch.equal(a, b), "dataset %d" % k
+    # the summed entry on the same mix: two datasets from the merged launch + ONE sum launch, the third on its own route
+    ref_s = [p.alloc_gram(ds)[1] for ds in dss]
+    got_b = [torch.full_like(g, float("nan")) for g in ref]
+    got_s = [torch.full_like(t, float("nan")) for t in ref_s]
+    p.prepare()
+    for ds, g, t in zip(dss, ref, ref_s):
+        p.gram_fused_sum(ds, g, t)
+    p.gram_fused_sum_all(got_b, got_s)
+    p.synchronize()
+    for k in range(3):
+        assert torch.equal(ref[k], got_b[k]) and torch.equal(ref_s[k], got_s[k]), "dataset %d" % k
     s = p.solve(max_num_iterations=100)
     assert s["termination"].startswith("CONVERGENCE") and s["final_cost"] < s["initial_cost"]
     p.close()

@@ -109,10 +109,8 @@ def main():
 
         def jtj():
             p.prepare()
-            if len(dss) > 1:   # every dataset in one pass (vg_problem_gram_fused: merged launch), then the fixed-order sums
-                p.gram_fused_all([g for g, _ in grams])
-                for (ds, _, _, _), (gram, gsum) in zip(dss, grams):
-                    p.gram_sum(ds, gram, gsum)
+            if len(dss) > 1:   # every dataset in one pass (vg_problem_gram_fused_sum: merged Gram launch + ONE sum launch)
+                p.gram_fused_sum_all([g for g, _ in grams], [s for _, s in grams])
             else:
                 for (ds, _, _, _), (gram, gsum) in zip(dss, grams):
                     p.gram_fused_sum(ds, gram, gsum)

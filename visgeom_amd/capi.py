@@ -116,6 +116,7 @@ SIGNATURES = {
     "vg_dataset_gram_width": (ctypes.c_int, [_vp, ctypes.c_int]),
     "vg_dataset_gram_fused": (ctypes.c_int, [_vp, ctypes.c_int, _vp]),
     "vg_problem_gram_fused": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_void_p)]),
+    "vg_problem_gram_fused_sum": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p)]),
     "vg_dataset_gram_fused_sum": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp]),
     "vg_dataset_gram_from_rows": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vpp, _vp]),
     "vg_dataset_gram_sum": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp]),

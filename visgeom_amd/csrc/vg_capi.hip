@@ -1053,6 +1053,59 @@ int vg_problem_gram_fused(vg_problem *p, double *const *grams)
     return VG_OK;
 }
 
+int vg_problem_gram_fused_sum(vg_problem *p, double *const *grams, double *const *sums)
+{
+    if (!p || !grams || !sums) return fail(VG_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!p->finalized) return fail(VG_ERR_STATE, "problem not finalized");
+    VG_HIP(hipSetDevice(p->device));
+    const int n_ds = (int)p->dss.size();
+    int rc;
+    for (int i = 0; i < n_ds; i++) {
+        if (!sums[i]) return fail(VG_ERR_INVALID_ARGUMENT, "sum is NULL");
+        if (p->dss[i].n_blocks && !grams[i]) return fail(VG_ERR_INVALID_ARGUMENT, "gram is NULL");
+    }
+    if (vgi::gram_needs_frames(p) && (rc = vgi::ensure_frames(p)) != VG_OK) return rc;
+    // the datasets that share the merged launch leave per-workgroup partial sums; ONE launch adds them for all of them
+    std::vector<double *> parts((size_t)n_ds, nullptr);
+    for (int i = 0; i < n_ds; i++) {
+        Dataset &d = p->dss[i];
+        if (!d.n_blocks || d.n_blocks > 0x7fffffff) continue;
+        const int W = p->cams[d.camera].K + 6 * d.L + 1, E = W * (W + 1) / 2;
+        const size_t n_wg = (size_t)((d.n_blocks + vg::kValuImagesPerBlock - 1) / vg::kValuImagesPerBlock);
+        if (!d.d_wg_partials) VG_HIP(hipMalloc(&d.d_wg_partials, sizeof(double) * (size_t)E * n_wg));
+        parts[(size_t)i] = d.d_wg_partials;
+    }
+    std::vector<char> taken;
+    if ((rc = vgi::gram_fused_merged_at(p, p->d_params, grams, taken, parts.data())) != VG_OK) return rc;
+    vg::PartialSumArgs a;
+    a.n = 0;
+    unsigned int blocks = 0;
+    auto flush = [&]() {
+        if (!a.n) return;
+        hipLaunchKernelGGL(vg::vg_gram_partials_sum_args_kernel, dim3(blocks), dim3(256), 0, p->stream, a);
+        a.n = 0;
+        blocks = 0;
+    };
+    for (int i = 0; i < n_ds; i++) {
+        if (!taken[(size_t)i]) continue;
+        const Dataset &d = p->dss[i];
+        const int W = p->cams[d.camera].K + 6 * d.L + 1;
+        vg::PartialSumDataset &pd = a.ds[a.n++];
+        pd.partials = parts[(size_t)i];
+        pd.out = sums[i];
+        pd.n_wg = (unsigned int)((d.n_blocks + vg::kValuImagesPerBlock - 1) / vg::kValuImagesPerBlock);
+        pd.W = W;
+        pd.first_block = blocks;
+        blocks += (unsigned int)(W * (W + 1) / 2);
+        if (a.n == vg::kPartialSumMax) flush();
+    }
+    flush();
+    VG_HIP(hipGetLastError());
+    for (int i = 0; i < n_ds; i++)   // what the merged launch did not take (a single dataset, tiny boards, empty datasets)
+        if (!taken[(size_t)i] && (rc = vgi::gram_fused_at(p, i, p->d_params, grams[i], sums[i])) != VG_OK) return rc;
+    return VG_OK;
+}
+
 int vg_dataset_gram_fused_sum(vg_problem *p, int dataset_id, double *gram, double *sum)
 {
     int rc = valid_dataset(p, dataset_id);

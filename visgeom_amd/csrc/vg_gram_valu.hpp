@@ -732,11 +732,8 @@ struct PartialSumDataset {
     unsigned int first_block;  // first workgroup of this dataset in the launch (E of them)
 };
 
-__global__ __launch_bounds__(256) void vg_gram_partials_sum_multi_kernel(const PartialSumDataset *__restrict__ ds, int n_ds)
+__device__ __forceinline__ void gram_partials_sum_entry(const PartialSumDataset &D)
 {
-    int d = 0;
-    while (d + 1 < n_ds && blockIdx.x >= ds[d + 1].first_block) d++;
-    const PartialSumDataset D = ds[d];
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
     const int e = (int)(blockIdx.x - D.first_block);
     const double *src = D.partials + (size_t)e * D.n_wg;
@@ -766,6 +763,29 @@ __global__ __launch_bounds__(256) void vg_gram_partials_sum_multi_kernel(const P
         D.out[r * D.W + c] = t;
         D.out[c * D.W + r] = t;
     }
+}
+
+__global__ __launch_bounds__(256) void vg_gram_partials_sum_multi_kernel(const PartialSumDataset *__restrict__ ds, int n_ds)
+{
+    int d = 0;
+    while (d + 1 < n_ds && blockIdx.x >= ds[d + 1].first_block) d++;
+    const PartialSumDataset D = ds[d];
+    gram_partials_sum_entry(D);
+}
+
+// the same with the table in the kernel arguments (vg_problem_gram_fused_sum: the output pointers are the caller's and may
+// change from call to call -- no table to upload)
+constexpr int kPartialSumMax = 8;
+struct PartialSumArgs {
+    PartialSumDataset ds[kPartialSumMax];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void vg_gram_partials_sum_args_kernel(PartialSumArgs a)
+{
+    int d = 0;
+    while (d + 1 < a.n && blockIdx.x >= a.ds[d + 1].first_block) d++;
+    gram_partials_sum_entry(a.ds[d]);
 }
 
 // Sum of n_items row-major blocks of `entries` doubles: out[e] = sum_i in[i * entries + e], one workgroup per entry, every

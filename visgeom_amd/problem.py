@@ -318,6 +318,16 @@ class CalibrationProblem:
             arr[i] = g.data_ptr() if g is not None else None
         capi.check(self._lib.vg_problem_gram_fused(self._h, arr))
 
+    def gram_fused_sum_all(self, grams, sums):
+        """gram_fused_all + the fixed-order sum of every dataset's blocks (sums[d]: [W, W] tensor), the sums of all merged
+        datasets in ONE more launch (vg_problem_gram_fused_sum)."""
+        n = max(len(grams), 1)
+        ga, sa = (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)()
+        for i, (g, s) in enumerate(zip(grams, sums)):
+            ga[i] = g.data_ptr() if g is not None else None
+            sa[i] = s.data_ptr()
+        capi.check(self._lib.vg_problem_gram_fused_sum(self._h, ga, sa))
+
     def gram_fused_sum(self, d, gram, out):
         """gram_fused + the fixed-order sum over the dataset's blocks in two launches (vg_dataset_gram_fused_sum)."""
         capi.check(self._lib.vg_dataset_gram_fused_sum(self._h, d, ctypes.c_void_p(gram.data_ptr()),
