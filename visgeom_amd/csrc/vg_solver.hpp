@@ -200,25 +200,28 @@ __global__ __launch_bounds__(256) void vg_schur_rows_kernel(SchurArgs a)
 // gives the Schur complement's Gram and the count -- two launches where there were three (rows, MFMA Gram per 96 rows,
 // sum), and the rows are read back from LDS instead of from HBM.  Not for host-eliminated sequences (mode 2): their rows are
 // rewritten by the host before the Gram.
-constexpr int kSchurThreads = 256;
+constexpr int kSchurThreads = 256;      // lanes of one batch: (pose of the batch, column)
+constexpr int kSchurMaxBatches = 4;    // batches of a workgroup run side by side: blockDim.x = kSchurThreads * batches
 
-__global__ __launch_bounds__(kSchurThreads) void vg_schur_rows_gram_kernel(SchurArgs a, int poses_per_wg, int batches,
+__global__ __launch_bounds__(kSchurThreads * kSchurMaxBatches) void vg_schur_rows_gram_kernel(SchurArgs a, int poses_per_wg, int batches,
                                                                             double *__restrict__ partials /* [n_wg][C*C + 1] */)
 {
     extern __shared__ __attribute__((aligned(16))) double sm_rows[];  // [batches * poses_per_wg * 6][C + 1] (odd-ish stride)
-    const int C = a.G + 1, CS = C + 1, tid = threadIdx.x;
+    const int C = a.G + 1, CS = C + 1, tid = threadIdx.x % kSchurThreads;
     if (gate_closed(a.gate, a.gate_expect)) return;
     // poses of this workgroup whose damped block was not positive definite: the last entry of the workgroup's partial, so
     // that the fixed-order sum over the workgroups delivers the count next to the Gram (no atomic, no counter to clear)
     __shared__ int s_bad;
-    if (tid == 0) {
+    if (threadIdx.x == 0) {
         s_bad = 0;
         if (a.zero_u64 && blockIdx.x == 0) *a.zero_u64 = 0ull;
     }
     __syncthreads();
     const int pl = tid / C, gcol = tid - pl * C;        // pose of the batch, column
     const bool lane_on = pl < poses_per_wg;
-    for (int bt = 0; bt < batches; bt++) {
+    // every batch has its own 256 lanes: the chains pose -> reference list -> Gram blocks -> factorisation of the batches
+    // overlap instead of following one another (four in a row were 13 us of a wave's life, 73 % of it waiting)
+    for (int bt = threadIdx.x / kSchurThreads; bt < batches; bt += blockDim.x / kSchurThreads) {
         const int i = (blockIdx.x * batches + bt) * poses_per_wg + pl;
         double y[6] = {0., 0., 0., 0., 0., 0.};
         if (lane_on && i < a.n_poses) {
@@ -269,8 +272,8 @@ __global__ __launch_bounds__(kSchurThreads) void vg_schur_rows_gram_kernel(Schur
     // entry-parallel Gram of the workgroup's rows (rows in increasing order: a fixed order)
     const int n_rows_wg = batches * poses_per_wg * 6, E = C * (C + 1) / 2;
     double *P = partials + (size_t)blockIdx.x * (C * C + 1);
-    if (tid == 0) P[C * C] = (double)s_bad;
-    for (int e = tid; e < E; e += kSchurThreads) {
+    if (threadIdx.x == 0) P[C * C] = (double)s_bad;
+    for (int e = threadIdx.x; e < E; e += blockDim.x) {
         int r = 0, rem = e;
         while (rem >= C - r) {
             rem -= C - r;

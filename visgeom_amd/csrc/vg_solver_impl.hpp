@@ -740,7 +740,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
     // `sg_ppw` poses each so that the partials stay in the hundreds and the rows of a workgroup fit 48 KB of LDS
     const int sg_ppw = vg::kSchurThreads / (G + 1);
     int sg_batches = (int)((n_poses + (int64_t)sg_ppw * 512 - 1) / ((int64_t)sg_ppw * 512));
-    sg_batches = sg_batches < 1 ? 1 : sg_batches;
+    sg_batches = sg_batches < 1 ? 1 : (sg_batches > vg::kSchurMaxBatches ? vg::kSchurMaxBatches : sg_batches);
     while (sg_batches > 1 && sizeof(double) * (size_t)sg_batches * sg_ppw * 6 * (G + 2) > 48 * 1024) sg_batches--;
     const size_t sg_lds = sizeof(double) * (size_t)sg_batches * sg_ppw * 6 * (G + 2);
     const unsigned int sg_wgs = (unsigned int)((n_poses + (int64_t)sg_ppw * sg_batches - 1) / ((int64_t)sg_ppw * sg_batches));
@@ -1155,7 +1155,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             sa.gate_expect = par;
             if (n_poses) {
                 // rows of every pose + the Gram of the rows, one launch; then ONE fixed-order sum over the workgroups
-                hipLaunchKernelGGL(vg::vg_schur_rows_gram_kernel, dim3(sg_wgs), dim3(vg::kSchurThreads), sg_lds, st, sa, sg_ppw, sg_batches, d_rgroups.p);
+                hipLaunchKernelGGL(vg::vg_schur_rows_gram_kernel, dim3(sg_wgs), dim3(vg::kSchurThreads * sg_batches), sg_lds, st, sa, sg_ppw, sg_batches, d_rgroups.p);
                 VG_HIP(hipGetLastError());
                 vg::launch_strided_sum(st, d_rgroups.p, sg_wgs, C * C + 1, d_rgram.p);  // the Gram and the count of bad pose blocks
                 VG_HIP(hipGetLastError());
@@ -1361,7 +1361,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
         if (n_poses) {
             if (coupled.empty()) {
                 sa.zero_u64 = d_gmax.p;  // the step's max |g_pose|, cleared here instead of by a memset in front of the back-substitution
-                hipLaunchKernelGGL(vg::vg_schur_rows_gram_kernel, dim3(sg_wgs), dim3(vg::kSchurThreads), sg_lds, st, sa, sg_ppw, sg_batches, d_rgroups.p);
+                hipLaunchKernelGGL(vg::vg_schur_rows_gram_kernel, dim3(sg_wgs), dim3(vg::kSchurThreads * sg_batches), sg_lds, st, sa, sg_ppw, sg_batches, d_rgroups.p);
             } else {
                 VG_HIP(hipMemsetAsync(d_bad, 0, sizeof(double), st));
                 hipLaunchKernelGGL(vg::vg_schur_rows_kernel, dim3((unsigned)((n_poses * C + 255) / 256)), dim3(256), 0, st, sa);
