@@ -903,3 +903,50 @@ def test_iteration_limits_of_the_device_resident_loop(vg, model):
     q.close()
     assert abs(s2["final_cost"] - sf["final_cost"]) <= 1e-10 * sf["final_cost"]
     assert np.max(np.abs(x2 - xf) / np.maximum(np.abs(xf), 1.0)) < 1e-7
+
+
+@pytest.mark.parametrize("case", ["mono", "stereo_empty_second_dataset", "stereo_soft_l1"])
+def test_host_driven_loop_equals_the_device_resident_loop(vg, case):
+    """the host-driven loop (taken for wide systems, priors, odometry; forced here through the debug hook) delivers what
+    the host reads through pinned memory written by the kernels themselves -- no copy commands: same iterates as the
+    device-resident loop on a mono set, on a stereo pair whose second dataset is EMPTY (its slot of the sums is cleared by
+    a memset on the pinned block) and with the SoftLOne loss (the re-weighting kernel runs between Gram and sums)"""
+    from visgeom_amd import capi, synthetic as S
+
+    def build():
+        p = vg.CalibrationProblem(0)
+        if case == "mono":
+            d = S.make_mono("eucm", 300, 1)
+            c = p.add_camera("eucm", d["init_intrinsics"])
+            s = p.add_transform(False, d["init_poses"])
+            p.add_dataset(c, [(s, 0)], d["board"], d["corners"])
+        else:
+            st = S.make_stereo(40, sigma=0.1)
+            c1 = p.add_camera("eucm", st["init_intrinsics1"])
+            c2 = p.add_camera("eucm", st["init_intrinsics2"], constant=(case == "stereo_empty_second_dataset"))
+            x12 = p.add_transform(True, st["init_xi12"], constant=(case == "stereo_empty_second_dataset"))
+            seq = p.add_transform(False, st["init_poses"])
+            p.add_dataset(c1, [(seq, 0)], st["board"], st["corners1"])
+            n2 = 0 if case == "stereo_empty_second_dataset" else 40
+            p.add_dataset(c2, [(x12, 1), (seq, 0)], st["board"], st["corners2"][:n2], image_index=np.arange(n2, dtype=np.int32))
+        p.finalize()
+        return p
+
+    kw = {"max_num_iterations": 60}
+    if case == "stereo_soft_l1":
+        kw["soft_l1_scale"] = 2.0
+    out = []
+    for host in (0, 1):
+        capi.debug_set("solver_host_loop", host)
+        try:
+            p = build()
+            s = p.solve(**kw)
+            out.append((s, p.get_parameters()))
+            p.close()
+        finally:
+            capi.debug_set("solver_host_loop", 0)
+    (s_dev, x_dev), (s_host, x_host) = out
+    assert s_dev["termination"].startswith("CONVERGENCE") and s_host["termination"].startswith("CONVERGENCE")
+    assert abs(s_host["initial_cost"] - s_dev["initial_cost"]) <= 1e-13 * s_dev["initial_cost"]
+    assert abs(s_host["final_cost"] - s_dev["final_cost"]) <= 1e-9 * s_dev["final_cost"]
+    assert np.max(np.abs(x_host - x_dev) / np.maximum(np.abs(x_dev), 1.0)) < 1e-6
