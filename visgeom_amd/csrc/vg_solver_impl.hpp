@@ -1097,13 +1097,16 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
         // outcome of step k -- every kernel of a queued iteration returns at once if the gate says otherwise (a
         // rejected step: the same parity is queued again; convergence: gate = -1) -- and only then waits for the state
         // of iteration k.  The GPU always has the next iteration in its queue: no launch latency, no idle time behind
-        // the host's read-back.  Robust (SoftLOne) evaluations re-weight the Gram set in place with an ungated kernel
-        // and RCCL calls cannot be skipped on one rank only, so those solves queue one iteration at a time.
+        // the host's read-back.  Robust (SoftLOne) evaluations re-weight the Gram set in place with an ungated kernel, so
+        // those solves queue one iteration at a time.  Several ranks speculate too: every rank holds the same state, so every
+        // rank queues the same launches and the same collectives; a collective of an iteration that skips itself is NOT
+        // skipped -- it runs on every rank, on buffers nobody reads (whatever a real iteration reads it has rewritten or
+        // cleared before its own collective).
         // MEASURED (tools/exp/solve_probe.py, 10 k images, state published by the accept kernel itself): EUCM 0.111 vs
         // 0.115 ms per iteration, Mei 0.119 vs 0.126 -- the iteration is bound by its eight dependent launches on the GPU.
         // Replaying the gated iteration as a hipGraph (one per parity) was slower than queueing its launches: 0.120 /
         // 0.126 ms (profiles/NOTES.md).  vg_debug_set("solver_no_speculation", 1) queues one iteration at a time.
-        const bool speculate = opt.soft_l1_scale <= 0. && !multi_rank && !vgi::debug_hook(vgi::kHookSolverNoSpeculation);
+        const bool speculate = opt.soft_l1_scale <= 0. && !vgi::debug_hook(vgi::kHookSolverNoSpeculation);
         DevBuf<double> *gset[2] = {gramA, gramB};
         vg::SolveDatasetDev *dset[2] = {d_dsA.p, d_dsB.p};
         double *xbuf[2] = {d_x.p, d_xc.p};
