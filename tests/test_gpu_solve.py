@@ -950,3 +950,29 @@ def test_host_driven_loop_equals_the_device_resident_loop(vg, case):
     assert abs(s_host["initial_cost"] - s_dev["initial_cost"]) <= 1e-13 * s_dev["initial_cost"]
     assert abs(s_host["final_cost"] - s_dev["final_cost"]) <= 1e-9 * s_dev["final_cost"]
     assert np.max(np.abs(x_host - x_dev) / np.maximum(np.abs(x_dev), 1.0)) < 1e-6
+
+
+def test_wide_system_on_the_device_resident_loop(vg):
+    """45 global columns (a four-camera rig) take the host-driven loop by default; forced onto the device-resident loop the
+    reduced system is factorised by the entry-parallel one-workgroup kernel (vg_lm_reduced_solve_entries_kernel, 24 < G <=
+    63): same optimum (iteration counts differ at the tail: with tolerances of 1e-15 the last accept / reject decisions hang
+    on the last bits of the two loops' differently ordered sums)"""
+    from tests.test_gpu_rig import build_rig
+    from visgeom_amd import capi, synthetic as S
+
+    r = S.make_rig(30, sigma=0.1)
+    out = []
+    for device in (0, 1):
+        capi.debug_set("solver_device_loop", device)
+        try:
+            p, cams, x1k, seq, dss = build_rig(vg, r)
+            s = p.solve(max_num_iterations=200)
+            out.append((s, p.get_parameters()))
+            p.close()
+        finally:
+            capi.debug_set("solver_device_loop", 0)
+    (s_host, x_host), (s_dev, x_dev) = out
+    assert s_host["num_global_columns"] == 45
+    assert s_dev["termination"].startswith("CONVERGENCE") and s_host["termination"].startswith("CONVERGENCE")
+    assert abs(s_host["final_cost"] - s_dev["final_cost"]) <= 1e-9 * s_dev["final_cost"]
+    assert np.max(np.abs(x_host - x_dev) / np.maximum(np.abs(x_dev), 1.0)) < 1e-6

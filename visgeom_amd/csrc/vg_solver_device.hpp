@@ -147,6 +147,118 @@ __global__ __launch_bounds__(kLmThreads) void vg_lm_reduced_solve_kernel(LmSolve
     lm_reduced_solve_body(a, sm, threadIdx.x, blockDim.x, true);
 }
 
+// Wide reduced systems (a rig: G = 45) in one workgroup of 256 threads, ENTRY-parallel: thread t owns the entries
+// e = t + 256 m of the lower triangle of the augmented matrix [[S, .], [rhs^T, .]] (row G of its factor is y = L^-1 rhs: the
+// forward substitution comes with the factorisation).  A column step is: every thread takes sqrt(A_jj) itself, the first G + 1
+// threads scale column j, barrier, every owned entry (i, k > j) subtracts L_ij L_kj (independent LDS read-modify-writes),
+// barrier.  The row-per-lane version above walks up to G entries of its row one after the other per column step: 107 us at
+// G = 45 (rocprofv3), which is what kept the rig on the host-driven loop.  Each entry still sees its subtractions in
+// increasing column order, square roots and divisions are IEEE: same bits as lm_reduced_solve_body / the host's chol_solve.
+constexpr int kEntrySolveMaxG = 63;
+constexpr int kEntrySolveSlots = ((kEntrySolveMaxG + 1) * (kEntrySolveMaxG + 2) / 2 + kLmThreads - 1) / kLmThreads;   // 9
+
+__device__ __forceinline__ double readlane_f64(double v, int lane /* uniform */)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// dynamic LDS in doubles: A [C*C] | S [E] | Ld [G] | x [G] | held [G] | flag [2]
+__host__ __device__ inline size_t lm_entry_solve_lds_doubles(int G)
+{
+    const size_t C = (size_t)G + 1;
+    return C * C + C * (C + 1) / 2 + 3 * (size_t)G + 2;
+}
+
+__global__ __launch_bounds__(kLmThreads) void vg_lm_reduced_solve_entries_kernel(LmSolveArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    LmState *st = a.st;
+    if (st->done || (a.gate_expect >= 0 && st->gate != a.gate_expect)) return;
+    const int G = a.G, C = G + 1, E = C * (C + 1) / 2, tid = threadIdx.x;
+    double *A = sm, *S = A + C * C, *Ld = S + E, *x = Ld + G, *heldf = x + G, *flag = heldf + G;
+    const double mu = st->mu;
+    const double *U = a.U + (size_t)st->ucur * G * G, *gg = a.gg + (size_t)st->ucur * G;
+    int ri[kEntrySolveSlots], ck[kEntrySolveSlots];
+#pragma unroll
+    for (int m = 0; m < kEntrySolveSlots; m++) {
+        const int e = tid + kLmThreads * m;
+        int i = (int)((sqrtf(8.f * (float)e + 1.f) - 1.f) * 0.5f);
+        while (i * (i + 1) / 2 > e) i--;
+        while ((i + 1) * (i + 2) / 2 <= e) i++;
+        const int k = e - i * (i + 1) / 2;
+        const bool valid = e < E - 1;   // (G, G) is not used
+        ri[m] = valid ? i : -1;
+        ck[m] = valid ? k : 0;
+        if (valid) {
+            double v;
+            if (i < G) {
+                v = U[(size_t)i * G + k] - a.rgram[(size_t)i * C + k];
+                if (i == k) v += mu * clampd(U[(size_t)i * G + i], a.dmin, a.dmax);
+            } else {
+                v = -gg[k] + a.rgram[(size_t)k * C + G];
+            }
+            S[e] = v;
+        }
+    }
+    if (tid < G) heldf[tid] = a.gfrozen[tid] ? 1. : 0.;
+    __syncthreads();
+    bool ok = true;
+    for (int pass = 0; pass <= G; pass++) {
+        // constant blocks and the active set of the box bounds leave the system (unit row / column, zero right-hand side)
+#pragma unroll
+        for (int m = 0; m < kEntrySolveSlots; m++) {
+            if (ri[m] < 0) continue;
+            const int i = ri[m], k = ck[m];
+            const bool h = (i < G && heldf[i] != 0.) || heldf[k] != 0.;
+            A[i * C + k] = h ? ((i == k) ? 1. : 0.) : S[tid + kLmThreads * m];
+        }
+        if (tid == 0) flag[0] = 0.;
+        __syncthreads();
+        ok = true;
+        for (int j = 0; j < G; j++) {
+            const double d = A[j * C + j];   // never written during the factorisation: L_jj goes to Ld
+            if (!(d > 0.) || !isfinite(d)) ok = false;
+            const double sq = sqrt(d > 0. ? d : 1.);
+            if (tid > j && tid <= G) A[tid * C + j] = A[tid * C + j] / sq;
+            if (tid == j) Ld[j] = sq;
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < kEntrySolveSlots; m++) {
+                if (ri[m] >= 0 && ck[m] > j) {
+                    const int i = ri[m], k = ck[m];
+                    A[i * C + k] -= A[i * C + j] * A[k * C + j];
+                }
+            }
+            __syncthreads();
+        }
+        // L^T x = y (row G of the factor) from the last column up: first wave, the running right-hand side in registers
+        if (tid < kWave) {
+            double yy = tid < G ? A[G * C + tid] : 0., xv = 0.;
+            const double dd = tid < G ? Ld[tid] : 1.;
+            for (int j = G - 1; j >= 0; j--) {
+                const double lj = tid < j ? A[j * C + tid] : 0.;
+                const double xj = readlane_f64(yy, j) / readlane_f64(dd, j);
+                yy -= lj * xj;
+                if (tid == j) xv = xj;
+            }
+            if (tid < G) {
+                x[tid] = xv;
+                if (ok && a.use_bounds && heldf[tid] == 0. &&
+                    ((a.xcur[tid] <= a.lo[tid] && xv < 0.) || (a.xcur[tid] >= a.hi[tid] && xv > 0.))) {
+                    heldf[tid] = 1.;
+                    flag[0] = 1.;
+                }
+            }
+        }
+        __syncthreads();
+        if (flag[0] == 0. || !ok) break;
+        __syncthreads();   // everybody has read the flag before the next pass clears it
+    }
+    if (tid < G) a.dg[tid] = x[tid];
+    if (tid == 0) st->step_ok = (G == 0 || ok) ? 1 : 0;
+}
+
 // Narrow reduced systems (a mono or stereo calibration: G <= kFoldMaxG): EVERY workgroup of the back-substitution solves
 // the G x G system itself (its first wave, in LDS, the arithmetic of vg_lm_reduced_solve_kernel: every workgroup gets the
 // same bits) and goes on with the step in LDS -- one launch and one dependent round trip through HBM less per iteration; a

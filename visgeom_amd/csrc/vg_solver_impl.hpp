@@ -1171,7 +1171,10 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             r2.gate_expect = gated ? par : -1;
             const bool fold_solve = G > 0 && G <= vg::kFoldMaxG;   // every back-substitution workgroup solves the reduced system itself
             if (!fold_solve) {
-                hipLaunchKernelGGL(vg::vg_lm_reduced_solve_kernel, dim3(1), dim3(G <= 64 ? vg::kWave : vg::kLmThreads), solve_lds, st, r2);
+                if (G <= vg::kEntrySolveMaxG)   // (51 KB of LDS at G = 63: inside the 64 KB a launch may ask for without an attribute)
+                    hipLaunchKernelGGL(vg::vg_lm_reduced_solve_entries_kernel, dim3(1), dim3(vg::kLmThreads), sizeof(double) * vg::lm_entry_solve_lds_doubles(G), st, r2);
+                else
+                    hipLaunchKernelGGL(vg::vg_lm_reduced_solve_kernel, dim3(1), dim3(G <= 64 ? vg::kWave : vg::kLmThreads), solve_lds, st, r2);
                 VG_HIP(hipGetLastError());
             }
             vg::BacksubArgs ba;
