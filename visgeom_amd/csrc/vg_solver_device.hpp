@@ -316,41 +316,9 @@ __global__ __launch_bounds__(kLmThreads) void vg_lm_accept_kernel(LmAcceptArgs a
     const int slot = a.init ? st->ucur : 1 - st->ucur;  // where the freshly evaluated point's blocks go
     double *Uc = a.U + (size_t)slot * G * G, *gc = a.gg + (size_t)slot * G;
     const size_t WW = (size_t)a.Wmax * a.Wmax;
-    // the column maps and the summed blocks are read many times: staged in LDS when they fit (a handful of datasets)
-    extern __shared__ __attribute__((aligned(16))) double sm_acc[];
-    const bool staged = a.lds_doubles >= (size_t)a.n_ds * WW + ((size_t)a.n_ds * G + 1) / 2 + 1;
-    const double *sums = a.sums;
-    const int *inv = a.inv;
-    if (staged) {
-        double *s_sums = sm_acc;
-        int *s_inv = reinterpret_cast<int *>(sm_acc + (size_t)a.n_ds * WW);
-        for (size_t i = tid; i < (size_t)a.n_ds * WW; i += kLmThreads) s_sums[i] = a.sums[i];
-        for (int i = tid; i < a.n_ds * G; i += kLmThreads) s_inv[i] = a.inv[i];
-        __syncthreads();
-        sums = s_sums;
-        inv = s_inv;
-    }
-    // U, g of the evaluated point from the per-dataset sums, dataset after dataset (the order the host uses)
-    for (int i = tid; i < G * G; i += kLmThreads) {
-        const int ga = i / G, gb = i - ga * G;
-        double s = 0.;
-        for (int d = 0; d < a.n_ds; d++) {
-            const int la = inv[d * G + ga], lb = inv[d * G + gb], W = a.Wd[d];
-            if (la >= 0 && lb >= 0) s += sums[d * WW + (size_t)la * W + lb];
-        }
-        Uc[i] = s;
-    }
-    for (int ga = tid; ga < G; ga += kLmThreads) {
-        double s = 0.;
-        for (int d = 0; d < a.n_ds; d++) {
-            const int la = inv[d * G + ga], W = a.Wd[d];
-            if (la >= 0) s += sums[d * WW + (size_t)la * W + W - 1];
-        }
-        gc[ga] = s;
-        if (a.init) a.xcur[ga] = a.x[a.gcol_param[ga]];
-    }
-    // everything the scalar logic reads, staged once (a dependent global load per loop step made this kernel 41 us at
-    // G = 45): current U diagonal / g, the step, the current global values, their box
+    // ONE round of global loads: everything below is requested before the first barrier -- the inputs of the scalar logic
+    // (staged once: a dependent global load per loop step made this kernel 41 us at G = 45), the partials of the step's five
+    // scalar sums, the state itself (thread 0) and the summed blocks.  (Four dependent rounds before: 7.4 us at G = 6.)
     __shared__ double s_ud[128], s_g[128], s_dg[128], s_x[128], s_lo[128], s_hi[128];
     __shared__ unsigned char s_fz[128];
     {
@@ -379,20 +347,57 @@ __global__ __launch_bounds__(kLmThreads) void vg_lm_accept_kernel(LmAcceptArgs a
             if ((tid & (kWave - 1)) == 0) s_red[q][tid >> 6] = acc[q];
         }
     }
+    // The scalar logic runs on a LOCAL copy of the state: read once (together with the two counters), written back once.
+    // Through the pointer every read after a write had to be a fresh global load (the compiler cannot rule out aliasing
+    // with the counters): half a dozen dependent memory round trips in a one-thread section.
+    LmState S;
+    int n_bad = 0;                      // the GLOBAL count: every rank takes the same accept / reject branch
+    unsigned long long gmax_bits = 0ull;
+    if (tid == 0) {
+        S = *st;
+        n_bad = (int)*a.bad;
+        gmax_bits = *a.gmax_bits;
+    }
+    // the column maps and the summed blocks are read many times: staged in LDS when they fit (a handful of datasets)
+    extern __shared__ __attribute__((aligned(16))) double sm_acc[];
+    const bool staged = a.lds_doubles >= (size_t)a.n_ds * WW + ((size_t)a.n_ds * G + 1) / 2 + 1;
+    const double *sums = a.sums;
+    const int *inv = a.inv;
+    if (staged) {
+        double *s_sums = sm_acc;
+        int *s_inv = reinterpret_cast<int *>(sm_acc + (size_t)a.n_ds * WW);
+        for (size_t i = tid; i < (size_t)a.n_ds * WW; i += kLmThreads) s_sums[i] = a.sums[i];
+        for (int i = tid; i < a.n_ds * G; i += kLmThreads) s_inv[i] = a.inv[i];
+        sums = s_sums;
+        inv = s_inv;
+    }
     __syncthreads();
     if (tid < 5 && a.scal_partials && !a.init) {
         double t = 0.;
         for (int w = 0; w < kLmThreads / kWave; w++) t += s_red[tid][w];
         s_sc[tid] = t;
     }
+    // U, g of the evaluated point from the per-dataset sums, dataset after dataset (the order the host uses)
+    for (int i = tid; i < G * G; i += kLmThreads) {
+        const int ga = i / G, gb = i - ga * G;
+        double s = 0.;
+        for (int d = 0; d < a.n_ds; d++) {
+            const int la = inv[d * G + ga], lb = inv[d * G + gb], W = a.Wd[d];
+            if (la >= 0 && lb >= 0) s += sums[d * WW + (size_t)la * W + lb];
+        }
+        Uc[i] = s;
+    }
+    for (int ga = tid; ga < G; ga += kLmThreads) {
+        double s = 0.;
+        for (int d = 0; d < a.n_ds; d++) {
+            const int la = inv[d * G + ga], W = a.Wd[d];
+            if (la >= 0) s += sums[d * WW + (size_t)la * W + W - 1];
+        }
+        gc[ga] = s;
+        if (a.init) a.xcur[ga] = a.x[a.gcol_param[ga]];
+    }
     __syncthreads();
     if (tid != 0) return;
-    // The scalar logic runs on a LOCAL copy of the state: read once (together with the two counters), written back once.
-    // Through the pointer every read after a write had to be a fresh global load (the compiler cannot rule out aliasing
-    // with the counters): half a dozen dependent memory round trips in a one-thread section.
-    LmState S = *st;
-    const int n_bad = (int)*a.bad;  // the GLOBAL count: every rank takes the same accept / reject branch
-    const unsigned long long gmax_bits = *a.gmax_bits;
     double cost2_c = 0.;
     for (int d = 0; d < a.n_ds; d++) cost2_c += sums[d * WW + (size_t)a.Wd[d] * a.Wd[d] - 1];
     auto publish = [&]() {
