@@ -80,13 +80,16 @@ def test_rig_parity_gram_and_solve(vg):
     p.close()
 
 
-def test_wide_rig_more_than_63_global_columns(vg):
+@pytest.mark.parametrize("n_cam,device_loop", [(8, 0), (8, 1), (4, 1)])
+def test_wide_rig_more_than_63_global_columns(vg, n_cam, device_loop):
     """eight Mei cameras on one rig: G = 8 * 10 intrinsics + 7 * 6 global transforms = 122 global columns -- the reduced
-    system is handled as 8 x 8 MFMA tiles (tile-pair kernel) and 8 columns per lane in the back-substitution.
+    system is handled as 8 x 8 MFMA tiles (tile-pair kernel) and 8 columns per lane in the back-substitution; forced onto the
+    device-resident loop it is factorised by the row-per-lane one-workgroup kernel (133 KB of LDS).  Four cameras: G = 58,
+    on the device loop the entry-parallel kernel with more than 48 KB of LDS.
     Noise-free data: the solve must return the generating values."""
-    from visgeom_amd import synthetic as S
+    from visgeom_amd import capi, synthetic as S
 
-    n_cam, n_frames = 8, 40
+    n_frames = 40
     board = S.board_points()
     gts = [S.GT_MEI * (1 + 0.002 * k * np.array([1, 0, 0, 0, 0, 0, 1, 1, 0.2, 0.2])) for k in range(n_cam)]
     xi1k = [np.array([0.06 * (k % 4), 0.06 * (k // 4), 0.0, 0.004 * k, -0.003 * k, 0.002 * k]) for k in range(1, n_cam)]
@@ -106,15 +109,19 @@ def test_wide_rig_more_than_63_global_columns(vg):
         chain = [(seq, 0)] if k == 0 else [(tids[k - 1], 1), (seq, 0)]
         p.add_dataset(cids[k], chain, board, uv)
     p.finalize()
-    s = p.solve(max_num_iterations=300)
+    capi.debug_set("solver_device_loop", device_loop)
+    try:
+        s = p.solve(max_num_iterations=300)
+    finally:
+        capi.debug_set("solver_device_loop", 0)
     x = p.get_parameters()
     print("wide rig", s["termination"], s["num_iterations"], "G", s["num_global_columns"], "cost %.3e -> %.3e" % (s["initial_cost"], s["final_cost"]))
-    assert s["num_global_columns"] == 122
+    assert s["num_global_columns"] == 10 * n_cam + 6 * (n_cam - 1)
     assert s["final_cost"] < 1e-15 * s["initial_cost"]
     for k in range(n_cam):
         assert np.max(np.abs(x[10 * k:10 * k + 10] - gts[k]) / np.maximum(np.abs(gts[k]), 1.0)) < 1e-6
     for k in range(n_cam - 1):
-        assert np.max(np.abs(x[80 + 6 * k:86 + 6 * k] - xi1k[k])) < 1e-6
+        assert np.max(np.abs(x[10 * n_cam + 6 * k:10 * n_cam + 6 + 6 * k] - xi1k[k])) < 1e-6
     p.close()
 
 

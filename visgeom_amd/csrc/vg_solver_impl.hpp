@@ -1088,6 +1088,9 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
         if (solve_lds > 64 * 1024)  // up to 127 global columns: 133 KB of the CU's 160 KB
             VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(vg::vg_lm_reduced_solve_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_lds));
+        if (G <= vg::kEntrySolveMaxG && sizeof(double) * vg::lm_entry_solve_lds_doubles(G) > 48 * 1024)   // 51 KB at G = 63
+            VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(vg::vg_lm_reduced_solve_entries_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * vg::lm_entry_solve_lds_doubles(G))));
 
         aa.gate_expect = -1;
         ra.gate_expect = -1;
@@ -1171,7 +1174,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             r2.gate_expect = gated ? par : -1;
             const bool fold_solve = G > 0 && G <= vg::kFoldMaxG;   // every back-substitution workgroup solves the reduced system itself
             if (!fold_solve) {
-                if (G <= vg::kEntrySolveMaxG)   // (51 KB of LDS at G = 63: inside the 64 KB a launch may ask for without an attribute)
+                if (G <= vg::kEntrySolveMaxG)
                     hipLaunchKernelGGL(vg::vg_lm_reduced_solve_entries_kernel, dim3(1), dim3(vg::kLmThreads), sizeof(double) * vg::lm_entry_solve_lds_doubles(G), st, r2);
                 else
                     hipLaunchKernelGGL(vg::vg_lm_reduced_solve_kernel, dim3(1), dim3(G <= 64 ? vg::kWave : vg::kLmThreads), solve_lds, st, r2);
