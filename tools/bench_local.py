@@ -94,6 +94,26 @@ def main():
                  "features_per_s": 5 * nb / t, "algorithmic_bytes": 240 * 5 * nb, "GBps": 240 * 5 * nb / t / 1e9,
                  "frac_of_hbm_peak": 240 * 5 * nb / t / HBM_PEAK})
     st.close()
+    # CameraJacobian::dpdxi / dfdxi (jacobian.h:51-119), two-transform constructor, 1 M points of a depth map: 24 (X2) + 16
+    # (gradient) read, 96 (dpdxi) + 48 (dfdxi) written = 184 B per point
+    import ctypes
+    from visgeom_amd import capi
+    L = capi.load()
+    n = 1000000
+    X = torch.tensor(np.column_stack([rng.uniform(-1, 1, n), rng.uniform(-0.7, 0.7, n), rng.uniform(1.5, 5, n)]), device="cuda")
+    g = torch.tensor(rng.standard_normal((n, 2)), device="cuda")
+    dp = torch.empty((n, 2, 6), dtype=torch.float64, device="cuda")
+    df = torch.empty((n, 6), dtype=torch.float64, device="cuda")
+    T12, T23 = np.array([0.3, -0.2, 0.1, 0.4, -0.3, 0.2]), np.array([-0.1, 0.25, 0.05, -0.2, 0.1, 0.5])
+    intr = np.ascontiguousarray(INTR["mei"], float)
+    dpt = ctypes.POINTER(ctypes.c_double)
+    st_ptr = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+    def cj():
+        capi.check(L.vg_camera_jacobian_evaluate(0, st_ptr, 2, intr.ctypes.data_as(dpt), T12.ctypes.data_as(dpt), T23.ctypes.data_as(dpt), n, vp(X), vp(g), vp(dp), vp(df)))
+    t = timed(cj)
+    rows.append({"case": "camera jacobian: 1 M points, two transforms", "model": "mei", "features": n, "blocks": 1, "evaluation_us": t * 1e6,
+                 "features_per_s": n / t, "algorithmic_bytes": 184 * n, "GBps": 184 * n / t / 1e9, "frac_of_hbm_peak": 184 * n / t / HBM_PEAK})
     for r in rows:
         print(json.dumps(r))
     print()

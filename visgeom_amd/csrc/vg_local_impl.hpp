@@ -330,9 +330,9 @@ int vg_camera_jacobian_evaluate(int device, void *hip_stream, int model, const d
     a.n = (unsigned)n;
     const dim3 grid((unsigned)((n + 255) / 256)), blk(256);
     switch (model) {
-    case vg::kEUCM: hipLaunchKernelGGL((vg::vg_camera_jacobian_kernel<vg::kEUCM>), grid, blk, 0, st, a); break;
-    case vg::kUCM: hipLaunchKernelGGL((vg::vg_camera_jacobian_kernel<vg::kUCM>), grid, blk, 0, st, a); break;
-    default: hipLaunchKernelGGL((vg::vg_camera_jacobian_kernel<vg::kMEI>), grid, blk, 0, st, a); break;
+    case vg::kEUCM: hipLaunchKernelGGL((vg::vg_camera_jacobian_kernel<vg::kEUCM>), grid, blk, vgl::kLocalLds, st, a); break;
+    case vg::kUCM: hipLaunchKernelGGL((vg::vg_camera_jacobian_kernel<vg::kUCM>), grid, blk, vgl::kLocalLds, st, a); break;
+    default: hipLaunchKernelGGL((vg::vg_camera_jacobian_kernel<vg::kMEI>), grid, blk, vgl::kLocalLds, st, a); break;
     }
     VG_HIP(hipGetLastError());
     return VG_OK;
