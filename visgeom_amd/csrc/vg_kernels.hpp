@@ -310,11 +310,12 @@ __global__ __launch_bounds__(kEmitThreads) void vg_emit_kernel(EmitArgs a)
 // ------------------------------------------------------------------------------------------
 // kernel 2, several datasets in ONE launch (stereo pair, camera rig): a problem's datasets are small launches each
 // (2 000 stereo pairs: 42 + 62 MB) whose ramp-up, drain and inter-kernel gap cost a quarter of the pass.  The tiles of
-// all datasets form one range; XCD x streams a contiguous piece of it, so a die works inside one dataset's output
-// arrays at a time -- a piece of EQUAL BYTES, not of equal tile count: a rig's Mei tile writes 1.85 x the bytes of its UCM
-// tile, and with equal counts the dies holding the wide datasets finished last (rig, 591 MB: 117.6 us against 103.8 us for
-// the four datasets launched one by one; profiles/NOTES.md "Merged emit launch").  The host cuts the range (xcd_first /
-// xcd_count); the grid is 8 x the longest piece, surplus workgroups of the shorter pieces leave at once.  Per-dataset arguments travel by value in the kernel argument segment (no table upload per
+// all datasets form one range; XCD x streams the x-th contiguous eighth of EVERY dataset, dataset after dataset, so a die
+// works inside one dataset's output arrays at a time and every die gets the same bytes and the same arithmetic whatever the
+// mix of models (a rig's Mei tile writes 1.85 x the bytes of its UCM tile: with one contiguous piece of equal tile count
+// per die, the dies holding the wide datasets finished last -- rig, 591 MB: 116 us against 109 us; profiles/NOTES.md "Merged
+// emit launch").  The earlier cuts (one contiguous piece per die, of equal tile count or equal bytes: xcd_first / xcd_count)
+// stay behind the emit_equal_tiles hook for A/B.  The grid is 8 x the longest piece; surplus workgroups leave at once.  Per-dataset arguments travel by value in the kernel argument segment (no table upload per
 // evaluation); the camera model and the chain route are wave-uniform run-time switches over the same tile routine.
 // ------------------------------------------------------------------------------------------
 constexpr int kEmitMultiMax = 8;
@@ -326,6 +327,7 @@ struct EmitMultiArgs {
     int inline_chain[kEmitMultiMax];
     int n;
     unsigned int xcd_first[8], xcd_count[8];   // tiles of XCD x: [xcd_first[x], xcd_first[x] + xcd_count[x])
+    int per_dataset;                           // 1: XCD x takes the x-th eighth of EVERY dataset, dataset after dataset
 };
 
 template <int MODEL>
@@ -337,11 +339,24 @@ __device__ __forceinline__ void emit_tile_route(const EmitArgs &a, unsigned int 
 
 __global__ __launch_bounds__(kEmitThreads) void vg_emit_multi_kernel(EmitMultiArgs m)
 {
-    const unsigned int x = blockIdx.x & 7u, j = blockIdx.x >> 3;   // workgroup b runs on XCD b % 8 (observed dispatch order)
-    if (j >= m.xcd_count[x]) return;
-    const unsigned int t = m.xcd_first[x] + j;
+    const unsigned int x = blockIdx.x & 7u;   // workgroup b runs on XCD b % 8 (observed dispatch order)
+    unsigned int j = blockIdx.x >> 3, t;
     int d = 0;
-    while (d + 1 < m.n && t >= m.first_tile[d + 1]) d++;
+    if (m.per_dataset) {
+        for (;; d++) {
+            if (d == m.n) return;
+            const unsigned int nt = m.first_tile[d + 1] - m.first_tile[d], q = nt >> 3, r = nt & 7u, cnt = q + (x < r ? 1u : 0u);
+            if (j < cnt) {
+                t = m.first_tile[d] + x * q + (x < r ? x : r) + j;
+                break;
+            }
+            j -= cnt;
+        }
+    } else {
+        if (j >= m.xcd_count[x]) return;
+        t = m.xcd_first[x] + j;
+        while (d + 1 < m.n && t >= m.first_tile[d + 1]) d++;
+    }
     const unsigned int o0 = (t - m.first_tile[d]) * (unsigned)kEmitThreads;
     const bool inl = m.inline_chain[d] != 0;
     switch (m.model[d]) {
