@@ -991,7 +991,7 @@ bool vgi::gram_merge_covers_all(const vg_problem *p)
 int vgi::gram_fused_merged_at(vg_problem *p, const double *d_params, double *const *grams, std::vector<char> &taken,
                               double *const *partials)
 {
-    const bool off = vgi::debug_hook(vgi::kHookGramNoMerge) != 0 || vgi::debug_hook(vgi::kHookGramCh1) != 0;  // measurement hooks
+    const bool off = vgi::debug_hook(vgi::kHookGramNoMerge) == 1 || vgi::debug_hook(vgi::kHookGramCh1) != 0;  // measurement hooks
     const int n_ds = (int)p->dss.size();
     taken.assign((size_t)n_ds, 0);
     std::vector<int> ids;
@@ -1001,6 +1001,13 @@ int vgi::gram_fused_merged_at(vg_problem *p, const double *d_params, double *con
             ids.push_back(i);
     }
     if (ids.size() < 2) return VG_OK;
+    // heaviest workgroups first: the launch ends on the light datasets' workgroups instead of a tail of the widest blocks
+    // (same box, merged launch in dataset order -> heaviest first: stereo 14.4 -> 12.7 us, rig 66-71 -> 61-64 us)
+    if (vgi::debug_hook(vgi::kHookGramNoMerge) != 2)
+        std::stable_sort(ids.begin(), ids.end(), [&](int a2, int b2) {
+            const Dataset &da = p->dss[a2], &db = p->dss[b2];
+            return p->cams[da.camera].K + 6 * da.L > p->cams[db.camera].K + 6 * db.L;
+        });
     for (size_t g0 = 0; g0 < ids.size(); g0 += vg::kGramMultiMax) {
         vg::GramValuMultiArgs m;
         m.n = (int)(ids.size() - g0 < (size_t)vg::kGramMultiMax ? ids.size() - g0 : (size_t)vg::kGramMultiMax);

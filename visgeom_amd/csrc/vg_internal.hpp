@@ -24,7 +24,7 @@ enum DebugHook {
     kHookInlineChainMaxBytes = 0,  // largest evaluation (bytes) whose single-member chain is walked in the emit kernel
     kHookGramForceMfma,            // single-member chains on the matrix-core Gram kernel as well
     kHookGramCh1,                  // one corner per lane in the vector-pipe Gram kernel
-    kHookGramNoMerge,              // one Gram launch per dataset
+    kHookGramNoMerge,              // 1: one Gram launch per dataset; 2: merged launch in dataset order instead of heaviest first
     kHookMaxObsPerLaunch,          // chunk size of the emit launches (the chunked path without a 240 GB problem)
     kHookSolverTiming,             // print where the solver's set-up time goes
     kHookSolverHostLoop,           // force the host-driven LM loop
