@@ -20,7 +20,7 @@ for cfg in (3, 5):
                                                                                                32 + 16 * (B.KOF[m] + 6 * L)))
     nb = sum(n * 96 * (32 + 16 * (B.KOF[m] + 6 * L)) for _, m, L, n in dss)
     from visgeom_amd import capi
-    for hook, what in ((1, "equal tile counts per XCD"), (2, "equal bytes per XCD"), (3, "an eighth of every dataset per XCD"), (0, "default"), (1, "equal tile counts per XCD"), (2, "equal bytes per XCD"), (3, "an eighth of every dataset per XCD")):
+    for hook, what in ((1, "contiguous pieces of equal tile counts"), (2, "contiguous pieces of equal bytes"), (4, "eighths of every dataset, problem order"), (0, "default: eighths, widest rows first"), (4, "eighths of every dataset, problem order"), (0, "default: eighths, widest rows first")):
         capi.debug_set("emit_equal_tiles", hook)
         t = B.timed(lambda: p.evaluate_all(outs))
         print("  all datasets, merged launch, %s: %.1f us, %.0f GB/s" % (what, t * 1e6, nb / t / 1e9))

@@ -813,6 +813,11 @@ int vg_problem_evaluate(vg_problem *p, const vg_dataset_outputs *outs)
         alone.insert(alone.end(), shared.begin(), shared.end());
         shared.clear();
     }
+    if (vgi::debug_hook(vgi::kHookEmitEqualTiles) != 4)   // widest rows first: every die ends on its lightest tiles (hook 4: problem order)
+        std::stable_sort(shared.begin(), shared.end(), [&](int a2, int b2) {
+            const Dataset &da = p->dss[a2], &db = p->dss[b2];
+            return p->cams[da.camera].K + 6 * da.L > p->cams[db.camera].K + 6 * db.L;
+        });
     for (int i : shared) need_frames = need_frames || !single_launch_dataset(p, p->dss[i]);
     if (need_frames && (rc = vgi::ensure_frames(p)) != VG_OK) return rc;
     for (size_t g0 = 0; g0 < shared.size(); g0 += vg::kEmitMultiMax) {

@@ -30,7 +30,7 @@ enum DebugHook {
     kHookSolverHostLoop,           // force the host-driven LM loop
     kHookSolverDeviceLoop,         // force the device-resident LM loop
     kHookSolverNoSpeculation,      // queue one LM iteration at a time
-    kHookEmitEqualTiles,           // merged emit launch: contiguous XCD pieces of 1 = equal tile counts, 2 = equal bytes (default: an eighth of every dataset)
+    kHookEmitEqualTiles,           // merged emit launch: contiguous XCD pieces of 1 = equal tile counts, 2 = equal bytes (default: an eighth of every dataset, widest rows first; 4: in problem order)
     kHookCount
 };
 #ifdef VG_DEBUG_HOOKS
