@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--sharded-solve-images", type=int, default=100000,
                     help="total images of the large sharded LM solve (0: skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary-configs", action="store_true",
+                    help="skip the per-config sections (BASELINE configs 3 and 5, the beyond-L3 stream)")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU-baseline budget per leg")
     return ap.parse_args()
 

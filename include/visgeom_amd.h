@@ -444,6 +444,10 @@ int vg_reconstruct_point(int model, const double *intrinsics, const double *uv, 
 int vg_initial_grid_pose(int model, const double *intrinsics, const double *board4, const double *corners4, double *xi6);
 int vg_init_transform(int chain_len, const int *status, int init_index, const double *chain_values, const double *xi_camera,
                       double *out6);
+/* the same for a member that occurs more than once in the chain: the reference's forward loop stops at the FIRST occurrence
+ * (:314-318), its backward loop at the LAST (:327-337); the members in between are read by neither */
+int vg_init_transform_range(int chain_len, const int *status, int first_index, int last_index, const double *chain_values,
+                            const double *xi_camera, double *out6);
 /* transformFromData, include/json.h:36-67: 3 [x,y,theta] / 6 [t,rotvec] / 7 [t,qx,qy,qz,qw] / 12 row-major [R|t] */
 int vg_transform_from_values(int n, const double *values, double *out6);
 

@@ -1491,18 +1491,19 @@ int vgo_initial_grid_pose(int model, const double *intr, const double board4[12]
 
 /* getInitTransform (:311-348): peel the chain members before / after the one being initialised off a camera-frame pose.
  * chain [n][6]: current value of every chain member (camera side first); init_index: the member to initialise. */
-void vgo_init_transform(int n, const int *status, int init_index, const double *chain, const double xi_in[6], double out[6])
+void vgo_init_transform_range(int n, const int *status, int first_index, int last_index, const double *chain, const double xi_in[6],
+                              double out[6])
 {
     double xi[6], t[6];
     memcpy(xi, xi_in, sizeof xi);
     for (int i = 0; i < n; i++) {
-        if (i == init_index) break;
+        if (i == first_index) break; /* name == initName: the first occurrence ends the forward loop (:318) */
         else if (status[i] == VGO_TRANSFORM_DIRECT) inverse_compose(chain + 6 * i, xi, t); /* getTransform(name).inverseCompose(xi) */
         else compose_(chain + 6 * i, xi, t);                                              /* getTransform(name).compose(xi)        */
         memcpy(xi, t, sizeof xi);
     }
     for (int i = n - 1; i >= 0; i--) {
-        if (i == init_index) {
+        if (i == last_index) { /* name == initName: the last occurrence ends the backward loop (:330-337) */
             if (status[i] == VGO_TRANSFORM_INVERSE) {
                 inverse_(xi, t);
                 memcpy(xi, t, sizeof xi);
@@ -1513,6 +1514,11 @@ void vgo_init_transform(int n, const int *status, int init_index, const double *
         memcpy(xi, t, sizeof xi);
     }
     memcpy(out, xi, sizeof xi);
+}
+
+void vgo_init_transform(int n, const int *status, int init_index, const double *chain, const double xi_in[6], double out[6])
+{
+    vgo_init_transform_range(n, status, init_index, init_index, chain, xi_in, out);
 }
 
 int vgo_max_threads(void)

@@ -141,6 +141,8 @@ void vgo_rotation_vector(const double R[9], double rot[3]);                     
 int vgo_initial_grid_pose(int model, const double *intr, const double board4[12], const double corners4[8], double xi[6]);
 /* getInitTransform (unified_calibration.cpp:311-348) */
 void vgo_init_transform(int n, const int *status, int init_index, const double *chain, const double xi_in[6], double out[6]);
+void vgo_init_transform_range(int n, const int *status, int first_index, int last_index, const double *chain, const double xi_in[6],
+                              double out[6]);
 
 int vgo_max_threads(void);
 

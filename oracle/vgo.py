@@ -101,6 +101,8 @@ def lib():
         L.vgo_initial_grid_pose.argtypes = [ctypes.c_int, _dp, _dp, _dp, _dp]
         L.vgo_init_transform.restype = None
         L.vgo_init_transform.argtypes = [ctypes.c_int, _ip, ctypes.c_int, _dp, _dp, _dp]
+        L.vgo_init_transform_range.restype = None
+        L.vgo_init_transform_range.argtypes = [ctypes.c_int, _ip, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp]
         _lib = L
     return _lib
 
@@ -357,6 +359,14 @@ def init_transform(status, init_index, chain, xi):
     chain, xi, out = _c(chain).reshape(-1, 6), _c(xi), np.empty(6)
     st = (ctypes.c_int * max(len(status), 1))(*[int(s) for s in status])
     lib().vgo_init_transform(chain.shape[0], st, int(init_index), _ptr(chain), _ptr(xi), _ptr(out))
+    return out
+
+
+def init_transform_range(status, first_index, last_index, chain, xi):
+    """getInitTransform for a member that occurs more than once: forward loop to its first, backward loop to its last occurrence"""
+    chain, xi, out = _c(chain).reshape(-1, 6), _c(xi), np.empty(6)
+    st = (ctypes.c_int * max(len(status), 1))(*[int(s) for s in status])
+    lib().vgo_init_transform_range(chain.shape[0], st, int(first_index), int(last_index), _ptr(chain), _ptr(xi), _ptr(out))
     return out
 
 

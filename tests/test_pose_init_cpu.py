@@ -129,3 +129,34 @@ def test_init_transform_equals_the_oracle_and_recovers_the_member(lib):
     chain = np.array([[0.1, 0.2, 0.3, 0.01, 0.02, 0.03]])
     xi = np.array([0.5, 0.1, 1.0, 0.1, 0.2, 0.3])
     assert np.max(np.abs(product_init_transform(lib, [0], 1, chain, xi) - vgo.init_transform([0], 1, chain, xi))) <= 1e-13
+
+
+def test_init_transform_with_a_member_that_occurs_twice(lib):
+    """unified_calibration.cpp:311-348 compares NAMES: when the member being initialised occurs twice in a chain the forward
+    loop stops at its first occurrence and the backward loop at its LAST one; the members in between are visited by
+    neither loop (the product kept only the first occurrence)"""
+    rng = np.random.default_rng(11)
+    for trial in range(40):
+        L = int(rng.integers(2, 6))
+        status = [int(s) for s in rng.integers(0, 2, L)]
+        chain = np.concatenate([rng.uniform(-0.5, 0.5, (L, 3)), rng.uniform(-0.6, 0.6, (L, 3))], axis=1)
+        first = int(rng.integers(0, L - 1))
+        last = int(rng.integers(first + 1, L))
+        xi = np.concatenate([rng.uniform(-0.5, 0.5, 3), rng.uniform(-0.6, 0.6, 3)])
+        st = (ctypes.c_int * L)(*status)
+        got = np.empty(6)
+        assert lib.vg_init_transform_range(L, st, first, last, _p(np.ascontiguousarray(chain)), _p(xi), _p(got)) == 0
+        ref = vgo.init_transform_range(status, first, last, chain, xi)
+        assert np.max(np.abs(got - ref)) <= 1e-13, (status, first, last)
+        # independent restatement with the oracle's compose primitives: members before `first` peeled from the left, members
+        # after `last` from the right, inversion when the LAST occurrence is used INVERSE
+        acc = xi.copy()
+        inv = lambda a: vgo.compose(np.zeros(6), a, inverse=True)
+        for i in range(first):
+            acc = vgo.compose(inv(chain[i]), acc) if status[i] == 0 else vgo.compose(chain[i], acc)
+        for i in range(L - 1, last, -1):
+            acc = vgo.compose(acc, chain[i], inverse=(status[i] == 0))
+        if status[last] == 1:
+            acc = inv(acc)
+        Ra, Rg = vgo.rotation_matrix(acc[3:]), vgo.rotation_matrix(got[3:])
+        assert np.max(np.abs(Ra - Rg)) < 1e-12 and np.max(np.abs(acc[:3] - got[:3])) < 1e-12, (status, first, last)

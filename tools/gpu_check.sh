@@ -26,8 +26,10 @@ for C in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$P/pmc_$C" -o t -- python "$R/bench.py" --steps 20 --warmup 2 --no-cpu-baseline > "$P.pmc_$C.log" 2>&1
   echo "rocprof pmc $C rc=$?"
 done
-timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d "$P/pmc_SQ" -o t -- python "$R/bench.py" --steps 20 --warmup 2 --no-cpu-baseline > "$P.pmc_SQ.log" 2>&1
-echo "rocprof pmc SQ rc=$?"
+# SQ counters: tools/pmc_sq.sh (own passes, aggregated on the box -- the per-dispatch CSV of an 8-counter pass is larger
+# than what the size filter below lets travel, which is how the SQ tables of r02g..r03f came back empty)
+bash "$R/tools/pmc_sq.sh" "$TAG"
+cd /tmp
 find "$P" -type f | head -40
 f=$(find "$P/trace" -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && head -8 "$f"
 k=$(find "$P/trace" -name '*kernel_trace.csv' | head -1)

@@ -40,7 +40,11 @@ def short(name):
 
 shutil.copy(os.path.join(P, "trace", "t_kernel_stats.csv"), os.path.join(OUT, tag + "_kernel_stats.csv"))
 stats = {short(r["Name"]): r for r in csv.DictReader(open(os.path.join(P, "trace", "t_kernel_stats.csv")))}
-fetch, write, sq = counters("pmc_FETCH_SIZE"), counters("pmc_WRITE_SIZE"), counters("pmc_SQ")
+fetch, write = counters("pmc_FETCH_SIZE"), counters("pmc_WRITE_SIZE")
+if not fetch or not write:
+    print("EMPTY counter table: pmc_FETCH_SIZE has %d rows, pmc_WRITE_SIZE %d (was the CSV deleted by a size filter?)" % (len(fetch), len(write)),
+          file=sys.stderr)
+    sys.exit(3)
 mean = lambda v: sum(v) / len(v)
 fk = {short(k[0]): mean(v) for k, v in fetch.items()}
 wk = {short(k[0]): mean(v) for k, v in write.items()}
@@ -63,10 +67,7 @@ for k in sorted(set(fk) | set(wk)):
     lines.append("| %s | %s | %s | %.1f | %.1f | %.4g |" % (k, s.get("Calls", "-"), s.get("AverageNs", "-"), fk.get(k, 0),
                                                         wk.get(k, 0), b))
     traffic[k] = b
-lines += ["", "SQ counters (means per dispatch):", "", "| kernel | counter | mean |", "|---|---|---|"]
-for (kn, cn), v in sorted(sq.items()):
-    if short(kn).startswith("vg::") and "stream" not in kn:
-        lines.append("| %s | %s | %.4g |" % (short(kn), cn, mean(v)))
+lines += ["", "SQ counters (issue / stall split per kernel): `profiles/%s_pmc_sq.md` (tools/pmc_sq.sh, aggregated on the box)." % tag]
 open(os.path.join(OUT, tag + "_pmc.md"), "w").write("\n".join(lines) + "\n")
 emit = [k for k in traffic if "vg_emit_kernel" in k]
 tj = os.path.join(OUT, "pmc_traffic.json")

@@ -148,6 +148,7 @@ SIGNATURES = {
     "vg_reconstruct_point": (ctypes.c_int, [ctypes.c_int, _dp, _dp, _dp]),
     "vg_initial_grid_pose": (ctypes.c_int, [ctypes.c_int, _dp, _dp, _dp, _dp]),
     "vg_init_transform": (ctypes.c_int, [ctypes.c_int, _ip, ctypes.c_int, _dp, _dp, _dp]),
+    "vg_init_transform_range": (ctypes.c_int, [ctypes.c_int, _ip, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp]),
     "vg_transform_from_values": (ctypes.c_int, [ctypes.c_int, _dp, _dp]),
     "vg_sparse_reproject_create": (ctypes.c_int, [_vpp, ctypes.c_int, _vp, ctypes.c_int, _dp, _dp, ctypes.c_int64, _i64p, _dp, _dp, _dp, _dp]),
     "vg_mono_reproject_create": (ctypes.c_int, [_vpp, ctypes.c_int, _vp, ctypes.c_int, _dp, _dp, ctypes.c_int64, _dp, _dp]),

@@ -313,16 +313,18 @@ inline Array6d estimate_initial_grid_geometric(vg_calibration *c, const ImageDat
 }
 
 // getInitTransform  unified_calibration.cpp:311-348 on plain arrays: peel the other chain members (current values
-// chain[i], statuses status[i]) off the camera-frame pose xi; init_index = the member being initialised
-inline Array6d init_transform(int n, const int *status, int init_index, const Array6d *chain, Array6d xi)
+// chain[i], statuses status[i]) off the camera-frame pose xi.  The member being initialised may occur more than once in a
+// chain: the reference's forward loop stops at its FIRST occurrence (:314-318), the backward loop at its LAST (:327-337);
+// whatever lies between the two is visited by neither.
+inline Array6d init_transform(int n, const int *status, int first_index, int last_index, const Array6d *chain, Array6d xi)
 {
     for (int i = 0; i < n; i++) {
-        if (i == init_index) break;
+        if (i == first_index) break;
         else if (status[i] == VG_TRANSFORM_DIRECT) xi = inverse_compose(chain[i], xi);
         else xi = compose(chain[i], xi);
     }
     for (int i = n - 1; i >= 0; i--) {
-        if (i == init_index) {
+        if (i == last_index) {
             if (status[i] == VG_TRANSFORM_INVERSE) xi = inverse(xi);
             break;
         } else if (status[i] == VG_TRANSFORM_DIRECT) xi = compose_inverse(xi, chain[i]);
@@ -336,12 +338,14 @@ inline Array6d get_init_transform(vg_calibration *c, Array6d xi, const std::stri
 {
     const int n = (int)data.transNameVec.size();
     std::vector<Array6d> chain((size_t)n);
-    int init_index = n;  // a name that is not in the chain: every member is peeled off by the first loop, as in the reference
+    int first = n, last = -1;  // a name that is not in the chain: every member is peeled off by both loops, as in the reference
     for (int i = 0; i < n; i++) {
-        if (data.transNameVec[(size_t)i] == initName && init_index == n) init_index = i;
-        else chain[(size_t)i] = c->getTransformData(data.transNameVec[(size_t)i], transfIdx);
+        if (data.transNameVec[(size_t)i] == initName) {
+            if (first == n) first = i;
+            last = i;
+        } else chain[(size_t)i] = c->getTransformData(data.transNameVec[(size_t)i], transfIdx);
     }
-    return init_transform(n, data.transStatusVec.data(), init_index, chain.data(), xi);
+    return init_transform(n, data.transStatusVec.data(), first, last, chain.data(), xi);
 }
 
 // estimateInitialGrid for a set of images at once: geometric estimate, then (unless do_not_solve) the refinement of
@@ -734,16 +738,22 @@ int vg_initial_grid_pose(int model, const double *intrinsics, const double *boar
     return bad < 0 ? VG_OK : vgi::fail(VG_ERR_NUMERIC, "corner " + std::to_string(bad) + " of the four cannot be reconstructed with these intrinsics");
 }
 
-int vg_init_transform(int chain_len, const int *status, int init_index, const double *chain_values, const double *xi_camera, double *out6)
+int vg_init_transform_range(int chain_len, const int *status, int first_index, int last_index, const double *chain_values,
+                            const double *xi_camera, double *out6)
 {
     if (chain_len < 0 || chain_len > VG_MAX_CHAIN || (chain_len && (!status || !chain_values)) || !xi_camera || !out6)
         return vgi::fail(VG_ERR_INVALID_ARGUMENT, "bad arguments");
     vgcal::Array6d chain[VG_MAX_CHAIN], xi;
     for (int i = 0; i < chain_len; i++) std::memcpy(chain[i].data(), chain_values + 6 * i, sizeof(double) * 6);
     std::memcpy(xi.data(), xi_camera, sizeof(double) * 6);
-    const vgcal::Array6d r = vgcal::init_transform(chain_len, status, init_index, chain, xi);
+    const vgcal::Array6d r = vgcal::init_transform(chain_len, status, first_index, last_index, chain, xi);
     std::memcpy(out6, r.data(), sizeof(double) * 6);
     return VG_OK;
+}
+
+int vg_init_transform(int chain_len, const int *status, int init_index, const double *chain_values, const double *xi_camera, double *out6)
+{
+    return vg_init_transform_range(chain_len, status, init_index, init_index, chain_values, xi_camera, out6);
 }
 
 int vg_calibration_create(vg_calibration **out, int device)

@@ -43,9 +43,14 @@ struct LocalGroup {
             cv.notify_all();
             return true;
         }
-        if (!cv.wait_for(lk, std::chrono::seconds(120), [&] { return generation != gen || broken; })) broken = true;
-        if (broken) cv.notify_all();
-        return !broken;
+        // Success is decided by the generation alone: a waiter that was released by the last arrival has completed the
+        // collective, also when a faster rank has meanwhile left the group (vg_comm_destroy marks it broken for those who
+        // would otherwise wait for the leaver) before this thread re-acquired the mutex.
+        cv.wait_for(lk, std::chrono::seconds(120), [&] { return generation != gen || broken; });
+        if (generation != gen) return true;
+        broken = true;  // timed out, or a rank left while this one was still waiting for it
+        cv.notify_all();
+        return false;
     }
 };
 }  // namespace vgc
@@ -139,15 +144,19 @@ inline int allreduce_sum(const vg_comm *c, double *device_buf, size_t n, hipStre
     if (!c || c->n_ranks <= 1 || !n) return VG_OK;
     if (c->local) {  // in-process ranks: host-synchronous (a test transport, not a fast one)
         LocalGroup *g = c->local;
-        if (n > g->cap) return vgi::fail(VG_ERR_INVALID_ARGUMENT, "message larger than the local communicator's slots");
-        VG_HIP(hipMemcpyAsync(g->slots + (size_t)c->rank * g->cap, device_buf, sizeof(double) * n, hipMemcpyDeviceToDevice, stream));
-        VG_HIP(hipStreamSynchronize(stream));
-        if (!g->barrier()) return vgi::fail(VG_ERR_STATE, "local communicator: a rank failed or did not arrive");
-        hipLaunchKernelGGL(vg_local_sum_slots_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
-                           (const double *)g->slots, g->cap, g->n, device_buf, n);
-        VG_HIP(hipGetLastError());
-        VG_HIP(hipStreamSynchronize(stream));
-        if (!g->barrier()) return vgi::fail(VG_ERR_STATE, "local communicator: a rank failed or did not arrive");  // slots free again
+        // messages longer than a slot (the raw pose blocks of a long coupled sequence, the packed Gram blocks of many
+        // datasets) go through the slots piece by piece; every rank walks the same pieces in the same order
+        for (size_t off = 0; off < n; off += g->cap) {
+            const size_t m = n - off < g->cap ? n - off : g->cap;
+            VG_HIP(hipMemcpyAsync(g->slots + (size_t)c->rank * g->cap, device_buf + off, sizeof(double) * m, hipMemcpyDeviceToDevice, stream));
+            VG_HIP(hipStreamSynchronize(stream));
+            if (!g->barrier()) return vgi::fail(VG_ERR_STATE, "local communicator: a rank failed or did not arrive");
+            hipLaunchKernelGGL(vg_local_sum_slots_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, stream,
+                               (const double *)g->slots, g->cap, g->n, device_buf + off, m);
+            VG_HIP(hipGetLastError());
+            VG_HIP(hipStreamSynchronize(stream));
+            if (!g->barrier()) return vgi::fail(VG_ERR_STATE, "local communicator: a rank failed or did not arrive");  // slots free again
+        }
         return VG_OK;
     }
     if (c->replicas > 0) {  // the sum over `replicas` identical ranks
@@ -247,7 +256,7 @@ int vg_comm_create_local(vg_comm **out, int n_ranks, int device)
     if (!g) return vgi::fail(VG_ERR_ALLOC, "out of host memory");
     g->n = n_ranks;
     g->device = device;
-    g->cap = 1u << 16;  // 64 Ki doubles per rank: the solver's messages are at most 128^2 + 1
+    g->cap = 1u << 16;  // 64 Ki doubles per rank and piece; longer messages are walked in pieces (allreduce_sum)
     if (hipMalloc(reinterpret_cast<void **>(&g->slots), sizeof(double) * g->cap * (size_t)n_ranks) != hipSuccess) {
         delete g;
         return vgi::fail(VG_ERR_ALLOC, "hipMalloc of the local communicator's slots failed");

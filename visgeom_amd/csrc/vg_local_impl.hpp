@@ -46,8 +46,9 @@ inline size_t io_doubles(const vg_reproject_set *s)
     return 12 + 2 * n + 12 * n + (s->sparse ? 0 : 10 * n);
 }
 
-inline int create(vg_reproject_set **out, int device, void *hip_stream, int model, const double *intr, const double *xb, bool sparse,
-                  int64_t n_blocks, const int64_t *offsets, const double *x1, const double *x2, const double *p2, const double *size)
+inline int create_unguarded(vg_reproject_set **out, int device, void *hip_stream, int model, const double *intr, const double *xb, bool sparse,
+                            int64_t n_blocks, const int64_t *offsets, const double *x1, const double *x2, const double *p2, const double *size,
+                            vg_reproject_set *&live)
 {
     if (!out) return fail(VG_ERR_INVALID_ARGUMENT, "out is NULL");
     *out = nullptr;
@@ -64,6 +65,7 @@ inline int create(vg_reproject_set **out, int device, void *hip_stream, int mode
     if (device < 0 || device >= n_dev) return fail(VG_ERR_INVALID_ARGUMENT, "device index out of range");
     vg_reproject_set *s = new (std::nothrow) vg_reproject_set();
     if (!s) return fail(VG_ERR_ALLOC, "out of host memory");
+    live = s;   // what create() releases if a container below throws
     s->device = device;
     s->model = model;
     s->K = K;
@@ -72,11 +74,12 @@ inline int create(vg_reproject_set **out, int device, void *hip_stream, int mode
     s->n_blocks = n_blocks;
     s->offsets.resize((size_t)n_blocks + 1);
     for (int64_t b = 0; b <= n_blocks; b++) {
-        s->offsets[(size_t)b] = sparse ? offsets[b] : b * vg::kMonoPoints;
+        s->offsets[(size_t)b] = (sparse && n_blocks > 0) ? offsets[b] : b * vg::kMonoPoints;   // an empty sparse set may pass offsets = NULL
         if (b > 0) {
             const int64_t n = s->offsets[(size_t)b] - s->offsets[(size_t)b - 1];
             if (n < 0) {
                 delete s;
+                live = nullptr;
                 return fail(VG_ERR_INVALID_ARGUMENT, "offsets must not decrease");
             }
             s->max_points = n > s->max_points ? n : s->max_points;
@@ -84,11 +87,13 @@ inline int create(vg_reproject_set **out, int device, void *hip_stream, int mode
     }
     if (n_blocks > 0 && s->offsets[0] != 0) {
         delete s;
+        live = nullptr;
         return fail(VG_ERR_INVALID_ARGUMENT, "offsets[0] must be 0");
     }
     s->total = s->offsets[(size_t)n_blocks];
     if (s->total >= (1ll << 31)) {
         delete s;
+        live = nullptr;
         return fail(VG_ERR_INVALID_ARGUMENT, "too many points");
     }
     const size_t T = (size_t)s->total;
@@ -110,9 +115,9 @@ inline int create(vg_reproject_set **out, int device, void *hip_stream, int mode
         return rc;
     };
     hipError_t e;
-    if ((e = hipSetDevice(device)) != hipSuccess) { hip_fail(e, "hipSetDevice"); destroy(s); return rc; }
-    if ((e = hipMalloc(reinterpret_cast<void **>(&s->d_const), sizeof(double) * n_const)) != hipSuccess) { hip_fail(e, "hipMalloc"); destroy(s); return rc; }
-    if ((e = hipMemcpy(s->d_const, h.data(), sizeof(double) * n_const, hipMemcpyHostToDevice)) != hipSuccess) { hip_fail(e, "hipMemcpy"); destroy(s); return rc; }
+    if ((e = hipSetDevice(device)) != hipSuccess) { hip_fail(e, "hipSetDevice"); destroy(s); live = nullptr; return rc; }
+    if ((e = hipMalloc(reinterpret_cast<void **>(&s->d_const), sizeof(double) * n_const)) != hipSuccess) { hip_fail(e, "hipMalloc"); destroy(s); live = nullptr; return rc; }
+    if ((e = hipMemcpy(s->d_const, h.data(), sizeof(double) * n_const, hipMemcpyHostToDevice)) != hipSuccess) { hip_fail(e, "hipMemcpy"); destroy(s); live = nullptr; return rc; }
     s->d_intr = s->d_const + o_intr;
     s->d_xb = s->d_const + o_xb;
     s->d_x1 = s->d_const + o_x1;
@@ -129,16 +134,31 @@ inline int create(vg_reproject_set **out, int device, void *hip_stream, int mode
             const int64_t span = (int64_t)pb[j] - pb[i] + 1;
             s->max_wg_span = span > s->max_wg_span ? span : s->max_wg_span;
         }
-        if ((e = hipMalloc(reinterpret_cast<void **>(&s->d_point_block), sizeof(int) * pb.size())) != hipSuccess) { hip_fail(e, "hipMalloc"); destroy(s); return rc; }
-        if ((e = hipMemcpy(s->d_point_block, pb.data(), sizeof(int) * pb.size(), hipMemcpyHostToDevice)) != hipSuccess) { hip_fail(e, "hipMemcpy"); destroy(s); return rc; }
+        if ((e = hipMalloc(reinterpret_cast<void **>(&s->d_point_block), sizeof(int) * pb.size())) != hipSuccess) { hip_fail(e, "hipMalloc"); destroy(s); live = nullptr; return rc; }
+        if ((e = hipMemcpy(s->d_point_block, pb.data(), sizeof(int) * pb.size(), hipMemcpyHostToDevice)) != hipSuccess) { hip_fail(e, "hipMemcpy"); destroy(s); live = nullptr; return rc; }
     }
     const size_t fr = sparse ? (size_t)(n_blocks ? n_blocks : 1) * vg::kSparseFrame : 2;   // mono frames live in LDS only
-    if ((e = hipMalloc(reinterpret_cast<void **>(&s->d_frames), sizeof(double) * fr)) != hipSuccess) { hip_fail(e, "hipMalloc"); destroy(s); return rc; }
+    if ((e = hipMalloc(reinterpret_cast<void **>(&s->d_frames), sizeof(double) * fr)) != hipSuccess) { hip_fail(e, "hipMalloc"); destroy(s); live = nullptr; return rc; }
     const size_t io = io_doubles(s);
-    if ((e = hipMalloc(reinterpret_cast<void **>(&s->d_io), sizeof(double) * io)) != hipSuccess) { hip_fail(e, "hipMalloc"); destroy(s); return rc; }
-    if ((e = hipHostMalloc(reinterpret_cast<void **>(&s->h_pin), sizeof(double) * io, hipHostMallocDefault)) != hipSuccess) { hip_fail(e, "hipHostMalloc"); destroy(s); return rc; }
+    if ((e = hipMalloc(reinterpret_cast<void **>(&s->d_io), sizeof(double) * io)) != hipSuccess) { hip_fail(e, "hipMalloc"); destroy(s); live = nullptr; return rc; }
+    if ((e = hipHostMalloc(reinterpret_cast<void **>(&s->h_pin), sizeof(double) * io, hipHostMallocDefault)) != hipSuccess) { hip_fail(e, "hipHostMalloc"); destroy(s); live = nullptr; return rc; }
     *out = s;
+    live = nullptr;
     return VG_OK;
+}
+
+// std::vector growth inside the set-up may throw; nothing may cross the extern "C" boundary
+inline int create(vg_reproject_set **out, int device, void *hip_stream, int model, const double *intr, const double *xb, bool sparse,
+                  int64_t n_blocks, const int64_t *offsets, const double *x1, const double *x2, const double *p2, const double *size)
+{
+    vg_reproject_set *live = nullptr;
+    try {
+        return create_unguarded(out, device, hip_stream, model, intr, xb, sparse, n_blocks, offsets, x1, x2, p2, size, live);
+    } catch (const std::exception &e) {
+        destroy(live);
+        if (out) *out = nullptr;
+        return fail(VG_ERR_ALLOC, std::string("out of host memory while building the block set: ") + e.what());
+    }
 }
 
 constexpr size_t kLocalLds = sizeof(double) * (vg::kEmitThreads / vg::kWave) * 2 * vg::kWave * 6;

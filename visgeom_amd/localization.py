@@ -47,6 +47,11 @@ class ReprojectSet:
         if stream is None and torch.cuda.is_available():
             stream = torch.cuda.current_stream(device).cuda_stream
         self.stream = stream or 0
+        # a torch view of the set's stream, for the event edges of evaluate() (the NULL stream is torch's default stream)
+        self._torch_stream = None
+        if torch.cuda.is_available():
+            self._torch_stream = (torch.cuda.ExternalStream(self.stream, device=device) if self.stream
+                                  else torch.cuda.default_stream(device))
         intr, xb = _c(intrinsics), _c(xi_base_cam)
         if intr.size != capi.NUM_INTRINSICS[_model(model)] or xb.size != 6:
             raise ValueError("wrong number of intrinsics / xi_base_cam needs 6 values")
@@ -86,17 +91,39 @@ class ReprojectSet:
 
         xo = dev_t(xi_odom, (self.n_blocks, 6))
         vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+        # The kernels run on the stream the set was created on; uploads and allocations above / below happen on torch's
+        # CURRENT stream, which may be another one at call time (`with torch.cuda.stream(...)`).  Order the two: the set's
+        # stream waits for what the current stream has queued (the uploads), the current stream waits for the kernels
+        # before anybody can read -- or the caching allocator can reuse -- the outputs.
+        cur = torch.cuda.current_stream(dev)
+        mine = self._torch_stream if cur.cuda_stream != self.stream else None
+
+        def enter():
+            if mine is not None:
+                mine.wait_stream(cur)
+
+        def leave(*tensors):
+            if mine is not None:
+                cur.wait_stream(mine)
+                for t in tensors:
+                    if t is not None:
+                        t.record_stream(mine)
+
         if self.sparse:
             res = torch.empty((self.n_points, 2), dtype=torch.float64, device=dev)
             jac = torch.empty((self.n_points, 2, 6), dtype=torch.float64, device=dev) if want_jac else None
+            enter()
             capi.check(self._lib.vg_sparse_reproject_evaluate(self._h, vp(xo), vp(res), vp(jac)))
+            leave(xo, res, jac)
             self._keep = (xo,)
             return res, jac
         ln = dev_t(lengths, (self.n_blocks, 5))
         res = torch.empty((self.n_blocks, 10), dtype=torch.float64, device=dev)
         j0 = torch.empty((self.n_blocks, 10, 6), dtype=torch.float64, device=dev) if want_jac else None
         j1 = torch.empty((self.n_blocks, 10, 5), dtype=torch.float64, device=dev) if want_jac else None
+        enter()
         capi.check(self._lib.vg_mono_reproject_evaluate(self._h, vp(xo), vp(ln), vp(res), vp(j0), vp(j1)))
+        leave(xo, ln, res, j0, j1)
         self._keep = (xo, ln)
         return res, j0, j1
 
