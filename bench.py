@@ -304,7 +304,7 @@ def main():
             try:
                 snap = dict(out)
                 snap["secondary_sections"] = "not finished within %.0f s: %s missing" % (
-                    limit, ", ".join(k for k in ("roofline", "jtj", "sharded_mei", "sharded_solve", "solve", "pcie_inclusive") if k not in snap))
+                    limit, ", ".join(k for k in ("roofline", "jtj", "sharded_mei", "sharded_solve", "solve", "pcie_inclusive", "config3_stereo", "config5_rig", "eucm_100k") if k not in snap))
                 line = json.dumps(snap)
                 break
             except RuntimeError:   # the main thread added a key meanwhile
@@ -584,6 +584,41 @@ def main():
     # (b) EUCM, 100 000 images in total: the size from which sharding is expected to pay.  With one
     # rank these are plain solves; the communicator is passed whenever one exists.
     sharded_solve = {}
+    stream_100k = None
+
+    def beyond_l3_stream(dd, model_b, n_b):
+        """The emit step on a working set far beyond the 256 MiB Infinity Cache (100 000 images: 2.15 GB of output per step):
+        chain prep + emit kernel on prepared frames, HIP events on the launch stream."""
+        from visgeom_amd.benchlib import emit_bytes_per_obs, timed as timed_b
+
+        pb = CalibrationProblem(local_rank)
+        cb = pb.add_camera(model_b, dd["init_intrinsics"])
+        sb = pb.add_transform(False, dd["init_poses"])
+        db = pb.add_dataset(cb, [(sb, 0)], dd["board"], dd["corners"])
+        pb.finalize()
+        rb, jib, jmb = pb.alloc_outputs(db)
+
+        def step_b():
+            pb.prepare()
+            pb.evaluate_dataset(db, rb, jib, jmb)
+
+        def emit_b():
+            pb.evaluate_dataset(db, rb, jib, jmb)
+
+        reps_b = 40
+        t_step, t_emit = timed_b(step_b, reps_b), timed_b(emit_b, reps_b)
+        nb = n_b * N * emit_bytes_per_obs(model_b, 1)
+        one = capi.load().vg_dataset_single_launch(pb._h, db) == 1
+        pb.close()
+        del rb, jib, jmb
+        return {"workload": "%s mono, %d images x %d corners on this GPU: %.2f GB of output per step (beyond the 256 MiB Infinity Cache)" % (model_b.upper(), n_b, N, nb / 1e9),
+                "step_ms": t_step * 1e3, "evals_per_s": n_b * N / t_step,
+                "launches": "one launch" if one else "vg_chain_prep_kernel + vg_emit_kernel on prepared frames",
+                "roofline": {"bound": "hbm", "kernel": "vg_emit_kernel<%s,jac,frames-in-LDS%s>" % (model_b, ",inline-chain" if one else ""),
+                             "achieved": nb / t_emit / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nb / t_emit / 1e9 / HBM_PEAK_GBS,
+                             "frac_whole_step": nb / t_step / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": nb,
+                             "avg_launch_ms": t_emit * 1e3, "traffic": None}}
+
     try:
         from visgeom_amd import distributed as vdist
 
@@ -613,6 +648,8 @@ def main():
                 runs.append(dt * 1e3)
                 xsh = psh.get_parameters()
                 psh.close()
+            if key == "eucm_100k" and not a.no_secondary_configs:
+                stream_100k = beyond_l3_stream(dsh, model_s, hi - lo)
             Ksh = dsh["init_intrinsics"].size
             sharded_solve[key] = {
                 "workload": "%s mono, %d images x %d corners in total over %d rank(s), full LM solve" % (model_s.upper(), n_total, N, world),
@@ -627,8 +664,23 @@ def main():
         sharded_solve["error"] = repr(e)
 
     out["sharded_solve"] = sharded_solve
+    # ---- BASELINE.json configs 3 (stereo pair, two-member chain) and 5 (four-camera rig, full LM loop) and the beyond-L3
+    # stream, measured in the driver's own run: emit step, merged Gram iteration, LM solve; every emit /
+    # Gram pass carries its own `roofline` and the kernel name the rocprofv3 trace of tools/prof_configs.sh shows.  Every rank
+    # measures its own replica of the configuration on its GPU (no collective: these sizes are one-GPU problems); rank 0 reports.
+    if not a.no_secondary_configs:
+        from visgeom_amd import benchlib
+
+        small = int(os.environ.get("VG_BENCH_CONFIG_IMAGES", "0")) or None    # rehearsals shrink the configurations
+        for key, cfg_c in (("config3_stereo", 3), ("config5_rig", 5)):
+            try:
+                out[key] = benchlib.section(cfg_c, reps=100 if small is None else 5, device=local_rank, images=small)
+            except Exception as e:  # never take the headline down
+                out[key] = {"error": repr(e)}
+        out["eucm_100k"] = stream_100k if stream_100k is not None else {"skipped": "no 100 k-image set in this run (--sharded-solve-images 0)"}
     # key order of the line as before: headline fields, then the sections
-    out = {k: out[k] for k in list(out)[:13] + ["roofline", "jtj", "sharded_mei", "sharded_solve", "solve", "pcie_inclusive"]}
+    out = {k: out[k] for k in list(out)[:13] + ["roofline", "jtj", "sharded_mei", "sharded_solve", "solve", "pcie_inclusive"] +
+           [k for k in ("config3_stereo", "config5_rig", "eucm_100k") if k in out]}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(d, a.model, a.cpu_seconds)
         out["gpu_over_cpu_allcores"] = value / out["cpu_baseline"]["value"]

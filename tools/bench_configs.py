@@ -20,7 +20,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-from visgeom_amd import CalibrationProblem, synthetic  # noqa: E402
 from visgeom_amd import capi as _capi  # noqa: E402
 
 _capi.hooks_from_env()  # legacy VG_* switches -> vg_debug_set
@@ -30,96 +29,26 @@ ONLY_CONFIG = int(_args[_args.index("--config") + 1]) if "--config" in _args els
 ONLY = _args[_args.index("--only") + 1] if "--only" in _args else None
 _pos = [a for i, a in enumerate(_args) if not a.startswith("--") and (i == 0 or _args[i - 1] not in ("--config", "--only"))]
 REPS = int(_pos[0]) if _pos else 100
-KOF = {"eucm": 6, "ucm": 5, "mei": 10}
-EVAL_FLOPS = {"eucm": 200, "ucm": 197, "mei": 346}   # counted from the restatement
-HBM_PEAK, FP64_PEAK = 8.0e12, 78.6e12
-
-
-def gram_flops_per_obs(model, L):
-    P = KOF[model] + 6 * L
-    return EVAL_FLOPS[model] + 48 * (L - 1) + 2 * (P + 1) * (P + 2)
+from visgeom_amd.benchlib import EVAL_FLOPS, FP64_PEAK, HBM_PEAK, KOF, gram_flops_per_obs, passes  # noqa: E402
+from visgeom_amd.benchlib import build as _build_config, timed as _timed  # noqa: E402
 
 
 def timed(fn, reps=REPS):
-    for _ in range(max(3, reps // 10)):
-        fn()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps * 1e-3   # seconds
+    return _timed(fn, reps)
 
 
 def build(cfg):
-    p = CalibrationProblem(0)
-    if cfg == 2 or cfg == 4:
-        model, n = ("eucm", 1000) if cfg == 2 else ("mei", 10000)
-        d = synthetic.make_mono(model, n, cfg)
-        cam = p.add_camera(model, d["init_intrinsics"])
-        seq = p.add_transform(False, d["init_poses"])
-        dss = [(p.add_dataset(cam, [(seq, 0)], d["board"], d["corners"]), model, 1, n)]
-        gt = [d["gt_intrinsics"]]
-        name = "config %d: %s mono, %d images" % (cfg, model.upper(), n)
-    elif cfg == 3:
-        s = synthetic.make_stereo(2000)
-        c1 = p.add_camera("eucm", s["init_intrinsics1"])
-        c2 = p.add_camera("eucm", s["init_intrinsics2"])
-        x12 = p.add_transform(True, s["init_xi12"])
-        seq = p.add_transform(False, s["init_poses"])
-        dss = [(p.add_dataset(c1, [(seq, 0)], s["board"], s["corners1"]), "eucm", 1, 2000),
-               (p.add_dataset(c2, [(x12, 1), (seq, 0)], s["board"], s["corners2"]), "eucm", 2, 2000)]
-        gt = [s["gt_intrinsics1"], s["gt_intrinsics2"]]
-        name = "config 3: stereo 2 x EUCM + xiCam12, 2000 pairs"
-    else:
-        r = synthetic.make_rig(5000)
-        cams = [p.add_camera(m, r["init_intrinsics"][k]) for k, m in enumerate(r["models"])]
-        x1k = [p.add_transform(True, r["init_xi1k"][k]) for k in range(3)]
-        seq = p.add_transform(False, r["init_poses"])
-        dss = [(p.add_dataset(cams[0], [(seq, 0)], r["board"], r["corners"][0]), r["models"][0], 1, 5000)]
-        for k in range(3):
-            dss.append((p.add_dataset(cams[k + 1], [(x1k[k], 1), (seq, 0)], r["board"], r["corners"][k + 1]), r["models"][k + 1], 2, 5000))
-        gt = r["gt_intrinsics"]
-        name = "config 5: rig [UCM, EUCM, EUCM, Mei], 5000 frames"
-    p.finalize()
-    return p, dss, gt, name
+    return _build_config(cfg, 0)
 
 
 def main():
     rows = []
     for cfg in ((ONLY_CONFIG,) if ONLY_CONFIG else (2, 3, 4, 5)):
         p, dss, gt, name = build(cfg)
-        outs = [p.alloc_outputs(ds) for ds, _, _, _ in dss]
-        grams = [p.alloc_gram(ds) for ds, _, _, _ in dss]
+        f = passes(p, dss)
+        emit, emit_only, emit_per_dataset, jtj, gram_only = f["emit"], f["emit_only"], f["emit_per_dataset"], f["jtj"], f["gram_only"]
         n_obs = sum(n * 96 for _, _, _, n in dss)
         bytes_emit = sum(n * 96 * (32 + 16 * (KOF[m] + 6 * L)) for _, m, L, n in dss)
-
-        def emit():
-            p.prepare()
-            p.evaluate_all(outs)   # every dataset of the problem in one pass (vg_problem_evaluate: merged launches)
-
-        def emit_only():
-            p.evaluate_all(outs)
-
-        def emit_per_dataset():
-            for (ds, _, _, _), (res, ji, jm) in zip(dss, outs):
-                p.evaluate_dataset(ds, res, ji, jm)
-
-        def jtj():
-            p.prepare()
-            if len(dss) > 1:   # every dataset in one pass (vg_problem_gram_fused_sum: merged Gram launch + ONE sum launch)
-                p.gram_fused_sum_all([g for g, _ in grams], [s for _, s in grams])
-            else:
-                for (ds, _, _, _), (gram, gsum) in zip(dss, grams):
-                    p.gram_fused_sum(ds, gram, gsum)
-
-        def gram_only():   # the fused Gram launch(es) alone: what roofline_jtj prices
-            if len(dss) > 1:
-                p.gram_fused_all([g for g, _ in grams])
-            else:
-                p.gram_fused(dss[0][0], grams[0][0])
 
         if ONLY in ("emit", "jtj", "solve"):   # one kind of launch only: a clean rocprofv3 / PMC pass
             if ONLY == "emit":

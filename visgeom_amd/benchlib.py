@@ -1,0 +1,173 @@
+"""Measurement helpers shared by bench.py (the driver's contract line and its per-config sections) and tools/bench_configs.py:
+BASELINE.json's configs 2-5 built on one GPU, timed with HIP events on the launch stream, priced against the roofline that
+bounds each pass.  Not part of the product path (nothing here is called by the library or the solver).
+
+Algorithmic work per observation:
+  emit pass   16 (observation) + 16 (residual pair) + 16 (K + 6 L) (Jacobian rows) bytes         -> HBM, 8 TB/s
+  fused Gram  EVAL_FLOPS[model] + 48 (L - 1) + 2 (P + 1)(P + 2) flops, P = K + 6 L               -> FP64 vector pipe, 78.6 TFLOP/s
+"""
+import numpy as np
+
+KOF = {"eucm": 6, "ucm": 5, "mei": 10}
+EVAL_FLOPS = {"eucm": 200, "ucm": 197, "mei": 346}   # counted from the restatement
+HBM_PEAK, FP64_PEAK = 8.0e12, 78.6e12
+N_CORNERS = 96
+
+
+def gram_flops_per_obs(model, L):
+    P = KOF[model] + 6 * L
+    return EVAL_FLOPS[model] + 48 * (L - 1) + 2 * (P + 1) * (P + 2)
+
+
+def emit_bytes_per_obs(model, L):
+    return 32 + 16 * (KOF[model] + 6 * L)
+
+
+def timed(fn, reps):
+    """seconds per call: HIP events on torch's current stream (the stream the problems launch on) around `reps` calls"""
+    import torch
+
+    for _ in range(max(3, reps // 10)):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e-3
+
+
+def build(cfg, device=0, images=None):
+    """BASELINE.json config `cfg` (2..5) -> (problem, [(dataset id, model, chain length, images)], generating intrinsics, name).
+    `images` scales the image count down (rehearsals); None = the configuration's own size."""
+    from . import CalibrationProblem, synthetic
+
+    p = CalibrationProblem(device)
+    if cfg == 2 or cfg == 4:
+        model, n = ("eucm", 1000) if cfg == 2 else ("mei", 10000)
+        n = images or n
+        d = synthetic.make_mono(model, n, cfg)
+        cam = p.add_camera(model, d["init_intrinsics"])
+        seq = p.add_transform(False, d["init_poses"])
+        dss = [(p.add_dataset(cam, [(seq, 0)], d["board"], d["corners"]), model, 1, n)]
+        gt = [d["gt_intrinsics"]]
+        name = "config %d: %s mono, %d images" % (cfg, model.upper(), n)
+    elif cfg == 3:
+        n = images or 2000
+        s = synthetic.make_stereo(n)
+        c1 = p.add_camera("eucm", s["init_intrinsics1"])
+        c2 = p.add_camera("eucm", s["init_intrinsics2"])
+        x12 = p.add_transform(True, s["init_xi12"])
+        seq = p.add_transform(False, s["init_poses"])
+        dss = [(p.add_dataset(c1, [(seq, 0)], s["board"], s["corners1"]), "eucm", 1, n),
+               (p.add_dataset(c2, [(x12, 1), (seq, 0)], s["board"], s["corners2"]), "eucm", 2, n)]
+        gt = [s["gt_intrinsics1"], s["gt_intrinsics2"]]
+        name = "config 3: stereo 2 x EUCM + xiCam12, %d pairs" % n
+    elif cfg == 5:
+        n = images or 5000
+        r = synthetic.make_rig(n)
+        cams = [p.add_camera(m, r["init_intrinsics"][k]) for k, m in enumerate(r["models"])]
+        x1k = [p.add_transform(True, r["init_xi1k"][k]) for k in range(3)]
+        seq = p.add_transform(False, r["init_poses"])
+        dss = [(p.add_dataset(cams[0], [(seq, 0)], r["board"], r["corners"][0]), r["models"][0], 1, n)]
+        for k in range(3):
+            dss.append((p.add_dataset(cams[k + 1], [(x1k[k], 1), (seq, 0)], r["board"], r["corners"][k + 1]), r["models"][k + 1], 2, n))
+        gt = r["gt_intrinsics"]
+        name = "config 5: rig [UCM, EUCM, EUCM, Mei], %d frames" % n
+    else:
+        raise ValueError("config must be 2..5")
+    p.finalize()
+    return p, dss, gt, name
+
+
+def passes(p, dss):
+    """the closures every measurement times: (emit step, emit launches only, JtJ iteration, Gram launch(es) only, per-dataset emit)"""
+    outs = [p.alloc_outputs(ds) for ds, _, _, _ in dss]
+    grams = [p.alloc_gram(ds) for ds, _, _, _ in dss]
+
+    def emit():
+        p.prepare()
+        p.evaluate_all(outs)   # every dataset of the problem in one pass (vg_problem_evaluate: merged launches)
+
+    def emit_only():
+        p.evaluate_all(outs)
+
+    def emit_per_dataset():
+        for (ds, _, _, _), (res, ji, jm) in zip(dss, outs):
+            p.evaluate_dataset(ds, res, ji, jm)
+
+    def jtj():
+        p.prepare()
+        if len(dss) > 1:   # every dataset in one pass (vg_problem_gram_fused_sum: merged Gram launch + ONE sum launch)
+            p.gram_fused_sum_all([g for g, _ in grams], [s for _, s in grams])
+        else:
+            for (ds, _, _, _), (gram, gsum) in zip(dss, grams):
+                p.gram_fused_sum(ds, gram, gsum)
+
+    def gram_only():   # the fused Gram launch(es) alone: what roofline_jtj prices
+        if len(dss) > 1:
+            p.gram_fused_all([g for g, _ in grams])
+        else:
+            p.gram_fused(dss[0][0], grams[0][0])
+
+    return {"emit": emit, "emit_only": emit_only, "emit_per_dataset": emit_per_dataset, "jtj": jtj, "gram_only": gram_only,
+            "keep": (outs, grams)}
+
+
+def section(cfg, reps=200, device=0, images=None, solve_runs=2, comm=None, allreduce=None):
+    """One BASELINE config as a bench.py section: emit step, merged Gram iteration and full LM solve, each emit / Gram pass with
+    its own `roofline` object and the name of the kernel that rocprofv3 --kernel-trace shows for it."""
+    import torch
+
+    p, dss, gt, name = build(cfg, device, images)
+    f = passes(p, dss)
+    multi = len(dss) > 1
+    n_obs = sum(n * N_CORNERS for _, _, _, n in dss)
+    bytes_emit = sum(n * N_CORNERS * emit_bytes_per_obs(m, L) for _, m, L, n in dss)
+    flops_jtj = sum(n * N_CORNERS * gram_flops_per_obs(m, L) for _, m, L, n in dss)
+    t_emit, t_emit_only = timed(f["emit"], reps), timed(f["emit_only"], reps)
+    t_jtj = timed(f["jtj"], reps)
+    p.prepare()
+    f["gram_only"]()
+    t_gram = timed(f["gram_only"], reps)
+    x0 = p.get_parameters()
+    best = None
+    for _ in range(max(1, solve_runs)):
+        p.set_parameters(x0)
+        torch.cuda.synchronize()
+        s = p.solve(max_num_iterations=200, comm=comm, allreduce=allreduce)
+        if best is None or s["total_seconds"] < best["total_seconds"]:
+            best = s
+    x = p.get_parameters()
+    err, off = 0.0, 0
+    for g in gt:
+        err = max(err, float(np.max(np.abs(x[off:off + g.size] - g) / np.maximum(np.abs(g), 1.0))))
+        off += g.size
+    from . import capi
+
+    one_launch = (not multi) and capi.load().vg_dataset_single_launch(p._h, dss[0][0]) == 1
+    row = {
+        "workload": name, "observations": n_obs,
+        "emit": {"step_ms": t_emit * 1e3, "evals_per_s": n_obs / t_emit,
+                 "launches": ("vg_chain_prep_multi_kernel + one emit launch for all datasets" if multi else
+                              "one launch: the emit kernel walks the single-member chain" if one_launch else "chain prep + emit"),
+                 "roofline": {"bound": "hbm", "kernel": "vg_emit_multi_kernel" if multi else "vg_emit_kernel", "achieved": bytes_emit / t_emit_only / 1e9,
+                              "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": bytes_emit / t_emit_only / HBM_PEAK,
+                              "frac_whole_step": bytes_emit / t_emit / HBM_PEAK, "algorithmic_bytes_per_launch": bytes_emit,
+                              "avg_launch_ms": t_emit_only * 1e3, "traffic": None}},
+        "jtj": {"ms_per_iter": t_jtj * 1e3,
+                "launches": "chain prep + merged Gram launch + one partial-sum launch" if multi else "fused Gram launch + partial-sum launch",
+                "roofline": {"bound": "fp64", "kernel": "vg_gram_valu_multi_kernel" if multi else "vg_gram_valu_kernel", "achieved": flops_jtj / t_gram / 1e12,
+                             "peak": FP64_PEAK / 1e12, "unit": "TFLOP/s", "frac": flops_jtj / t_gram / FP64_PEAK,
+                             "frac_whole_iteration": flops_jtj / t_jtj / FP64_PEAK, "algorithmic_flops_per_launch": flops_jtj,
+                             "flops_per_observation": {"%s L=%d" % (m, L): gram_flops_per_obs(m, L) for _, m, L, _ in dss},
+                             "avg_launch_ms": t_gram * 1e3}},
+        "solve": {"total_ms": best["total_seconds"] * 1e3, "iterations": best["num_iterations"],
+                  "ms_per_iteration": best["total_seconds"] * 1e3 / max(best["num_iterations"], 1), "termination": best["termination"],
+                  "final_cost": best["final_cost"], "global_columns": best["num_global_columns"],
+                  "max_rel_intrinsics_error_vs_generating": err},
+    }
+    p.close()
+    return row
