@@ -22,31 +22,60 @@ if not os.environ.get("VG_PRODUCTION"):
 
 
 def sources():
+    """the translation units of the library: every .hip file of csrc/ (vg_capi: problem assembly + emit; vg_gram_tu: normal
+    equations; vg_solver_tu: LM / Schur + communicator; vg_refine_tu: per-image pose LM; vg_frontend_tu: calibration JSON;
+    vg_local_tu: localization costs)"""
     return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
 
 
-def _deps():
-    out = []
-    for d in (CSRC, os.path.join(ROOT, "include")):
-        for f in os.listdir(d):
-            if f.endswith((".hip", ".hpp", ".h", ".cpp")):
-                out.append(os.path.join(d, f))
-    return out
-
-
+OBJ_DIR = os.path.join(LIB_DIR, "obj")
 STAMP = os.path.join(LIB_DIR, "libvisgeom_amd.sources.sha256")
+_INCLUDE = None
 
 
-def sources_digest():
-    """sha256 over the compiler flags and the CONTENT of every source / header the library is built from (a snapshot copied
-    to another machine has fresh mtimes everywhere: modification times say nothing about what a library was built from)"""
+def _closure(path, seen=None):
+    """the file and every project header it includes, transitively (quoted includes, resolved against csrc/ and include/)"""
+    import re
+
+    global _INCLUDE
+    if _INCLUDE is None:
+        _INCLUDE = re.compile(r'^\s*#\s*include\s+["<]([^">]+)[">]', re.M)
+    seen = seen if seen is not None else set()
+    if path in seen or not os.path.exists(path):
+        return seen
+    seen.add(path)
+    with open(path) as fh:
+        text = fh.read()
+    for inc in _INCLUDE.findall(text):
+        for base in (os.path.dirname(path), CSRC, os.path.join(ROOT, "include")):
+            cand = os.path.normpath(os.path.join(base, inc))
+            if os.path.exists(cand):
+                _closure(cand, seen)
+                break
+    return seen
+
+
+def unit_digest(src):
+    """sha256 over the compiler flags and the CONTENT of a translation unit and of every header it reaches (a snapshot copied
+    to another machine has fresh mtimes everywhere: modification times say nothing about what an object was built from)"""
     import hashlib
 
     h = hashlib.sha256(" ".join(HIPCC_FLAGS).encode())
-    for f in sorted(_deps()):
+    for f in sorted(_closure(src)):
         h.update(os.path.basename(f).encode())
         with open(f, "rb") as fh:
             h.update(fh.read())
+    return h.hexdigest()
+
+
+def sources_digest():
+    import hashlib
+
+    h = hashlib.sha256()
+    for src in sources():
+        h.update(unit_digest(src).encode())
+    with open(os.path.join(CSRC, "calib_main.cpp"), "rb") as fh:
+        h.update(fh.read())
     return h.hexdigest()
 
 
@@ -57,17 +86,51 @@ def up_to_date():
         return fh.read().strip() == sources_digest()
 
 
+def _compile_unit(hipcc, src, verbose):
+    """one translation unit -> lib/obj/<name>.o, skipped when the object was built from the same content"""
+    name = os.path.splitext(os.path.basename(src))[0]
+    obj, stamp = os.path.join(OBJ_DIR, name + ".o"), os.path.join(OBJ_DIR, name + ".sha256")
+    digest = unit_digest(src)
+    if os.path.exists(obj) and os.path.exists(stamp):
+        with open(stamp) as fh:
+            if fh.read().strip() == digest:
+                return obj, 0.0
+    import time
+
+    t0 = time.time()
+    cmd = [hipcc] + [f for f in HIPCC_FLAGS if f != "-shared"] + ["-I", os.path.join(ROOT, "include"), "-c", src, "-o", obj]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    with open(stamp, "w") as fh:
+        fh.write(digest + "\n")
+    return obj, time.time() - t0
+
+
 def build(force=False, verbose=False):
     if not force and up_to_date():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: the HIP library cannot be built (there is no CPU fallback)")
-    os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [hipcc] + HIPCC_FLAGS + ["-I", os.path.join(ROOT, "include"), "-o", LIB] + sources()
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    if force:
+        for f in os.listdir(OBJ_DIR):
+            os.remove(os.path.join(OBJ_DIR, f))
+    import time
+    from concurrent.futures import ThreadPoolExecutor
+
+    t0 = time.time()
+    srcs = sources()
+    with ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 1)) as ex:   # the units compile side by side
+        done = list(ex.map(lambda s: _compile_unit(hipcc, s, verbose), srcs))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + [o for o, _ in done]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
+    if verbose:
+        print("built %d translation units in %.1f s wall (%s)" % (len(srcs), time.time() - t0, ", ".join(
+            "%s %.1f s" % (os.path.basename(o), t) for o, t in done)), file=sys.stderr)
     build_cli(verbose)
     with open(STAMP, "w") as fh:
         fh.write(sources_digest() + "\n")

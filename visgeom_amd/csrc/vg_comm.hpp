@@ -123,12 +123,15 @@ inline int need_api()
             return vgi::fail(VG_ERR_HIP, std::string(#expr) + ": " + vgc::api().error_string(r_));        \
     } while (0)
 
+#ifdef VG_TU_SOLVER  // this kernel is launched by one translation unit only; the others see the header without it
 __global__ void vg_scale_in_place_kernel(double *buf, size_t n, double f)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) buf[i] *= f;
 }
+#endif
 
+#ifdef VG_TU_SOLVER  // this kernel is launched by one translation unit only; the others see the header without it
 __global__ void vg_local_sum_slots_kernel(const double *slots, size_t cap, int n_ranks, double *buf, size_t n)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -137,6 +140,7 @@ __global__ void vg_local_sum_slots_kernel(const double *slots, size_t cap, int n
     for (int r = 0; r < n_ranks; r++) s += slots[(size_t)r * cap + i];
     buf[i] = s;
 }
+#endif
 
 // in-place sum over the ranks of c, enqueued on `stream`; a NULL or one-rank communicator is the identity
 inline int allreduce_sum(const vg_comm *c, double *device_buf, size_t n, hipStream_t stream)

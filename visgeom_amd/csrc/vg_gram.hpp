@@ -394,11 +394,13 @@ __device__ __forceinline__ void gram_slab_sum_body(const double *__restrict__ in
     }
 }
 
+#ifdef VG_TU_GRAM  // this kernel is launched by one translation unit only; the others see the header without it
 __global__ __launch_bounds__(256) void vg_gram_slab_sum_kernel(const double *__restrict__ in, unsigned int n_items,
                                                                 int entries, double *__restrict__ out)
 {
     gram_slab_sum_body(in, n_items, entries, out, blockIdx.x);
 }
+#endif
 
 __device__ __forceinline__ void gram_final_sum_body(const double *__restrict__ in, unsigned int n_items, int entries,
                                                     double *__restrict__ out, unsigned int block)
@@ -425,21 +427,25 @@ __device__ __forceinline__ void gram_final_sum_body(const double *__restrict__ i
     if (lane == 0) out[e] = s;
 }
 
+#ifdef VG_TU_GRAM  // this kernel is launched by one translation unit only; the others see the header without it
 __global__ __launch_bounds__(256) void vg_gram_final_sum_kernel(const double *__restrict__ in, unsigned int n_items,
                                                                  int entries, double *__restrict__ out)
 {
     gram_final_sum_body(in, n_items, entries, out, blockIdx.x);
 }
+#endif
 
 // The five scalar sums of an LM step (per-workgroup partials of the back-substitution -> out[5], the final-sum order) and,
 // with them, the step's max |g_pose| (a bit pattern kept by atomicMax) copied to `gmax_out`: the host-driven loop points both
 // outputs at pinned host memory -- a store at the end of a kernel instead of a copy command behind it.
+#ifdef VG_TU_SOLVER  // this kernel is launched by one translation unit only; the others see the header without it
 __global__ __launch_bounds__(256) void vg_step_scalars_kernel(const double *__restrict__ in, unsigned int n_items, double *__restrict__ out,
                                                                const unsigned long long *__restrict__ gmax_bits, unsigned long long *gmax_out)
 {
     gram_final_sum_body(in, n_items, 5, out, blockIdx.x);
     if (blockIdx.x == 1 && threadIdx.x == 0 && gmax_out) *gmax_out = *gmax_bits;
 }
+#endif
 
 // The same two stages for SEVERAL datasets in one launch each (a rig has one Gram array per camera; their sums are
 // launch-latency bound, so four datasets cost two launches instead of eight).  Identical arithmetic and order per
@@ -454,6 +460,7 @@ struct SumDataset {
     unsigned int first_final_block;  // ... in the final launch (4 entries per workgroup)
 };
 
+#ifdef VG_TU_SOLVER  // this kernel is launched by one translation unit only; the others see the header without it
 __global__ __launch_bounds__(256) void vg_gram_slab_sum_multi_kernel(const SumDataset *__restrict__ ds, int n_ds)
 {
     int d = 0;
@@ -461,7 +468,9 @@ __global__ __launch_bounds__(256) void vg_gram_slab_sum_multi_kernel(const SumDa
     const SumDataset D = ds[d];
     gram_slab_sum_body(D.gram, D.n_items, D.entries, D.partials, blockIdx.x - D.first_slab_block);
 }
+#endif
 
+#ifdef VG_TU_SOLVER  // this kernel is launched by one translation unit only; the others see the header without it
 __global__ __launch_bounds__(256) void vg_gram_final_sum_multi_kernel(const SumDataset *__restrict__ ds, int n_ds)
 {
     int d = 0;
@@ -469,5 +478,6 @@ __global__ __launch_bounds__(256) void vg_gram_final_sum_multi_kernel(const SumD
     const SumDataset D = ds[d];
     gram_final_sum_body(D.partials, D.n_slabs, D.entries, D.out, blockIdx.x - D.first_final_block);
 }
+#endif
 
 }  // namespace vg

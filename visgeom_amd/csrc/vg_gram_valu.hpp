@@ -666,6 +666,7 @@ struct GramValuMultiArgs {
     int n;
 };
 
+#ifdef VG_TU_GRAM  // this kernel is launched by one translation unit only; the others see the header without it
 __global__ __launch_bounds__(kValuThreads, 2) void vg_gram_valu_multi_kernel(GramValuMultiArgs m)
 {
     extern __shared__ __attribute__((aligned(16))) double valu_lds[];
@@ -685,9 +686,11 @@ __global__ __launch_bounds__(kValuThreads, 2) void vg_gram_valu_multi_kernel(Gra
     default: gram_valu_z_body<kMEI, 2>(a, a.g.intr, block, valu_lds); break;
     }
 }
+#endif
 
 // final sum over the workgroup partials [E][n_wg] -> full symmetric W x W.  One WORKGROUP per entry: every lane's loads
 // (contiguous, up to 8 per lane) are in flight together, so 1 250 partials cost one memory round trip; fixed order.
+#ifdef VG_TU_GRAM  // this kernel is launched by one translation unit only; the others see the header without it
 __global__ __launch_bounds__(256) void vg_gram_partials_sum_kernel(const double *__restrict__ partials, unsigned int n_wg,
                                                                     int W, double *__restrict__ out)
 {
@@ -721,6 +724,7 @@ __global__ __launch_bounds__(256) void vg_gram_partials_sum_kernel(const double 
         out[c * W + r] = t;
     }
 }
+#endif
 
 // vg_gram_partials_sum_kernel for SEVERAL datasets in one launch (the merged Gram launch left one [E][n_wg] array per
 // dataset): one workgroup per (dataset, entry), same order of summation per dataset as the single-dataset kernel.
@@ -765,6 +769,7 @@ __device__ __forceinline__ void gram_partials_sum_entry(const PartialSumDataset 
     }
 }
 
+#ifdef VG_TU_SOLVER  // this kernel is launched by one translation unit only; the others see the header without it
 __global__ __launch_bounds__(256) void vg_gram_partials_sum_multi_kernel(const PartialSumDataset *__restrict__ ds, int n_ds)
 {
     int d = 0;
@@ -772,6 +777,7 @@ __global__ __launch_bounds__(256) void vg_gram_partials_sum_multi_kernel(const P
     const PartialSumDataset D = ds[d];
     gram_partials_sum_entry(D);
 }
+#endif
 
 // the same with the table in the kernel arguments (vg_problem_gram_fused_sum: the output pointers are the caller's and may
 // change from call to call -- no table to upload)
@@ -781,16 +787,19 @@ struct PartialSumArgs {
     int n;
 };
 
+#ifdef VG_TU_GRAM  // this kernel is launched by one translation unit only; the others see the header without it
 __global__ __launch_bounds__(256) void vg_gram_partials_sum_args_kernel(PartialSumArgs a)
 {
     int d = 0;
     while (d + 1 < a.n && blockIdx.x >= a.ds[d + 1].first_block) d++;
     gram_partials_sum_entry(a.ds[d]);
 }
+#endif
 
 // Sum of n_items row-major blocks of `entries` doubles: out[e] = sum_i in[i * entries + e], one workgroup per entry, every
 // lane's (strided) loads in flight together, fixed order.  One launch where slab + final sum were two: a few hundred small
 // blocks (the Gram of the pose rows per row group) are latency, not bandwidth.
+#ifdef VG_TU_SOLVER  // this kernel is launched by one translation unit only; the others see the header without it
 __global__ __launch_bounds__(256) void vg_gram_strided_sum_kernel(const double *__restrict__ in, unsigned int n_items, int entries,
                                                                    double *__restrict__ out)
 {
@@ -813,10 +822,12 @@ __global__ __launch_bounds__(256) void vg_gram_strided_sum_kernel(const double *
     __syncthreads();
     if (tid == 0) out[e] = (red[0] + red[1]) + (red[2] + red[3]);
 }
+#endif
 
 // The same sum for WIDE blocks (hundreds to thousands of entries: the Gram of the pose rows of a rig): a workgroup owns 16
 // consecutive entries, 16 lanes per entry walk the items, every load of a 16-lane group is one 128-byte segment; the 16
 // partial sums of an entry are added in a fixed order.
+#ifdef VG_TU_SOLVER  // this kernel is launched by one translation unit only; the others see the header without it
 __global__ __launch_bounds__(256) void vg_gram_strided_sum_tiled_kernel(const double *__restrict__ in, unsigned int n_items, int entries,
                                                                          double *__restrict__ out)
 {
@@ -843,11 +854,14 @@ __global__ __launch_bounds__(256) void vg_gram_strided_sum_tiled_kernel(const do
         out[blockIdx.x * 16 + tid] = t;
     }
 }
+#endif
 
+#ifdef VG_TU_SOLVER
 inline void launch_strided_sum(hipStream_t st, const double *in, unsigned int n_items, int entries, double *out)
 {
     if (entries <= 256) hipLaunchKernelGGL(vg_gram_strided_sum_kernel, dim3(entries), dim3(256), 0, st, in, n_items, entries, out);
     else hipLaunchKernelGGL(vg_gram_strided_sum_tiled_kernel, dim3((entries + 15) / 16), dim3(256), 0, st, in, n_items, entries, out);
 }
+#endif
 
 }  // namespace vg

@@ -153,6 +153,13 @@ struct vg_block {
 };
 
 namespace vgi {
+inline int valid_dataset(const vg_problem *p, int d)
+{
+    if (!p) return fail(VG_ERR_INVALID_ARGUMENT, "problem is NULL");
+    if (d < 0 || d >= (int)p->dss.size()) return fail(VG_ERR_INVALID_ARGUMENT, "dataset id out of range");
+    return VG_OK;
+}
+
 // kernel launches on an explicit parameter buffer (the solver evaluates candidate points without
 // touching the problem's own parameter vector); implemented in vg_capi.hip
 int prepare_at(vg_problem *p, const double *d_params);

@@ -31,6 +31,7 @@ struct ChainDesc {
 // wave each: the kernel is latency bound (a dependent chain of sqrt / sincos / atan2 / divisions),
 // not throughput bound.
 // ------------------------------------------------------------------------------------------
+#ifdef VG_TU_CORE  // this kernel is launched by one translation unit only; the others see the header without it
 __global__ __launch_bounds__(64) void vg_chain_prep_kernel(const double *__restrict__ params, ChainDesc cd,
                                                             const int *__restrict__ seq_index, long long n_blocks,
                                                             double *__restrict__ frames, int frame_stride_d)
@@ -42,6 +43,7 @@ __global__ __launch_bounds__(64) void vg_chain_prep_kernel(const double *__restr
     build_frame(cd.L, cd.status, [&](int l) { return params + cd.base[l] + cd.stride[l] * si; },
                 frames + b * frame_stride_d);
 }
+#endif
 
 // all datasets of a problem in ONE launch: the kernel is latency bound, so four datasets cost the same ~7 us as one
 struct PrepDataset {
@@ -53,6 +55,7 @@ struct PrepDataset {
     int frame_stride_d;
 };
 
+#ifdef VG_TU_CORE  // this kernel is launched by one translation unit only; the others see the header without it
 __global__ __launch_bounds__(64) void vg_chain_prep_multi_kernel(const double *__restrict__ params,
                                                                   const PrepDataset *__restrict__ dsets, int n_dsets,
                                                                   long long total_blocks)
@@ -71,6 +74,7 @@ __global__ __launch_bounds__(64) void vg_chain_prep_multi_kernel(const double *_
     build_frame(D->chain.L, D->chain.status, [&](int l) { return params + base[l] + stride[l] * si; },
                 D->frames + b * D->frame_stride_d);
 }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // kernel 2: emit.
@@ -337,6 +341,7 @@ __device__ __forceinline__ void emit_tile_route(const EmitArgs &a, unsigned int 
     else emit_tile<MODEL, true, true, false>(a, o0);
 }
 
+#ifdef VG_TU_CORE  // this kernel is launched by one translation unit only; the others see the header without it
 __global__ __launch_bounds__(kEmitThreads) void vg_emit_multi_kernel(EmitMultiArgs m)
 {
     const unsigned int x = blockIdx.x & 7u;   // workgroup b runs on XCD b % 8 (observed dispatch order)
@@ -365,6 +370,7 @@ __global__ __launch_bounds__(kEmitThreads) void vg_emit_multi_kernel(EmitMultiAr
     default: emit_tile_route<kMEI>(m.ds[d], o0, inl); break;
     }
 }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // measurement helpers: pure streaming write / copy with the emit kernel's store pattern -- every wave
@@ -374,6 +380,7 @@ __global__ __launch_bounds__(kEmitThreads) void vg_emit_multi_kernel(EmitMultiAr
 // ------------------------------------------------------------------------------------------
 constexpr int kStreamUnroll = 4;
 
+#ifdef VG_TU_CORE  // this kernel is launched by one translation unit only; the others see the header without it
 __global__ __launch_bounds__(256) void vg_stream_write_kernel(double *__restrict__ dst, long long n2, double value)
 {
     using d2 = HIP_vector_type<double, 2>;
@@ -388,7 +395,9 @@ __global__ __launch_bounds__(256) void vg_stream_write_kernel(double *__restrict
         if (i < n2) d[i] = v;
     }
 }
+#endif
 
+#ifdef VG_TU_CORE  // this kernel is launched by one translation unit only; the others see the header without it
 __global__ __launch_bounds__(256) void vg_stream_copy_kernel(double *__restrict__ dst, const double *__restrict__ src,
                                                               long long n2)
 {
@@ -408,5 +417,6 @@ __global__ __launch_bounds__(256) void vg_stream_copy_kernel(double *__restrict_
         if (i < n2) d[i] = t[k];
     }
 }
+#endif
 
 }  // namespace vg

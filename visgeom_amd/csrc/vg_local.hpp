@@ -204,6 +204,7 @@ VG_HD double triangulate_regular(const double *R, const double *t, double eps, c
 
 // ------------------------------------------------------------------------------------------ kernels
 // one lane per block: the block's frame at its current odometry parameter
+#ifdef VG_TU_LOCAL  // this kernel is launched by one translation unit only; the others see the header without it
 __global__ __launch_bounds__(64) void vg_local_frame_kernel(const double *__restrict__ xiBaseCam, const double *__restrict__ xiOdom,
                                                              long long first_block, long long n_blocks, int sparse,
                                                              double *__restrict__ frames)
@@ -214,6 +215,7 @@ __global__ __launch_bounds__(64) void vg_local_frame_kernel(const double *__rest
     if (sparse) sparse_frame(xiBaseCam, xo, frames + (first_block + b) * kSparseFrame);
     else mono_frame(xiBaseCam, xo, frames + (first_block + b) * kMonoFrame);
 }
+#endif
 
 struct MonoArgs {
     const double *xb;       // xiBaseCam [6]

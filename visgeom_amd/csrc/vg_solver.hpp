@@ -144,6 +144,7 @@ __device__ __forceinline__ void pose_factor(const SchurArgs &a, int i, PoseFacto
 
 // one lane per (pose, global column): column gcol of the six rows  L^-1 W_i^T  (gcol == G: L^-1 g_i; that lane also
 // leaves the pose's record [L | g | diag V | active] for the back-substitution and counts non-positive-definite blocks)
+#ifdef VG_TU_SOLVER  // this kernel is launched by one translation unit only; the others see the header without it
 __global__ __launch_bounds__(256) void vg_schur_rows_kernel(SchurArgs a)
 {
     const int C = a.G + 1;
@@ -191,6 +192,7 @@ __global__ __launch_bounds__(256) void vg_schur_rows_kernel(SchurArgs a)
 #pragma unroll
     for (int k = 0; k < 6; k++) out[k * C] = f.active ? y[k] : 0.;
 }
+#endif
 
 // vg_schur_rows_kernel AND the Gram of the rows it produces, in one launch: a workgroup owns `poses_per_wg` whole poses per
 // batch (one lane per (pose, column), as above), keeps the batch's 6 x poses_per_wg rows in LDS next to writing them out, and
@@ -203,6 +205,7 @@ __global__ __launch_bounds__(256) void vg_schur_rows_kernel(SchurArgs a)
 constexpr int kSchurThreads = 256;      // lanes of one batch: (pose of the batch, column)
 constexpr int kSchurMaxBatches = 4;    // batches of a workgroup run side by side: blockDim.x = kSchurThreads * batches
 
+#ifdef VG_TU_SOLVER  // this kernel is launched by one translation unit only; the others see the header without it
 __global__ __launch_bounds__(kSchurThreads * kSchurMaxBatches) void vg_schur_rows_gram_kernel(SchurArgs a, int poses_per_wg, int batches,
                                                                             double *__restrict__ partials /* [n_wg][C*C + 1] */)
 {
@@ -286,11 +289,13 @@ __global__ __launch_bounds__(kSchurThreads * kSchurMaxBatches) void vg_schur_row
         P[c * C + r] = s;
     }
 }
+#endif
 
 // ceres::SoftLOneLoss(a) on one residual block = one image: rho(s) = 2 a^2 (sqrt(1 + s / a^2) - 1), s = r^T r.
 // rho'' < 0, so Ceres' Corrector only scales residuals and Jacobian rows by sqrt(rho'): the block's Gram matrix
 // becomes rho' * G, and its last entry (r^T r, twice the cost term) becomes rho(s).  One wave per block; the wave
 // reads s before any of its lanes writes.
+#ifdef VG_TU_SOLVER  // this kernel is launched by one translation unit only; the others see the header without it
 __global__ __launch_bounds__(64) void vg_gram_soft_l1_kernel(double *__restrict__ gram, int entries, double a2)
 {
     double *G = gram + (size_t)blockIdx.x * entries;
@@ -300,6 +305,7 @@ __global__ __launch_bounds__(64) void vg_gram_soft_l1_kernel(double *__restrict_
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     for (int e = threadIdx.x; e < entries; e += kWave) G[e] = e == entries - 1 ? rho : w * G[e];
 }
+#endif
 
 struct BacksubArgs {
     SchurArgs s;
@@ -445,6 +451,7 @@ __global__ __launch_bounds__(kBsThreads) void vg_backsub_kernel(BacksubArgs b)
 }
 
 // x_new = x + delta (pose parameters: unbounded)
+#ifdef VG_TU_SOLVER  // this kernel is launched by one translation unit only; the others see the header without it
 __global__ __launch_bounds__(256) void vg_apply_step_kernel(const double *__restrict__ x, const double *__restrict__ delta, long long n,
                                                              double *__restrict__ x_new)
 {
@@ -452,6 +459,7 @@ __global__ __launch_bounds__(256) void vg_apply_step_kernel(const double *__rest
     if (i >= n) return;
     x_new[i] = x[i] + delta[i];
 }
+#endif
 
 // Gram of a plain row-major matrix X [n_rows][C], one wave per group of `rows_per_group` rows (a multiple of 4),
 // 4 rows per MFMA in increasing order: out[group][C*C].  Groups are then added by the slab / final sum kernels.
@@ -485,6 +493,7 @@ __global__ __launch_bounds__(256) void vg_dense_gram_kernel(const double *__rest
 
 // The same Gram for wide matrices (C > 64, i.e. more than 63 global columns): one wave per (row group, tile pair),
 // blockIdx.y enumerates the upper-triangle tile pairs; every pair writes its own entries of out[group].
+#ifdef VG_TU_SOLVER  // this kernel is launched by one translation unit only; the others see the header without it
 __global__ __launch_bounds__(256) void vg_dense_gram_pair_kernel(const double *__restrict__ X, unsigned int n_rows, int C,
                                                                   unsigned int rows_per_group, unsigned int n_groups,
                                                                   double *__restrict__ out)
@@ -520,5 +529,6 @@ __global__ __launch_bounds__(256) void vg_dense_gram_pair_kernel(const double *_
         }
     }
 }
+#endif
 
 }  // namespace vg

@@ -139,6 +139,7 @@ __device__ __forceinline__ void lm_reduced_solve_body(const LmSolveArgs &a, doub
     }
 }
 
+#ifdef VG_TU_SOLVER  // this kernel is launched by one translation unit only; the others see the header without it
 __global__ __launch_bounds__(kLmThreads) void vg_lm_reduced_solve_kernel(LmSolveArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -146,6 +147,7 @@ __global__ __launch_bounds__(kLmThreads) void vg_lm_reduced_solve_kernel(LmSolve
     if (st->done || (a.gate_expect >= 0 && st->gate != a.gate_expect)) return;
     lm_reduced_solve_body(a, sm, threadIdx.x, blockDim.x, true);
 }
+#endif
 
 // Wide reduced systems (a rig: G = 45) in one workgroup of 256 threads, ENTRY-parallel: thread t owns the entries
 // e = t + 256 m of the lower triangle of the augmented matrix [[S, .], [rhs^T, .]] (row G of its factor is y = L^-1 rhs: the
@@ -170,6 +172,7 @@ __host__ __device__ inline size_t lm_entry_solve_lds_doubles(int G)
     return C * C + C * (C + 1) / 2 + 3 * (size_t)G + 2;
 }
 
+#ifdef VG_TU_SOLVER  // this kernel is launched by one translation unit only; the others see the header without it
 __global__ __launch_bounds__(kLmThreads) void vg_lm_reduced_solve_entries_kernel(LmSolveArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -258,6 +261,7 @@ __global__ __launch_bounds__(kLmThreads) void vg_lm_reduced_solve_entries_kernel
     if (tid < G) a.dg[tid] = x[tid];
     if (tid == 0) st->step_ok = (G == 0 || ok) ? 1 : 0;
 }
+#endif
 
 // Narrow reduced systems (a mono or stereo calibration: G <= kFoldMaxG): EVERY workgroup of the back-substitution solves
 // the G x G system itself (its first wave, in LDS, the arithmetic of vg_lm_reduced_solve_kernel: every workgroup gets the
@@ -304,6 +308,7 @@ struct LmAcceptArgs {
     double dmin, dmax, ftol, gtol, ptol, min_rel_decrease, max_radius, min_radius;
 };
 
+#ifdef VG_TU_SOLVER  // this kernel is launched by one translation unit only; the others see the header without it
 __global__ __launch_bounds__(kLmThreads) void vg_lm_accept_kernel(LmAcceptArgs a)
 {
     const int G = a.G, tid = threadIdx.x;
@@ -500,5 +505,6 @@ __global__ __launch_bounds__(kLmThreads) void vg_lm_accept_kernel(LmAcceptArgs a
     S.gate = S.done ? -1 : S.ucur;
     publish();
 }
+#endif
 
 }  // namespace vg

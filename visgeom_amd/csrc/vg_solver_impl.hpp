@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "vg_internal.hpp"
+#include "vg_gram_valu.hpp"
 #include "vg_solver.hpp"
 #include "vg_solver_device.hpp"
 #include "vg_transf_host.hpp"
@@ -1204,8 +1205,8 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
                 VG_HIP(hipGetLastError());
             }
             if (n_bs_groups && multi_rank) {  // part of the evaluation's packed all-reduce; one rank: the accept kernel sums them
-                hipLaunchKernelGGL(vg::vg_gram_final_sum_kernel, dim3(2), dim3(256), 0, st, (const double *)d_scal.p, n_bs_groups, 5,
-                                   d_scal_sum.p);
+                hipLaunchKernelGGL(vg::vg_step_scalars_kernel, dim3(2), dim3(256), 0, st, (const double *)d_scal.p, n_bs_groups, d_scal_sum.p,
+                                   (const unsigned long long *)nullptr, (unsigned long long *)nullptr);   // the same fixed-order sum of 5 entries
                 VG_HIP(hipGetLastError());
             }
             p->gram_gate = gate;
