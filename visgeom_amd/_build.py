@@ -55,12 +55,15 @@ def _closure(path, seen=None):
     return seen
 
 
+_EXTRA_FLAGS = []   # build_variant(): additional -D switches of an A/B library (tools/exp)
+
+
 def unit_digest(src):
     """sha256 over the compiler flags and the CONTENT of a translation unit and of every header it reaches (a snapshot copied
     to another machine has fresh mtimes everywhere: modification times say nothing about what an object was built from)"""
     import hashlib
 
-    h = hashlib.sha256(" ".join(HIPCC_FLAGS).encode())
+    h = hashlib.sha256(" ".join(HIPCC_FLAGS + _EXTRA_FLAGS).encode())
     for f in sorted(_closure(src)):
         h.update(os.path.basename(f).encode())
         with open(f, "rb") as fh:
@@ -86,10 +89,11 @@ def up_to_date():
         return fh.read().strip() == sources_digest()
 
 
-def _compile_unit(hipcc, src, verbose):
+def _compile_unit(hipcc, src, verbose, obj_dir=None):
     """one translation unit -> lib/obj/<name>.o, skipped when the object was built from the same content"""
     name = os.path.splitext(os.path.basename(src))[0]
-    obj, stamp = os.path.join(OBJ_DIR, name + ".o"), os.path.join(OBJ_DIR, name + ".sha256")
+    obj_dir = obj_dir or OBJ_DIR
+    obj, stamp = os.path.join(obj_dir, name + ".o"), os.path.join(obj_dir, name + ".sha256")
     digest = unit_digest(src)
     if os.path.exists(obj) and os.path.exists(stamp):
         with open(stamp) as fh:
@@ -98,7 +102,7 @@ def _compile_unit(hipcc, src, verbose):
     import time
 
     t0 = time.time()
-    cmd = [hipcc] + [f for f in HIPCC_FLAGS if f != "-shared"] + ["-I", os.path.join(ROOT, "include"), "-c", src, "-o", obj]
+    cmd = [hipcc] + [f for f in HIPCC_FLAGS + _EXTRA_FLAGS if f != "-shared"] + ["-I", os.path.join(ROOT, "include"), "-c", src, "-o", obj]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
@@ -137,6 +141,28 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def build_variant(name, extra_flags, verbose=False):
+    """An A/B library for tools/exp probes: the same sources with additional -D switches -> lib/variants/libvisgeom_amd_<name>.so
+    (objects under lib/obj_<name>/; git-ignored like the product library, and like it carried to the GPU box by gpurun)."""
+    global _EXTRA_FLAGS
+    from concurrent.futures import ThreadPoolExecutor
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    obj_dir = os.path.join(LIB_DIR, "obj_" + name)
+    out = os.path.join(LIB_DIR, "variants", "libvisgeom_amd_%s.so" % name)
+    os.makedirs(obj_dir, exist_ok=True)
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    _EXTRA_FLAGS = list(extra_flags)
+    try:
+        srcs = sources()
+        with ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 1)) as ex:
+            done = list(ex.map(lambda s: _compile_unit(hipcc, s, verbose, obj_dir), srcs))
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + [o for o, _ in done])
+    finally:
+        _EXTRA_FLAGS = []
+    return out
+
+
 BIN_DIR = os.path.join(PKG, "bin")
 CLI = os.path.join(BIN_DIR, "calib")
 
@@ -153,4 +179,8 @@ def build_cli(verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--variant" in sys.argv:   # python -m visgeom_amd._build --variant NAME -DFLAG [-DFLAG ...]
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], sys.argv[i + 2:], verbose=True))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

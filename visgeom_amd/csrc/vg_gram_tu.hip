@@ -29,6 +29,9 @@ void fill_gram_args(const vg_problem *p, const Dataset &d, vg::GramArgs &a, doub
     a.obs = d.d_obs;
     a.intr = d_params + cam.offset;
     a.res = nullptr;
+#ifdef VG_GRAM_STAMPS
+    a.res = reinterpret_cast<double *>(vgi::debug_hook(vgi::kHookGramStamps));   // measurement build: the clock stamps' buffer
+#endif
     a.jac_intr = nullptr;
     for (int l = 0; l < vg::kMaxChain; l++) a.jac_member[l] = nullptr;
     a.gram = gram;

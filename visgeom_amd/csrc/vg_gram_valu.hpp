@@ -23,6 +23,23 @@
 
 #include "vg_gram.hpp"
 
+// Measurement build only (-DVG_GRAM_STAMPS, tools/exp/gram_stamps_probe.py): lane 0 of every wave stores the shader clock at
+// eight points of its life into the buffer the "gram_stamps" debug hook names (it travels in GramArgs::res, which the Gram
+// kernels do not use otherwise).  The product build compiles none of this.
+#ifdef VG_GRAM_STAMPS
+#define VG_STAMP(slot, i)                                                                    \
+    do {                                                                                     \
+        if (slot) {                                                                          \
+            const unsigned long long t_ = __builtin_readcyclecounter();                      \
+            if ((threadIdx.x & 63) == 0) (slot)[i] = t_;                                     \
+        }                                                                                    \
+    } while (0)
+#else
+#define VG_STAMP(slot, i) \
+    do {                  \
+    } while (0)
+#endif
+
 namespace vg {
 
 constexpr int kValuThreads = 256;
@@ -208,7 +225,7 @@ struct ValuChunkIn {
 // lanes in one depth-first pass; the lane's share of the image's Gram sum is added to out[].
 template <int MODEL, int L, int CC, int kOut>
 __device__ __forceinline__ void valu_chunk(const double *__restrict__ intr, const double *fr, const ValuChunkIn<CC> &in,
-                                           int sl, double (&out)[kOut])
+                                           int sl, double (&out)[kOut], unsigned long long *stamps = nullptr)
 {
     using Rows = ValuRows<MODEL, L, CC>;
     constexpr int K = Rows::K, W = Rows::W;
@@ -261,10 +278,12 @@ __device__ __forceinline__ void valu_chunk(const double *__restrict__ intr, cons
             }
     }
     // ---- phase 2: products and the sum over the 32 lanes of the image in one depth-first pass
+    VG_STAMP(stamps, 3);
     double t[kOut];
     valu_tree_all(R, t, std::make_integer_sequence<int, kOut>{});
 #pragma unroll
     for (int k = 0; k < kOut; k++) out[k] += t[k];
+    VG_STAMP(stamps, 4);
 }
 
 // CH = corners per lane in a full chunk (32 CH corners of the image): 3 covers an 8 x 12 board in one chunk for the 13-wide
@@ -293,6 +312,12 @@ __device__ __forceinline__ void gram_valu_body(const GramValuArgs &a, const unsi
     const unsigned int b0 = block * kValuImagesPerBlock;
     const unsigned int b = b0 + (unsigned)(tid / kValuLanesPerImage);
     const bool bvalid = b < a.g.n_blocks;
+#ifdef VG_GRAM_STAMPS
+    unsigned long long *stamps = a.g.res ? reinterpret_cast<unsigned long long *>(const_cast<double *>(a.g.res)) + ((size_t)block * (kValuThreads / kWave) + wave) * 8 : nullptr;
+#else
+    unsigned long long *stamps = nullptr;
+#endif
+    VG_STAMP(stamps, 0);
 
     // the first chunk's board points and observations are requested BEFORE the chain walk, so their HBM latency
     // overlaps it (a wave has one full chunk per image on an 8 x 12 board: nothing else could hide that latency)
@@ -307,6 +332,7 @@ __device__ __forceinline__ void gram_valu_body(const GramValuArgs &a, const unsi
     // waves of a workgroup drift apart and cover each other's latencies (with one walker per workgroup three waves
     // sat at the barrier for the whole dependent chain: 42 % of all wave cycles were waits)
     double *fr_mine = fr_lds + (tid / kValuLanesPerImage) * FS;
+    VG_STAMP(stamps, 1);
     if (INLINE) {
         if (sl == 0 && bvalid) {
             const long long si = a.seq_index ? (long long)a.seq_index[b] : (long long)b;
@@ -318,6 +344,7 @@ __device__ __forceinline__ void gram_valu_body(const GramValuArgs &a, const unsi
     }
     wave_lds_fence();
     const double *fr = fr_mine;
+    VG_STAMP(stamps, 2);
 
     double out[kOut];
 #pragma unroll
@@ -325,7 +352,7 @@ __device__ __forceinline__ void gram_valu_body(const GramValuArgs &a, const unsi
 
     unsigned int c0 = 0;
     for (unsigned int m = 0; m < n_full; m++) {
-        valu_chunk<MODEL, L, CH, kOut>(a.g.intr, fr, in_full, sl, out);
+        valu_chunk<MODEL, L, CH, kOut>(a.g.intr, fr, in_full, sl, out, stamps);
         c0 += kFull;
         if (m + 1 < n_full) in_full.load(a.g, b, b0, bvalid, sl, c0);
     }
@@ -376,8 +403,10 @@ __device__ __forceinline__ void gram_valu_body(const GramValuArgs &a, const unsi
             if (have && lane < kValuLanesPerImage) red[wave * E + e] = tot;
         }
     }
+    VG_STAMP(stamps, 5);
     if (a.partials) {
         __syncthreads();
+        VG_STAMP(stamps, 6);
         for (int e = tid; e < E; e += kValuThreads) {  // E = 276 for the 23-wide block: more entries than threads
             double s = red[e];
 #pragma unroll
@@ -385,6 +414,7 @@ __device__ __forceinline__ void gram_valu_body(const GramValuArgs &a, const unsi
             a.partials[(size_t)e * a.n_wg + block] = s;
         }
     }
+    VG_STAMP(stamps, 7);
 }
 
 template <int MODEL, int L, bool INLINE, int CH>

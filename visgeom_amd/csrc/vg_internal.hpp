@@ -31,6 +31,7 @@ enum DebugHook {
     kHookSolverDeviceLoop,         // force the device-resident LM loop
     kHookSolverNoSpeculation,      // queue one LM iteration at a time
     kHookEmitEqualTiles,           // merged emit launch: contiguous XCD pieces of 1 = equal tile counts, 2 = equal bytes (default: an eighth of every dataset, widest rows first; 4: in problem order)
+    kHookGramStamps,               // measurement build (-DVG_GRAM_STAMPS) only: device address of the per-wave clock stamps of the Gram kernel
     kHookCount
 };
 #ifdef VG_DEBUG_HOOKS
