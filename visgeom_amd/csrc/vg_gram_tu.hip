@@ -105,7 +105,11 @@ int launch_gram_valu_l(hipStream_t stream, const vg::GramValuArgs &a, bool inlin
 {
     const bool force_ch1 = vgi::debug_hook(vgi::kHookGramCh1) != 0;  // measurement hook
     constexpr int W = vg::CameraTraits<MODEL>::K + 6 * L + 1;
+#ifdef VG_GRAM_CH2
+    constexpr int kMain = W <= 19 ? 2 : 1;   // tools/exp A/B build: two corners per lane, three waves per SIMD on the 13-wide blocks
+#else
     constexpr int kMain = W <= 13 ? 3 : (W <= 19 ? 2 : 1);
+#endif
     if constexpr (kMain > 1)
         if (!force_ch1 && a.g.N > (unsigned)vg::kValuLanesPerImage) return launch_gram_valu_lch<MODEL, L, kMain>(stream, a, inline_chain);
     return launch_gram_valu_lch<MODEL, L, 1>(stream, a, inline_chain);

@@ -42,7 +42,10 @@
 
 namespace vg {
 
-constexpr int kValuThreads = 256;
+#ifndef VG_VALU_THREADS
+#define VG_VALU_THREADS 256   // tools/exp A/B builds set 128 (two waves per workgroup)
+#endif
+constexpr int kValuThreads = VG_VALU_THREADS;
 constexpr int kValuLanesPerImage = 32;
 constexpr int kValuImagesPerBlock = kValuThreads / kValuLanesPerImage;
 constexpr int kValuMaxW = 17;  // direct form: Mei with one member
@@ -143,6 +146,40 @@ struct TriTable {
 };
 template <int W>
 __device__ constexpr TriTable<W> kTriTable{};
+
+// What lane sl of an image's 32 holds after the five halving steps, packed into one 64-bit word per lane so that the kernel
+// fetches it with ONE load at its very start (the latency disappears behind the chain walk) instead of deriving it -- or
+// looking (row, column) up in memory -- between the last exchange and the first store:
+//   bits 18 k .. 18 k + 8   r W + c of the lane's k-th entry (k = 0, 1, 2), bits 18 k + 9 .. 18 k + 17  c W + r,
+//   bits 54 .. 61  index of its first entry in the row-major upper triangle,  bits 62 .. 63  how many entries it holds.
+template <int W>
+struct LaneOutTable {
+    unsigned long long v[32];
+    constexpr LaneOutTable() : v()
+    {
+        constexpr int E = W * (W + 1) / 2;
+        for (int sl = 0; sl < 32; sl++) {
+            int base = 0, real = E, n = E;
+            for (int s = 0; s < 5; s++) {
+                const int H = (n + 1) / 2;
+                const bool bit = (sl >> (4 - s)) & 1;
+                base += bit ? H : 0;
+                real = bit ? (real - H > 0 ? real - H : 0) : (real < H ? real : H);
+                n = H;
+            }
+            unsigned long long w = ((unsigned long long)base << 54) | ((unsigned long long)(real > 3 ? 3 : real) << 62);
+            for (int k = 0; k < 3; k++) {
+                const int e = base + k < E ? base + k : 0;
+                const unsigned long long r = (unsigned long long)tri_row<W>(e), c = (unsigned long long)tri_col<W>(e);
+                w |= (r * W + c) << (18 * k);
+                w |= (c * W + r) << (18 * k + 9);
+            }
+            v[sl] = w;
+        }
+    }
+};
+template <int W>
+__device__ constexpr LaneOutTable<W> kLaneOutTable{};
 
 // The rows of the CH corners a lane owns in one chunk, and the lane's side of every halving step.
 template <int MODEL, int L, int CH>
@@ -313,14 +350,31 @@ __device__ __forceinline__ void gram_valu_body(const GramValuArgs &a, const unsi
     const unsigned int b = b0 + (unsigned)(tid / kValuLanesPerImage);
     const bool bvalid = b < a.g.n_blocks;
 #ifdef VG_GRAM_STAMPS
-    unsigned long long *stamps = a.g.res ? reinterpret_cast<unsigned long long *>(const_cast<double *>(a.g.res)) + ((size_t)block * (kValuThreads / kWave) + wave) * 8 : nullptr;
+    unsigned long long *stamps = a.g.res ? reinterpret_cast<unsigned long long *>(const_cast<double *>(a.g.res)) + ((size_t)block * (kValuThreads / kWave) + wave) * 10 : nullptr;
 #else
     unsigned long long *stamps = nullptr;
 #endif
     VG_STAMP(stamps, 0);
+#ifdef VG_GRAM_STAMPS
+    if (stamps && (threadIdx.x & 63) == 0) stamps[8] = wall_clock64();   // 100 MHz, common to all XCDs: the launch's timeline
+#endif
 
-    // the first chunk's board points and observations are requested BEFORE the chain walk, so their HBM latency
-    // overlaps it (a wave has one full chunk per image on an 8 x 12 board: nothing else could hide that latency)
+    // The member's six parameters are the head of the wave's longest dependent chain (load -> rsqrt -> sincos -> frame ->
+    // every corner): requested FIRST, so that waiting for them does not wait for the twelve loads behind them (vmcnt counts
+    // in order).  Then the first chunk's board points and observations, whose latency the chain walk covers.
+    double xi_reg[6] = {0., 0., 0., 0., 0., 0.};
+    if (INLINE) {
+        if (sl == 0 && bvalid) {
+            const long long si = a.seq_index ? (long long)a.seq_index[b] : (long long)b;
+            const double *xp = a.chain_params + a.chain_stride * si;
+#pragma unroll
+            for (int k = 0; k < 6; k++) xi_reg[k] = xp[k];
+        }
+    }
+    // up to three entries per lane (blocks up to 13 wide): where they go comes packed in one word, fetched now, used at the end
+    constexpr bool kPackedOut = kOut <= 3 && W * W < 512;
+    unsigned long long lane_out = 0ull;
+    if constexpr (kPackedOut) lane_out = kLaneOutTable<W>.v[sl];
     constexpr unsigned int kFull = kValuLanesPerImage * CH;
     const unsigned int n_full = a.g.N / kFull;
     ValuChunkIn<CH> in_full;
@@ -334,10 +388,7 @@ __device__ __forceinline__ void gram_valu_body(const GramValuArgs &a, const unsi
     double *fr_mine = fr_lds + (tid / kValuLanesPerImage) * FS;
     VG_STAMP(stamps, 1);
     if (INLINE) {
-        if (sl == 0 && bvalid) {
-            const long long si = a.seq_index ? (long long)a.seq_index[b] : (long long)b;
-            build_frame_single_direct_fast(a.chain_params + a.chain_stride * si, fr_mine);
-        }
+        if (sl == 0 && bvalid) build_frame_single_direct_fast(xi_reg, fr_mine);
     } else if (bvalid) {
         const double *src = a.g.frames + (size_t)b * FS;
         for (int i = sl; i < FS; i += kValuLanesPerImage) fr_mine[i] = src[i];
@@ -375,9 +426,12 @@ __device__ __forceinline__ void gram_valu_body(const GramValuArgs &a, const unsi
         }
     }
 
-    // which entries this lane ended up with: [base, base + real)
+    // which entries this lane ended up with: [base, base + real), and where they go
     int base = 0, real = E;
-    {
+    if constexpr (kPackedOut) {
+        base = (int)((lane_out >> 54) & 0xff);
+        real = (int)(lane_out >> 62);
+    } else {
         int n = E;
 #pragma unroll
         for (int s = 0; s < 5; s++) {
@@ -391,20 +445,30 @@ __device__ __forceinline__ void gram_valu_body(const GramValuArgs &a, const unsi
     double *G = a.g.gram + (size_t)(bvalid ? b : 0) * (W * W);
 #pragma unroll
     for (int k = 0; k < kOut; k++) {
-        const int e = base + k;
         const bool have = k < real;
-        const int r = kTriTable<W>.r[have ? e : 0], cc = kTriTable<W>.c[have ? e : 0];
+        unsigned int o_rc, o_cr;
+        if constexpr (kPackedOut) {
+            o_rc = (unsigned)(lane_out >> (18 * k)) & 0x1ff;
+            o_cr = (unsigned)(lane_out >> (18 * k + 9)) & 0x1ff;
+        } else {
+            const int e = have ? base + k : 0;
+            const int r = kTriTable<W>.r[e], cc = kTriTable<W>.c[e];
+            o_rc = r * W + cc;
+            o_cr = cc * W + r;
+        }
         if (have && bvalid) {
-            G[r * W + cc] = out[k];
-            G[cc * W + r] = out[k];
+            G[o_rc] = out[k];
+            G[o_cr] = out[k];
         }
         if (a.partials) {  // both images of the wave: the other half-wave holds the same entry of its image
             const double tot = out[k] + __shfl_xor(out[k], 32, kWave);
-            if (have && lane < kValuLanesPerImage) red[wave * E + e] = tot;
+            if (have && lane < kValuLanesPerImage) red[wave * E + base + k] = tot;
         }
     }
     VG_STAMP(stamps, 5);
     if (a.partials) {
+        // the one barrier of the kernel, at its very end: the waves that arrive have nothing left to do (a barrier at the head
+        // -- needed by a "last wave adds" ticket -- delays every wave's first load instead: measured +480 cycles per wave)
         __syncthreads();
         VG_STAMP(stamps, 6);
         for (int e = tid; e < E; e += kValuThreads) {  // E = 276 for the 23-wide block: more entries than threads
@@ -415,10 +479,25 @@ __device__ __forceinline__ void gram_valu_body(const GramValuArgs &a, const unsi
         }
     }
     VG_STAMP(stamps, 7);
+#ifdef VG_GRAM_STAMPS
+    if (stamps && (threadIdx.x & 63) == 0) stamps[9] = wall_clock64();
+#endif
+}
+
+// waves per SIMD the register budget is cut for: two (256 registers); the tools/exp build -DVG_GRAM_CH2 asks for three with two
+// corners per lane on the 13-wide blocks (A/B of occupancy against the second reduction tree per image)
+template <int MODEL, int L, int CH>
+__host__ __device__ constexpr int valu_min_waves()
+{
+#ifdef VG_GRAM_CH2
+    return (CameraTraits<MODEL>::K + 6 * L + 1 <= 13 && CH <= 2) ? 3 : 2;
+#else
+    return 2;
+#endif
 }
 
 template <int MODEL, int L, bool INLINE, int CH>
-__global__ __launch_bounds__(kValuThreads, 2) void vg_gram_valu_kernel(GramValuArgs a)
+__global__ __launch_bounds__(kValuThreads, (valu_min_waves<MODEL, L, CH>())) void vg_gram_valu_kernel(GramValuArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double valu_lds[];
     gram_valu_body<MODEL, L, INLINE, CH>(a, blockIdx.x, valu_lds);
