@@ -23,6 +23,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+from visgeom_amd import _build  # noqa: E402
+
+if os.environ.get("AB_LIB"):   # same-box A/B against a variant library (python -m visgeom_amd._build --variant NAME ...)
+    _build.LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.environ["AB_LIB"])
 from visgeom_amd import localization as loc  # noqa: E402
 
 REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 200
