@@ -263,3 +263,82 @@ def test_merged_gram_launch_with_datasets_it_cannot_take(vg):
     s = p.solve(max_num_iterations=100)
     assert s["termination"].startswith("CONVERGENCE") and s["final_cost"] < s["initial_cost"]
     p.close()
+
+
+@pytest.mark.parametrize("n_ds", [9, 13])
+def test_more_datasets_than_one_merged_launch_takes(vg, n_ds):
+    """The merged launches carry their datasets by value in the kernel arguments: 8 per emit launch (kEmitMultiMax), 6 per Gram
+    launch (kGramMultiMax), 8 per partial-sum launch (kPartialSumMax).  A problem with 9 / 13 datasets (the rig's four cameras,
+    several datasets each) is cut into 8 + 1 / 8 + 5 emit launches, 6 + 3 / 6 + 6 + a lone leftover Gram launches, 8 + 1 / 8 + 5
+    sum launches -- and must give the bits of one launch per dataset (no fixed ceiling on the number of
+    cameras of a rig)."""
+    import torch
+
+    from visgeom_amd import synthetic as S
+
+    n = 19
+    r = S.make_rig(n, sigma=0.1)
+    rng = np.random.default_rng(3)
+    p = vg.CalibrationProblem(0)
+    cams = [p.add_camera(m, r["init_intrinsics"][k]) for k, m in enumerate(r["models"])]
+    x1k = [p.add_transform(True, r["init_xi1k"][k]) for k in range(3)]
+    seq = p.add_transform(False, r["init_poses"])
+    dss, which = [], []
+    for j in range(n_ds):
+        k = j % 4
+        chain = [(seq, 0)] if k == 0 else [(x1k[k - 1], 1), (seq, 0)]
+        dss.append(p.add_dataset(cams[k], chain, r["board"], r["corners"][k] + 0.05 * rng.standard_normal(r["corners"][k].shape)))
+        which.append(k)
+    p.finalize()
+    ref = [p.alloc_outputs(ds) for ds in dss]
+    got = [p.alloc_outputs(ds) for ds in dss]
+    for o in got:
+        o[0].fill_(float("nan"))
+        o[1].fill_(float("nan"))
+        for m in o[2]:
+            m.fill_(float("nan"))
+    p.prepare()
+    for ds, o in zip(dss, ref):
+        p.evaluate_dataset(ds, o[0], o[1], o[2])
+    p.prepare()
+    p.evaluate_all(got)
+    p.synchronize()
+    for j, (a, b) in enumerate(zip(ref, got)):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), "dataset %d" % j
+        assert all(torch.equal(x, y) for x, y in zip(a[2], b[2])), "dataset %d" % j
+    j = n_ds - 1   # the last dataset: the one-dataset tail launch of the 9-dataset problem
+    gram_ref = [p.alloc_gram(ds) for ds in dss]
+    gram_got = [(torch.full_like(g, float("nan")), torch.full_like(t, float("nan"))) for g, t in gram_ref]
+    p.prepare()
+    for ds, (g, t) in zip(dss, gram_ref):
+        p.gram_fused_sum(ds, g, t)
+    p.prepare()
+    p.gram_fused_sum_all([g for g, _ in gram_got], [t for _, t in gram_got])
+    p.synchronize()
+    for j2 in range(n_ds):
+        assert torch.equal(gram_ref[j2][0], gram_got[j2][0]) and torch.equal(gram_ref[j2][1], gram_got[j2][1]), "Gram of dataset %d" % j2
+    # the Gram blocks of the last dataset are those of its emitted rows (long-double Gram of the HIP rows: 1e-10)
+    res, ji = got[j][0].cpu().numpy(), got[j][1].cpu().numpy()
+    jm = [m.cpu().numpy() for m in got[j][2]]
+    for b in (0, n - 1):
+        J = np.concatenate([ji[b]] + [m[b] for m in jm] + [res[b][:, None]], axis=1).astype(np.longdouble)
+        G = (J.T @ J).astype(np.float64)
+        Gg = gram_got[j][0][b].cpu().numpy()
+        assert np.max(np.abs(Gg - G)) <= 1e-10 * np.max(np.abs(G)), "Gram block %d of the last dataset" % b
+    # the LM solve over all of them: merged launches against one launch per dataset (hook), same optimum
+    from visgeom_amd import capi
+
+    x0 = p.get_parameters()
+    s1 = p.solve(max_num_iterations=60)
+    x1 = p.get_parameters()
+    p.set_parameters(x0)
+    capi.debug_set("gram_no_merge", 1)
+    try:
+        s2 = p.solve(max_num_iterations=60)
+    finally:
+        capi.debug_set("gram_no_merge", 0)
+    x2 = p.get_parameters()
+    assert s1["final_cost"] < 0.05 * s1["initial_cost"]
+    assert abs(s1["final_cost"] - s2["final_cost"]) <= 1e-9 * s2["final_cost"]
+    assert np.max(np.abs(x1 - x2) / np.maximum(np.abs(x2), 1.0)) < 1e-6
+    p.close()
