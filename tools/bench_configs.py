@@ -20,6 +20,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+from visgeom_amd import _build as _b  # noqa: E402
+
+if os.environ.get("AB_LIB"):   # same-box A/B against a variant library (python -m visgeom_amd._build --variant NAME ...)
+    _b.LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.environ["AB_LIB"])
 from visgeom_amd import capi as _capi  # noqa: E402
 
 _capi.hooks_from_env()  # legacy VG_* switches -> vg_debug_set
