@@ -34,4 +34,6 @@ find "$P" -type f | head -40
 f=$(find "$P/trace" -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && head -8 "$f"
 k=$(find "$P/trace" -name '*kernel_trace.csv' | head -1)
 [ -n "$k" ] && python "$R/tools/kernel_context.py" "$k" "gram_valu_kernel<0, 1, true, 3>" > "$R/gpurun_out/gram_kernel_by_context_$TAG.txt" 2>&1
+# means per (pass, kernel, counter), computed HERE: whatever the size filter below removes, the summary can still be made
+python "$R/tools/pmc_aggregate.py" "$P" "$R/gpurun_out/pmc_traffic_$TAG.csv"
 find "$P" -name '*.csv' -size +8M -delete

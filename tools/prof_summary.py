@@ -27,7 +27,12 @@ CAL_BYTES = 64 * 1024 * 1024 * 8  # bench.py streams 2^26 doubles
 def counters(sub):
     agg = collections.defaultdict(list)
     f = os.path.join(P, sub, "t_counter_collection.csv")
-    if not os.path.exists(f):
+    if not os.path.exists(f):   # the per-dispatch file did not travel: the means aggregated on the box (tools/pmc_aggregate.py)
+        a = os.path.join(ROOT, "gpurun_out", "pmc_traffic_%s.csv" % tag)
+        if os.path.exists(a):
+            for r in csv.DictReader(open(a)):
+                if r["run"] == sub:
+                    agg[(r["kernel"], r["counter"])].append(float(r["mean"]))
         return agg
     for r in csv.DictReader(open(f)):
         agg[(r["Kernel_Name"], r["Counter_Name"])].append(float(r["Counter_Value"]))
