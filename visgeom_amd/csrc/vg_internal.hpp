@@ -31,6 +31,7 @@ enum DebugHook {
     kHookSolverDeviceLoop,         // force the device-resident LM loop
     kHookSolverNoSpeculation,      // queue one LM iteration at a time
     kHookEmitEqualTiles,           // merged emit launch: contiguous XCD pieces of 1 = equal tile counts, 2 = equal bytes (default: an eighth of every dataset, widest rows first; 4: in problem order)
+    kHookSchurPrivateGather,       // Schur rows kernel: every lane of a pose gathers V_i / g_i itself (the route before round 4), for A/B
     kHookGramStamps,               // measurement build (-DVG_GRAM_STAMPS) only: device address of the per-wave clock stamps of the Gram kernel
     kHookCount
 };

@@ -85,25 +85,10 @@ struct PoseFactor {
     unsigned char mode;
 };
 
-__device__ __forceinline__ void pose_factor(const SchurArgs &a, int i, PoseFactor &f)
+// damping + 6 x 6 Cholesky of a pose block whose V_i (packed lower, 21) and g_i (6) have been gathered; has_refs: the pose
+// is referenced by at least one residual block
+__device__ __forceinline__ void pose_factor_from(const SchurArgs &a, int i, double (&V)[21], bool has_refs, PoseFactor &f)
 {
-    const int r0 = a.ref_ptr[i], r1 = a.ref_ptr[i + 1];
-    double V[21];
-#pragma unroll
-    for (int k = 0; k < 21; k++) V[k] = 0.;
-#pragma unroll
-    for (int k = 0; k < 6; k++) f.gp[k] = 0.;
-    for (int q = r0; q < r1; q++) {
-        const SolveDatasetDev D = a.ds[a.ref_ds[q]];
-        const double *Gb = D.gram + (size_t)a.ref_blk[q] * D.W * D.W;
-        const int o = D.pose_off;
-#pragma unroll
-        for (int r = 0; r < 6; r++) {
-#pragma unroll
-            for (int c = 0; c <= r; c++) V[tri(r, c)] += Gb[(o + r) * D.W + o + c];
-            f.gp[r] += Gb[(o + r) * D.W + D.W - 1];
-        }
-    }
     // pose_frozen: 0 = eliminated here, 1 = constant, 2 = belongs to a sequence coupled by OdometryPrior blocks:
     // its raw V_i / g_i go to the record and the host eliminates the whole sequence as a block-tridiagonal system
     f.mode = a.pose_frozen[i];
@@ -116,7 +101,7 @@ __device__ __forceinline__ void pose_factor(const SchurArgs &a, int i, PoseFacto
         f.active = false;
         return;
     }
-    f.active = f.mode == 0 && r1 > r0;
+    f.active = f.mode == 0 && has_refs;
     const double mu = a.mu_dev ? *a.mu_dev : a.mu;
 #pragma unroll
     for (int r = 0; r < 6; r++) {
@@ -140,6 +125,28 @@ __device__ __forceinline__ void pose_factor(const SchurArgs &a, int i, PoseFacto
         }
     }
     if (f.active && !f.pd) f.active = false;
+}
+
+__device__ __forceinline__ void pose_factor(const SchurArgs &a, int i, PoseFactor &f)
+{
+    const int r0 = a.ref_ptr[i], r1 = a.ref_ptr[i + 1];
+    double V[21];
+#pragma unroll
+    for (int k = 0; k < 21; k++) V[k] = 0.;
+#pragma unroll
+    for (int k = 0; k < 6; k++) f.gp[k] = 0.;
+    for (int q = r0; q < r1; q++) {
+        const SolveDatasetDev D = a.ds[a.ref_ds[q]];
+        const double *Gb = D.gram + (size_t)a.ref_blk[q] * D.W * D.W;
+        const int o = D.pose_off;
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+#pragma unroll
+            for (int c = 0; c <= r; c++) V[tri(r, c)] += Gb[(o + r) * D.W + o + c];
+            f.gp[r] += Gb[(o + r) * D.W + D.W - 1];
+        }
+    }
+    pose_factor_from(a, i, V, r1 > r0, f);
 }
 
 // one lane per (pose, global column): column gcol of the six rows  L^-1 W_i^T  (gcol == G: L^-1 g_i; that lane also
@@ -204,10 +211,12 @@ __global__ __launch_bounds__(256) void vg_schur_rows_kernel(SchurArgs a)
 // rewritten by the host before the Gram.
 constexpr int kSchurThreads = 256;      // lanes of one batch: (pose of the batch, column)
 constexpr int kSchurMaxBatches = 4;    // batches of a workgroup run side by side: blockDim.x = kSchurThreads * batches
+constexpr int kSchurMaxRefs = 256;     // references of a workgroup's poses resolved into LDS (beyond: read per lane from memory)
 
 #ifdef VG_TU_SOLVER  // this kernel is launched by one translation unit only; the others see the header without it
 __global__ __launch_bounds__(kSchurThreads * kSchurMaxBatches) void vg_schur_rows_gram_kernel(SchurArgs a, int poses_per_wg, int batches,
-                                                                            double *__restrict__ partials /* [n_wg][C*C + 1] */)
+                                                                            double *__restrict__ partials /* [n_wg][C*C + 1] */,
+                                                                            int shared_gather)
 {
     extern __shared__ __attribute__((aligned(16))) double sm_rows[];  // [batches * poses_per_wg * 6][C + 1] (odd-ish stride)
     const int C = a.G + 1, CS = C + 1, tid = threadIdx.x % kSchurThreads;
@@ -222,29 +231,122 @@ __global__ __launch_bounds__(kSchurThreads * kSchurMaxBatches) void vg_schur_row
     __syncthreads();
     const int pl = tid / C, gcol = tid - pl * C;        // pose of the batch, column
     const bool lane_on = pl < poses_per_wg;
-    // every batch has its own 256 lanes: the chains pose -> reference list -> Gram blocks -> factorisation of the batches
-    // overlap instead of following one another (four in a row were 13 us of a wave's life, 73 % of it waiting)
-    for (int bt = threadIdx.x / kSchurThreads; bt < batches; bt += blockDim.x / kSchurThreads) {
-        const int i = (blockIdx.x * batches + bt) * poses_per_wg + pl;
-        double y[6] = {0., 0., 0., 0., 0., 0.};
-        if (lane_on && i < a.n_poses) {
-            PoseFactor f;
-            pose_factor(a, i, f);
-            double w[6];
-            if (gcol < a.G) {
+    // every batch has its own 256 lanes (blockDim.x = kSchurThreads * batches): the chains pose -> reference list -> Gram
+    // blocks -> factorisation of the batches overlap instead of following one another (four in a row were 13 us of a wave's
+    // life, 73 % of it waiting)
+    const int bt = threadIdx.x / kSchurThreads;
+    const int i = (blockIdx.x * batches + bt) * poses_per_wg + pl;
+    const bool pose_on = lane_on && bt < batches && i < a.n_poses;
+    // ---- the references of the workgroup's poses (a contiguous run of the CSR lists: the poses are consecutive), resolved ONCE
+    // per workgroup into LDS: [block address | W | pose column | dataset].  Every gather below then reads addresses from LDS
+    // and its global loads no longer hang off a chain pose -> reference -> dataset descriptor -> block, repeated per reference
+    // and per lane (the rig: four references per pose, ~12 dependent round trips per lane).
+    double *sm_V = sm_rows + (size_t)batches * poses_per_wg * 6 * CS;   // [batches * poses_per_wg][28]: V (21) | g (6) | has refs
+    struct RefMeta {
+        const double *Gb;
+        int W, o, d, pad;
+    };
+    RefMeta *sm_ref = reinterpret_cast<RefMeta *>(sm_V + (size_t)batches * poses_per_wg * 28);   // [kSchurMaxRefs]
+    const int i_first = blockIdx.x * batches * poses_per_wg;
+    int i_end = i_first + batches * poses_per_wg;
+    i_end = i_end < a.n_poses ? i_end : a.n_poses;
+    const int q_first = a.ref_ptr[i_first < a.n_poses ? i_first : a.n_poses], q_end = a.ref_ptr[i_end > i_first ? i_end : i_first];
+    const bool meta_lds = shared_gather && q_end - q_first <= kSchurMaxRefs;
+    if (meta_lds) {
+        for (int t = threadIdx.x; t < q_end - q_first; t += blockDim.x) {
+            const int d = a.ref_ds[q_first + t];
+            const SolveDatasetDev D = a.ds[d];
+            RefMeta m;
+            m.Gb = D.gram + (size_t)a.ref_blk[q_first + t] * D.W * D.W;
+            m.W = D.W;
+            m.o = D.pose_off;
+            m.d = d;
+            m.pad = 0;
+            sm_ref[t] = m;
+        }
+        __syncthreads();
+    }
+    int r0 = 0, r1 = 0;
+    if (pose_on) {
+        r0 = a.ref_ptr[i];
+        r1 = a.ref_ptr[i + 1];
+    }
+    auto ref_of = [&](int q, const double *&Gb, int &W, int &o, int &d) {
+        if (meta_lds) {
+            const RefMeta m = sm_ref[q - q_first];
+            Gb = m.Gb;
+            W = m.W;
+            o = m.o;
+            d = m.d;
+        } else {
+            d = a.ref_ds[q];
+            const SolveDatasetDev D = a.ds[d];
+            Gb = D.gram + (size_t)a.ref_blk[q] * D.W * D.W;
+            W = D.W;
+            o = D.pose_off;
+        }
+    };
+    // ---- this lane's column of W_i^T (six values per reference), requested BEFORE the pose's V_i / g_i are shared: the
+    // two gathers are independent and their loads are in flight together
+    double w[6] = {0., 0., 0., 0., 0., 0.};
+    if (pose_on && gcol < a.G) {
+        for (int q = r0; q < r1; q++) {
+            const double *Gb;
+            int W, o, d;
+            ref_of(q, Gb, W, o, d);
+            const int lc = a.inv[d * a.G + gcol];
+            if (lc < 0) continue;
 #pragma unroll
-                for (int c = 0; c < 6; c++) w[c] = 0.;
-                const int r0 = a.ref_ptr[i], r1 = a.ref_ptr[i + 1];
-                for (int q = r0; q < r1; q++) {
-                    const int d = a.ref_ds[q];
-                    const int lc = a.inv[d * a.G + gcol];
-                    if (lc < 0) continue;
-                    const SolveDatasetDev D = a.ds[d];
-                    const double *Gb = D.gram + (size_t)a.ref_blk[q] * D.W * D.W;
+            for (int c = 0; c < 6; c++) w[c] += Gb[lc * W + o + c];
+        }
+    }
+    // ---- V_i and g_i of the pose, gathered ONCE per pose: lane e of the pose's C lanes adds entry e (of 27: the packed lower
+    // triangle, then g) over the pose's references in order and parks it in LDS; every lane then reads the 27 values back.
+    // (Each of the C lanes used to walk the whole gather itself -- 27 loads per reference and lane.)  Same order of additions:
+    // same bits.
+    if (shared_gather) {
+        if (pose_on) {
+            double *Vs = sm_V + (size_t)(bt * poses_per_wg + pl) * 28;
+            for (int e = gcol; e < 27; e += C) {
+                int r, c;   // entry e: (r, c) of the packed lower triangle, or (e - 21, residual column)
+                if (e < 21) {
+                    r = 0;
 #pragma unroll
-                    for (int c = 0; c < 6; c++) w[c] += Gb[lc * D.W + D.pose_off + c];
+                    for (int k = 1; k < 6; k++) r += e >= k * (k + 1) / 2 ? 1 : 0;
+                    c = e - r * (r + 1) / 2;
+                } else {
+                    r = e - 21;
+                    c = -1;
                 }
+                double v = 0.;
+                for (int q = r0; q < r1; q++) {
+                    const double *Gb;
+                    int W, o, d;
+                    ref_of(q, Gb, W, o, d);
+                    v += Gb[(o + r) * W + (c < 0 ? W - 1 : o + c)];
+                }
+                Vs[e] = v;
+            }
+            if (gcol == 0) Vs[27] = r1 > r0 ? 1. : 0.;
+        }
+        __syncthreads();
+    }
+    {
+        double y[6] = {0., 0., 0., 0., 0., 0.};
+        if (pose_on) {
+            PoseFactor f;
+            if (shared_gather) {
+                const double *Vs = sm_V + (size_t)(bt * poses_per_wg + pl) * 28;
+                double V[21];
+#pragma unroll
+                for (int k = 0; k < 21; k++) V[k] = Vs[k];
+#pragma unroll
+                for (int k = 0; k < 6; k++) f.gp[k] = Vs[21 + k];
+                pose_factor_from(a, i, V, Vs[27] != 0., f);
             } else {
+                pose_factor(a, i, f);
+            }
+            if (gcol >= a.G) {
 #pragma unroll
                 for (int c = 0; c < 6; c++) w[c] = f.gp[c];
                 double *rec = a.rec + (size_t)i * kPoseRec;
@@ -256,7 +358,7 @@ __global__ __launch_bounds__(kSchurThreads * kSchurMaxBatches) void vg_schur_row
                     rec[27 + k] = f.vd[k];
                 }
                 rec[33] = f.active ? 1. : 0.;
-                if (f.mode == 0 && !f.pd && a.ref_ptr[i + 1] > a.ref_ptr[i]) atomicAdd(&s_bad, 1);
+                if (f.mode == 0 && !f.pd && r1 > r0) atomicAdd(&s_bad, 1);
             }
             fwd6(f.L, w, y);
             double *out = a.rows + (size_t)i * 6 * C + gcol;
@@ -266,7 +368,7 @@ __global__ __launch_bounds__(kSchurThreads * kSchurMaxBatches) void vg_schur_row
                 out[k * C] = y[k];
             }
         }
-        if (lane_on) {
+        if (lane_on && bt < batches) {
 #pragma unroll
             for (int k = 0; k < 6; k++) sm_rows[(size_t)((bt * poses_per_wg + pl) * 6 + k) * CS + gcol] = y[k];
         }

@@ -306,8 +306,12 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
     const int sg_ppw = vg::kSchurThreads / (G + 1);
     int sg_batches = (int)((n_poses + (int64_t)sg_ppw * 512 - 1) / ((int64_t)sg_ppw * 512));
     sg_batches = sg_batches < 1 ? 1 : (sg_batches > vg::kSchurMaxBatches ? vg::kSchurMaxBatches : sg_batches);
-    while (sg_batches > 1 && sizeof(double) * (size_t)sg_batches * sg_ppw * 6 * (G + 2) > 48 * 1024) sg_batches--;
-    const size_t sg_lds = sizeof(double) * (size_t)sg_batches * sg_ppw * 6 * (G + 2);
+    while (sg_batches > 1 && sizeof(double) * (size_t)sg_batches * sg_ppw * (6 * (G + 2) + 28) + 24 * (size_t)vg::kSchurMaxRefs > 64 * 1024) sg_batches--;   // two 1024-thread workgroups fill a CU: 64 KB each is free
+    // + V_i | g_i of every pose of the workgroup, gathered once and shared by the pose's lanes (28 doubles per pose)
+    const size_t sg_lds = sizeof(double) * ((size_t)sg_batches * sg_ppw * 6 * (G + 2) + (size_t)sg_batches * sg_ppw * 28) + 24 * (size_t)vg::kSchurMaxRefs;
+    const int sg_shared = vgi::debug_hook(vgi::kHookSchurPrivateGather) ? 0 : 1;   // A/B hook: every lane gathers for itself
+    if (sg_lds > 48 * 1024)
+        VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(vg::vg_schur_rows_gram_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sg_lds));
     const unsigned int sg_wgs = (unsigned int)((n_poses + (int64_t)sg_ppw * sg_batches - 1) / ((int64_t)sg_ppw * sg_batches));
     // one device block + one pinned block for the whole solve (SolveArena); sizes: the buffers below, generously rounded
     size_t up_need = 64 * 1024 + (size_t)n_ds * 1024;
@@ -726,7 +730,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             sa.gate_expect = par;
             if (n_poses) {
                 // rows of every pose + the Gram of the rows, one launch; then ONE fixed-order sum over the workgroups
-                hipLaunchKernelGGL(vg::vg_schur_rows_gram_kernel, dim3(sg_wgs), dim3(vg::kSchurThreads * sg_batches), sg_lds, st, sa, sg_ppw, sg_batches, d_rgroups.p);
+                hipLaunchKernelGGL(vg::vg_schur_rows_gram_kernel, dim3(sg_wgs), dim3(vg::kSchurThreads * sg_batches), sg_lds, st, sa, sg_ppw, sg_batches, d_rgroups.p, sg_shared);
                 VG_HIP(hipGetLastError());
                 vg::launch_strided_sum(st, d_rgroups.p, sg_wgs, C * C + 1, d_rgram.p);  // the Gram and the count of bad pose blocks
                 VG_HIP(hipGetLastError());
@@ -935,7 +939,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
         if (n_poses) {
             if (coupled.empty()) {
                 sa.zero_u64 = d_gmax.p;  // the step's max |g_pose|, cleared here instead of by a memset in front of the back-substitution
-                hipLaunchKernelGGL(vg::vg_schur_rows_gram_kernel, dim3(sg_wgs), dim3(vg::kSchurThreads * sg_batches), sg_lds, st, sa, sg_ppw, sg_batches, d_rgroups.p);
+                hipLaunchKernelGGL(vg::vg_schur_rows_gram_kernel, dim3(sg_wgs), dim3(vg::kSchurThreads * sg_batches), sg_lds, st, sa, sg_ppw, sg_batches, d_rgroups.p, sg_shared);
             } else {
                 VG_HIP(hipMemsetAsync(d_bad, 0, sizeof(double), st));
                 hipLaunchKernelGGL(vg::vg_schur_rows_kernel, dim3((unsigned)((n_poses * C + 255) / 256)), dim3(256), 0, st, sa);
