@@ -7,6 +7,10 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
+from visgeom_amd import _build as _b  # noqa: E402
+
+if os.environ.get("AB_LIB"):   # same-box A/B against a variant library
+    _b.LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.environ["AB_LIB"])
 from visgeom_amd import CalibrationProblem, synthetic  # noqa: E402
 from visgeom_amd import capi as _capi  # noqa: E402
 
