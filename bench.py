@@ -99,7 +99,14 @@ def cpu_baseline(d, model, budget_s):
                 break
     except OSError:
         pass
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        affinity = None
     return {"value": vc, "unit": "evals/s", "cores": cores, "kind": "port",
+            # the count actually used next to what the box offers -- logical CPUs (hardware_concurrency), the CPUs
+            # this process may run on, and OpenMP's own maximum (= `cores`, the threads of the timed passes)
+            "hardware_concurrency": os.cpu_count(), "cpus_allowed": affinity, "omp_max_threads": cores,
             "sample": "%d passes (%.1f s) over the same %d-image x %d-corner set with %d OpenMP threads; "
                       "single thread: %d passes (%.1f s)" % (pc, tc, n, N, cores, p1, t1),
             "single_thread_value": v1, "cpu_model": cpu_model,
