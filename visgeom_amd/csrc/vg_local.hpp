@@ -48,6 +48,26 @@ VG_HD void transf_inverse_compose(const double *a, const double *b, double *out)
     quat_to_rotvec(quat_mul(q1inv, q2), out + 3);
 }
 
+// the same two compositions with the quaternions of the rotation parts given (computed by quat_of_rotvec on the same device:
+// the same bits as the functions above produce inside)
+VG_HD void transf_compose_q(const double *a, const Quat &q1, const double *b, const Quat &q2, double *out)
+{
+    double rt[3];
+    quat_rotate(q1, b, rt);
+    out[0] = rt[0] + a[0];
+    out[1] = rt[1] + a[1];
+    out[2] = rt[2] + a[2];
+    quat_to_rotvec(quat_mul(q1, q2), out + 3);
+}
+
+VG_HD void transf_inverse_compose_q(const double *a, const Quat &q1, const double *b, const Quat &q2, double *out)
+{
+    const Quat q1inv = {-q1.x, -q1.y, -q1.z, q1.w};
+    const double d[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
+    quat_rotate(q1inv, d, out);
+    quat_to_rotvec(quat_mul(q1inv, q2), out + 3);
+}
+
 // rotMat() / rotMatInv()  transformation.h:131-132
 VG_HD void transf_rot_mat(const double *a, double sign, double *R)
 {
@@ -100,6 +120,57 @@ constexpr int kMonoFrame = 34;    // padded to even: 16-byte aligned frames
 constexpr int kSparseFrame = 70;
 constexpr int kMonoPoints = 5;    // "5-point algorithm", local_cost_functions.h:156-168
 
+// ---- what the block frames need of xiBaseCam ALONE -- a constructor argument of the cost functions (local_cost_functions.h:
+// 163, 189), the same for every block of a set and for every evaluation: Quaternion(xiBaseCam.rot) (used by both compositions
+// of the chain), xiBaseCam.inverse() and its rotation matrix (the InterJacobian's xi13), xiBaseCam.rotMatInv() (the depth
+// Jacobian).  Computed ONCE per set by vg_local_base_kernel -- on the device, by the functions the frames used to call, so the
+// frames keep their bits -- instead of by every block's lane in every evaluation: a third of the dependent chain that IS the
+// run time of the frame phase.   [qb (4) | inv (6) | R(inv) (9) | RcamBase (9)]
+constexpr int kBaseConst = 28;
+
+VG_HD void base_const(const double *xiBaseCam, double *c)
+{
+    const Quat qb = quat_of_rotvec(xiBaseCam + 3);
+    c[0] = qb.x; c[1] = qb.y; c[2] = qb.z; c[3] = qb.w;
+    transf_inverse(xiBaseCam, c + 4);
+    transf_rot_mat(c + 4, 1., c + 10);
+    transf_rot_mat(xiBaseCam, -1., c + 19);
+}
+
+// inter_jacobian_frame with R(xi13) and the trigonometry of xi23's rotation given (every consumer of one rotation vector shares
+// ONE evaluation of its norm, sine and cosine: the same values the separate calls produced)
+VG_HD void inter_jacobian_frame_r(const double *xi13, const double *Ra, const double *xi23, const RotTrig &g23, bool inverted, double *fm)
+{
+    double Rb[9], M[9], R12[9], M12[9];
+    rotation_matrix(xi23 + 3, -1., g23, Rb);
+    mat3_mul(Ra, Rb, R12);
+    inter_omega_rot(xi23 + 3, g23, M);
+    mat3_mul(R12, M, M12);
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        fm[i] = inverted ? R12[i] * -1 : R12[i];
+        fm[9 + i] = inverted ? M12[i] * -1 : M12[i];
+    }
+    fm[18] = xi13[0];
+    fm[19] = xi13[1];
+    fm[20] = xi13[2];
+}
+
+// mono_frame / sparse_frame (below) from the set's base constants
+VG_HD void mono_frame_c(const double *xiBaseCam, const double *c, const double *xiOdom, double *f)
+{
+    const Quat qb = {c[0], c[1], c[2], c[3]};
+    double inner[6], xi21[6];
+    const RotTrig go = rot_trig(xiOdom + 3, true, true);
+    transf_inverse_compose_q(xiOdom, quat_from_rotvec(xiOdom + 3, go), xiBaseCam, qb, inner);
+    transf_inverse_compose_q(xiBaseCam, qb, inner, quat_of_rotvec(inner + 3), xi21);
+    f[0] = xi21[0];
+    f[1] = xi21[1];
+    f[2] = xi21[2];
+    transf_rot_mat(xi21, 1., f + 3);
+    inter_jacobian_frame_r(c + 4, c + 10, xiOdom, go, true, f + 12);
+}
+
 // local_cost_functions.cpp:219-221 (chain), :251-252 (InterJacobian)
 VG_HD void mono_frame(const double *xiBaseCam, const double *xiOdom, double *f)
 {
@@ -141,6 +212,36 @@ VG_HD void sparse_frame(const double *xiBaseCam, const double *xiOdom, double *f
     mat3_vec(A, xiBaseCam, tBaseCam1);                  // tBaseCam1 = RcamBase * R21.transpose() * _xiBaseCam.trans()
     const double Hn[9] = {-0., tBaseCam1[2], -tBaseCam1[1], -tBaseCam1[2], -0., tBaseCam1[0], tBaseCam1[1], -tBaseCam1[0], -0.};
     mat3_mul(Hn, M, Q);                                 // Q = -hat(tBaseCam1) * M
+}
+
+VG_HD void sparse_frame_c(const double *xiBaseCam, const double *c, const double *xiOdom, double *f)
+{
+    const Quat qb = {c[0], c[1], c[2], c[3]};
+    double inner[6], xi12[6];
+    const RotTrig go = rot_trig(xiOdom + 3, true, true);
+    transf_compose_q(xiOdom, quat_from_rotvec(xiOdom + 3, go), xiBaseCam, qb, inner);
+    transf_inverse_compose_q(xiBaseCam, qb, inner, quat_of_rotvec(inner + 3), xi12);
+    f[0] = xi12[0];
+    f[1] = xi12[1];
+    f[2] = xi12[2];
+    double *Rt = f + 3, *R21 = f + 12, *RcamBase = f + 42, *M = f + 51, *Q = f + 60;
+    const RotTrig g12 = rot_trig(xi12 + 3, true, false);
+    rotation_matrix(xi12 + 3, 1., g12, Rt);
+    rotation_matrix(xi12 + 3, -1., g12, R21);
+    inter_jacobian_frame_r(c + 4, c + 10, xiOdom, go, true, f + 21);
+#pragma unroll
+    for (int i = 0; i < 9; i++) RcamBase[i] = c[19 + i];
+    double Mo[9], R21T[9], A[9], tBaseCam1[3];
+    inter_omega_rot(xiOdom + 3, go, Mo);
+    mat3_mul(RcamBase, Mo, M);
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) R21T[3 * r + cc] = R21[3 * cc + r];
+    mat3_mul(RcamBase, R21T, A);
+    mat3_vec(A, xiBaseCam, tBaseCam1);
+    const double Hn[9] = {-0., tBaseCam1[2], -tBaseCam1[1], -tBaseCam1[2], -0., tBaseCam1[0], tBaseCam1[1], -tBaseCam1[0], -0.};
+    mat3_mul(Hn, M, Q);
 }
 
 // Triangulator::regDiv  triangulator.cpp:114-128
@@ -205,20 +306,27 @@ VG_HD double triangulate_regular(const double *R, const double *t, double eps, c
 // ------------------------------------------------------------------------------------------ kernels
 // one lane per block: the block's frame at its current odometry parameter
 #ifdef VG_TU_LOCAL  // this kernel is launched by one translation unit only; the others see the header without it
-__global__ __launch_bounds__(64) void vg_local_frame_kernel(const double *__restrict__ xiBaseCam, const double *__restrict__ xiOdom,
-                                                             long long first_block, long long n_blocks, int sparse,
-                                                             double *__restrict__ frames)
+__global__ __launch_bounds__(64) void vg_local_frame_kernel(const double *__restrict__ xiBaseCam, const double *__restrict__ base,
+                                                             const double *__restrict__ xiOdom, long long first_block, long long n_blocks,
+                                                             int sparse, double *__restrict__ frames)
 {
     const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= n_blocks) return;
     const double *xo = xiOdom + 6 * b;                 // parameter array of THIS launch: block first_block + b at row b
-    if (sparse) sparse_frame(xiBaseCam, xo, frames + (first_block + b) * kSparseFrame);
-    else mono_frame(xiBaseCam, xo, frames + (first_block + b) * kMonoFrame);
+    if (sparse) sparse_frame_c(xiBaseCam, base, xo, frames + (first_block + b) * kSparseFrame);
+    else mono_frame_c(xiBaseCam, base, xo, frames + (first_block + b) * kMonoFrame);
+}
+
+// once per set, at its creation: the base constants (one lane)
+__global__ __launch_bounds__(64) void vg_local_base_kernel(const double *__restrict__ xiBaseCam, double *__restrict__ base)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) base_const(xiBaseCam, base);
 }
 #endif
 
 struct MonoArgs {
     const double *xb;       // xiBaseCam [6]
+    const double *base;     // [kBaseConst] what the frames need of xiBaseCam alone (vg_local_base_kernel)
     const double *xi_odom;  // rows of this launch: [count][6]
     const double *intr;
     const double *x1;       // [n_blocks][5][3]
@@ -258,7 +366,7 @@ __global__ __launch_bounds__(kMonoThreads) void vg_mono_reproject_kernel(MonoArg
         const unsigned int last = (o0 + kMonoThreads - 1 < a.n_points ? o0 + kMonoThreads - 1 : a.n_points - 1) / kMonoPoints;
         if ((unsigned)tid <= last - bl0) {
             double fr[kMonoFrame];
-            mono_frame(a.xb, a.xi_odom + 6 * (size_t)(bl0 + tid), fr);
+            mono_frame_c(a.xb, a.base, a.xi_odom + 6 * (size_t)(bl0 + tid), fr);
             fr[kMonoFrame - 1] = 0.;
 #pragma unroll
             for (int k = 0; k < kMonoFrame; k++) lds_frames[tid * kMonoFrame + k] = fr[k];
@@ -313,6 +421,7 @@ struct SparseArgs {
     const double *p2;          // [total][2]
     const double *size;        // [total]
     const int *point_block;    // [total] block of every point
+    const double *base;        // [kBaseConst] what the frames need of xiBaseCam alone (vg_local_base_kernel)
     const double *xb;          // xiBaseCam [6]                      } the FUSED kernel computes the frames itself
     const double *xi_odom;     // rows of this launch: [n_blocks][6] }
     long long first_block;     // block of row 0 of xi_odom
@@ -408,7 +517,7 @@ __global__ __launch_bounds__(kEmitThreads) void vg_sparse_reproject_kernel(Spars
         const unsigned int o_last = o0 + kEmitThreads - 1 < a.n_points ? o0 + kEmitThreads - 1 : a.n_points - 1;
         const int b_first = a.point_block[a.first_point + o0], b_last = a.point_block[a.first_point + o_last];
         if (tid <= b_last - b_first)   // blocks without points in between cost a lane each and are never read
-            sparse_frame(a.xb, a.xi_odom + 6 * (size_t)(b_first + tid - a.first_block), lds_frames + tid * kSparseFrame);
+            sparse_frame_c(a.xb, a.base, a.xi_odom + 6 * (size_t)(b_first + tid - a.first_block), lds_frames + tid * kSparseFrame);
         __syncthreads();
         sparse_point<MODEL>(a, lds_frames + (blk - b_first) * kSparseFrame, pt, o, active, o0, stage, wave, lane);
     } else {

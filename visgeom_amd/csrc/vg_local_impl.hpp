@@ -14,6 +14,7 @@ struct vg_reproject_set {
     std::vector<int64_t> offsets;          // [n_blocks + 1] first point of every block
     double *d_const = nullptr;             // one allocation: intrinsics | xiBaseCam | x1 | x2 | p2 | size
     double *d_intr = nullptr, *d_xb = nullptr, *d_x1 = nullptr, *d_x2 = nullptr, *d_p2 = nullptr, *d_size = nullptr;
+    double *d_base = nullptr;              // [kBaseConst] what the frames need of xiBaseCam alone, computed once on the device
     int *d_point_block = nullptr;
     double *d_frames = nullptr;
     // per-block host entry: parameters in, rows out, through one pinned block and one device block
@@ -99,7 +100,8 @@ inline int create_unguarded(vg_reproject_set **out, int device, void *hip_stream
     const size_t T = (size_t)s->total;
     // layout of the constant block (every piece 16-byte aligned)
     const size_t o_intr = 0, o_xb = 10, o_x1 = 16, o_x2 = o_x1 + 3 * T + (T & 1), o_p2 = o_x2 + (sparse ? 3 * T + (T & 1) : 0),
-                 o_size = o_p2 + 2 * T, n_const = o_size + (sparse ? T : 0) + 2;
+                 o_size = o_p2 + 2 * T, o_base = o_size + (sparse ? T : 0) + (((sparse ? T : 0)) & 1),
+                 n_const = o_base + vg::kBaseConst + 2;
     std::vector<double> h(n_const, 0.);
     std::memcpy(h.data() + o_intr, intr, sizeof(double) * K);
     std::memcpy(h.data() + o_xb, xb, sizeof(double) * 6);
@@ -124,6 +126,9 @@ inline int create_unguarded(vg_reproject_set **out, int device, void *hip_stream
     s->d_x2 = s->d_const + o_x2;
     s->d_p2 = s->d_const + o_p2;
     s->d_size = s->d_const + o_size;
+    s->d_base = s->d_const + o_base;
+    hipLaunchKernelGGL(vg::vg_local_base_kernel, dim3(1), dim3(64), 0, s->stream, (const double *)s->d_xb, s->d_base);
+    if ((e = hipGetLastError()) != hipSuccess) { hip_fail(e, "vg_local_base_kernel"); destroy(s); live = nullptr; return rc; }
     if (sparse) {
         std::vector<int> pb(T ? T : 1, 0);
         for (int64_t b = 0; b < n_blocks; b++)
@@ -175,8 +180,8 @@ inline int launch(vg_reproject_set *s, int64_t b0, int64_t nb, const double *xi_
     // few workgroups: each computes the frames of its own blocks (one launch, no frame round trip through HBM)
     const bool fused = s->sparse && grid.x <= kFusedMaxGrid && s->max_wg_span <= vg::kSparseWgBlocks;
     if (s->sparse && !fused) {
-        hipLaunchKernelGGL(vg::vg_local_frame_kernel, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, s->stream, (const double *)s->d_xb, xi_odom,
-                           (long long)b0, (long long)nb, 1, s->d_frames);
+        hipLaunchKernelGGL(vg::vg_local_frame_kernel, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, s->stream, (const double *)s->d_xb, (const double *)s->d_base,
+                           xi_odom, (long long)b0, (long long)nb, 1, s->d_frames);
         VG_HIP(hipGetLastError());
     }
     if (!np) return VG_OK;
@@ -190,6 +195,7 @@ inline int launch(vg_reproject_set *s, int64_t b0, int64_t nb, const double *xi_
         a.size = s->d_size;
         a.point_block = s->d_point_block;
         a.xb = s->d_xb;
+        a.base = s->d_base;
         a.xi_odom = xi_odom;
         a.first_block = b0;
         a.res = res;
@@ -214,6 +220,7 @@ inline int launch(vg_reproject_set *s, int64_t b0, int64_t nb, const double *xi_
         vg::MonoArgs a;
         const dim3 mgrid((unsigned)((np + vg::kMonoThreads - 1) / vg::kMonoThreads)), mblk(vg::kMonoThreads);
         a.xb = s->d_xb;
+        a.base = s->d_base;
         a.xi_odom = xi_odom;
         a.intr = s->d_intr;
         a.x1 = s->d_x1;
