@@ -58,15 +58,18 @@ def one_rank():
     return line
 
 
-def test_two_ranks_over_gloo_on_one_gpu_run_every_section_and_reach_the_one_rank_optimum(one_rank):
-    line, err = run([sys.executable, "bench.py", "--gpus", "2"] + SMALL, {"VG_BENCH_BACKEND": "gloo"})
-    assert line["n_gpus"] == 2 and line["scaling"] == "weak"
+@pytest.mark.parametrize("n_ranks", [2, 8])
+def test_ranks_over_gloo_on_one_gpu_run_every_section_and_reach_the_one_rank_optimum(one_rank, n_ranks):
+    """2 ranks, and the 8 of the driver's scaling run (the shard arithmetic, every collective and the deadline thread with the
+    world size the real run has)"""
+    line, err = run([sys.executable, "bench.py", "--gpus", str(n_ranks)] + SMALL, {"VG_BENCH_BACKEND": "gloo"})
+    assert line["n_gpus"] == n_ranks and line["scaling"] == "weak"
     check_sections(line)
     assert line["jtj"]["allreduce"] is True and "gloo" in line["jtj"]["collective"]
-    assert line["sharded_mei"]["n_ranks"] == 2 and line["sharded_mei"]["images_this_rank"] == 300
+    assert line["sharded_mei"]["n_ranks"] == n_ranks and line["sharded_mei"]["images_this_rank"] == 600 // n_ranks
     for key in ("mei_10k", "eucm_100k"):
         two, one = line["sharded_solve"][key], one_rank["sharded_solve"][key]
-        assert two["n_ranks"] == 2 and two["collectives_per_iteration"] == 2
+        assert two["n_ranks"] == n_ranks and two["collectives_per_iteration"] == 2
         # the same problem split over two ranks ends at the same optimum (summation order differs: 1e-9 on the cost)
         assert abs(two["final_cost"] - one["final_cost"]) <= 1e-9 * abs(one["final_cost"]), (key, two["final_cost"], one["final_cost"])
         assert abs(two["max_rel_intrinsics_error_vs_generating"] - one["max_rel_intrinsics_error_vs_generating"]) <= 1e-6
