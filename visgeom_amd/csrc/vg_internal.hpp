@@ -32,6 +32,7 @@ enum DebugHook {
     kHookSolverNoSpeculation,      // queue one LM iteration at a time
     kHookEmitEqualTiles,           // merged emit launch: contiguous XCD pieces of 1 = equal tile counts, 2 = equal bytes (default: an eighth of every dataset, widest rows first; 4: in problem order)
     kHookSchurPrivateGather,       // Schur rows kernel: every lane of a pose gathers V_i / g_i itself (the route before round 4), for A/B
+    kHookSolverEventWait,          // device-resident loop: wait for an event behind every accept kernel instead of spinning on its sequence word (A/B)
     kHookGramStamps,               // measurement build (-DVG_GRAM_STAMPS) only: device address of the per-wave clock stamps of the Gram kernel
     kHookCount
 };

@@ -301,6 +301,10 @@ struct LmAcceptArgs {
     const double *scal_partials;       // [n_scal][5] per-workgroup partials of the back-substitution's scalar sums, or NULL:
     unsigned int n_scal;               //   they were summed (and all-reduced) into sums[n_ds * Wmax^2 ..] by the caller
     int gate_expect;                   // run only if st->gate == gate_expect (-1: no test)
+    // the host does not wait for an event behind this kernel (a marker packet in the stream: 5-6 us before the next iteration's
+    // first kernel starts, rocprofv3 trace) but spins on host_seq: written with system-scope release AFTER the state
+    unsigned long long *host_seq = nullptr;   // pinned; NULL: the host waits for an event (A/B hook)
+    unsigned long long seq = 0;               // the value this launch leaves there
     LmState *host_state;               // pinned host memory (device-visible): the state after this call, for the host's
                                        //   decisions -- written by the kernel itself: a copy command between two kernels of
                                        //   a stream costs two engine hand-overs (~20 us), a store costs nothing
@@ -314,7 +318,10 @@ __global__ __launch_bounds__(kLmThreads) void vg_lm_accept_kernel(LmAcceptArgs a
     const int G = a.G, tid = threadIdx.x;
     LmState *st = a.st;
     if (st->done) {  // over before this launch (e.g. a non-finite cost at the starting point): the host still gets the state
-        if (tid == 0 && a.host_state) *a.host_state = *st;
+        if (tid == 0 && a.host_state) {
+            *a.host_state = *st;
+            if (a.host_seq) __hip_atomic_store(a.host_seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         return;
     }
     if (a.gate_expect >= 0 && st->gate != a.gate_expect) return;
@@ -407,7 +414,10 @@ __global__ __launch_bounds__(kLmThreads) void vg_lm_accept_kernel(LmAcceptArgs a
     for (int d = 0; d < a.n_ds; d++) cost2_c += sums[d * WW + (size_t)a.Wd[d] * a.Wd[d] - 1];
     auto publish = [&]() {
         *st = S;
-        if (a.host_state) *a.host_state = S;
+        if (a.host_state) {
+            *a.host_state = S;
+            if (a.host_seq) __hip_atomic_store(a.host_seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     };
     if (a.init) {
         S.cost2 = cost2_c;

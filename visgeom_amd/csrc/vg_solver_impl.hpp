@@ -685,6 +685,8 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
         constexpr int kSlots = 4;
         struct Slots {
             vg::LmState *p = nullptr;
+            volatile unsigned long long *seq = nullptr;   // pinned, behind the states: what the accept kernel of a slot wrote last
+            unsigned long long expect[kSlots] = {};
             bool owned = false;
             hipEvent_t ev[kSlots] = {};
             ~Slots()
@@ -694,17 +696,35 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
                     if (e) (void)hipEventDestroy(e);
             }
         } slots;
-        if (t_arena) slots.p = static_cast<vg::LmState *>(t_arena->pin_alloc(sizeof(vg::LmState) * kSlots));
+        const size_t slots_bytes = sizeof(vg::LmState) * kSlots + sizeof(unsigned long long) * kSlots;
+        if (t_arena) slots.p = static_cast<vg::LmState *>(t_arena->pin_alloc(slots_bytes));
         if (!slots.p) {
-            VG_HIP(hipHostMalloc(reinterpret_cast<void **>(&slots.p), sizeof(vg::LmState) * kSlots, hipHostMallocDefault));
+            VG_HIP(hipHostMalloc(reinterpret_cast<void **>(&slots.p), slots_bytes, hipHostMallocDefault));
             slots.owned = true;
         }
-        for (auto &e : slots.ev) VG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        slots.seq = reinterpret_cast<volatile unsigned long long *>(slots.p + kSlots);
+        for (int k = 0; k < kSlots; k++) slots.seq[k] = 0ull;
+        // The host learns the outcome of an iteration by SPINNING on the slot's sequence word, which the accept kernel stores
+        // (system-scope release) behind the state -- not from an event recorded behind the kernel: the event's marker packet kept
+        // the next iteration's first kernel waiting 5-6 us after every accept (rocprofv3 trace, tools/exp/trace_gaps.py).
+        // vg_debug_set("solver_event_wait", 1) restores the event (A/B).
+        const bool spin_wait = !vgi::debug_hook(vgi::kHookSolverEventWait);
+        if (!spin_wait)
+            for (auto &e : slots.ev) VG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        unsigned long long seq_counter = 0ull;
         int n_queued = 0;
-        // the accept kernel writes its state into pinned slot `slot` itself; the event tells the host when
+        // the accept kernel writes its state into pinned slot `slot` itself; the sequence word (or the event) tells the host when
         auto next_slot = [&]() { return n_queued++ % kSlots; };
+        auto arm_slot = [&](int slot, vg::LmAcceptArgs &args) {
+            args.host_state = slots.p + slot;
+            if (spin_wait) {
+                slots.expect[slot] = ++seq_counter;
+                args.host_seq = const_cast<unsigned long long *>(slots.seq + slot);
+                args.seq = slots.expect[slot];
+            }
+        };
         auto queue_state = [&](int slot) -> int {
-            VG_HIP(hipEventRecord(slots.ev[slot], st));
+            if (!spin_wait) VG_HIP(hipEventRecord(slots.ev[slot], st));
             return VG_OK;
         };
         // queue one LM iteration for parity `par` (current point = set / buffer `par`, candidate = the other one)
@@ -785,13 +805,25 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             vg::LmAcceptArgs a2 = aa;
             a2.gate_expect = gated ? par : -1;
             slot = next_slot();
-            a2.host_state = slots.p + slot;
+            arm_slot(slot, a2);
             hipLaunchKernelGGL(vg::vg_lm_accept_kernel, dim3(1), dim3(vg::kLmThreads), accept_lds, st, a2);
             VG_HIP(hipGetLastError());
             return queue_state(slot);
         };
         auto wait_state = [&](int slot) -> int {
-            VG_HIP(hipEventSynchronize(slots.ev[slot]));
+            if (!spin_wait) {
+                VG_HIP(hipEventSynchronize(slots.ev[slot]));
+                return VG_OK;
+            }
+            const double t_spin = now_s();
+            unsigned long spins = 0;
+            while (slots.seq[slot] != slots.expect[slot]) {
+                if ((++spins & 0xfffff) == 0 && now_s() - t_spin > 30.) {   // the device is gone or the launch failed: do not hang
+                    VG_HIP(hipStreamSynchronize(st));
+                    if (slots.seq[slot] != slots.expect[slot]) return fail(VG_ERR_STATE, "the accept kernel of an LM iteration never reported");
+                }
+            }
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
             return VG_OK;
         };
         if (t_arena) VG_TRY(t_arena->flush(st));  // every table of the set-up in one asynchronous copy
@@ -800,7 +832,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
         VG_HIP(hipMemcpyAsync(d_xc.p, d_x.p, sizeof(double) * (size_t)n_params, hipMemcpyDeviceToDevice, st));
         VG_TRY(enqueue_evaluate(xbuf[0], gset[0]));
         int parity = 0, pending = next_slot(), iter = 0;
-        aa.host_state = slots.p + pending;
+        arm_slot(pending, aa);
         hipLaunchKernelGGL(vg::vg_lm_accept_kernel, dim3(1), dim3(vg::kLmThreads), accept_lds, st, aa);
         VG_HIP(hipGetLastError());
         aa.init = 0;
