@@ -342,3 +342,48 @@ def test_more_datasets_than_one_merged_launch_takes(vg, n_ds):
     assert abs(s1["final_cost"] - s2["final_cost"]) <= 1e-9 * s2["final_cost"]
     assert np.max(np.abs(x1 - x2) / np.maximum(np.abs(x2), 1.0)) < 1e-6
     p.close()
+
+
+@pytest.mark.parametrize("problem,loop", [("stereo", "device"), ("stereo", "host"), ("rig", "host"), ("rig", "device"), ("stereo_gaps", "device")])
+def test_candidate_frames_from_the_back_substitution_equal_the_chain_prep_launch(vg, problem, loop):
+    """The frames of an LM candidate are built by the back-substitution kernel that computes the candidate (no
+    vg_chain_prep_multi_kernel in front of its evaluation; the reference walks the chain twice per Evaluate,
+    src/calibration/calib_cost_functions.cpp:32-46,76-92).  Same walk on the same values: the WHOLE solve is bit-identical with
+    the prep launch restored through the hook -- cost, iteration count and every parameter."""
+    from visgeom_amd import capi, synthetic as S
+
+    def build():
+        if problem == "rig":
+            return build_rig(vg, S.make_rig(70, sigma=0.1))[0]
+        st = S.make_stereo(90)
+        p = vg.CalibrationProblem(0)
+        c1 = p.add_camera("eucm", st["init_intrinsics1"])
+        c2 = p.add_camera("eucm", st["init_intrinsics2"])
+        x12 = p.add_transform(True, st["init_xi12"])
+        seq = p.add_transform(False, st["init_poses"])
+        p.add_dataset(c1, [(seq, 0)], st["board"], st["corners1"])
+        if problem == "stereo_gaps":   # the second camera saw every third pair only: blocks and sequence elements differ
+            idx = np.arange(0, 90, 3, dtype=np.int32)
+            p.add_dataset(c2, [(x12, 1), (seq, 0)], st["board"], st["corners2"][idx], image_index=idx)
+        else:
+            p.add_dataset(c2, [(x12, 1), (seq, 0)], st["board"], st["corners2"])
+        p.finalize()
+        return p
+
+    out = []
+    for no_fold in (0, 1):
+        capi.debug_set("solver_no_fold_frames", no_fold)
+        capi.debug_set("solver_device_loop" if loop == "device" else "solver_host_loop", 1)
+        try:
+            p = build()
+            s = p.solve(max_num_iterations=60)
+            out.append((s, p.get_parameters()))
+            p.close()
+        finally:
+            capi.debug_set("solver_no_fold_frames", 0)
+            capi.debug_set("solver_device_loop", 0)
+            capi.debug_set("solver_host_loop", 0)
+    (s_fold, x_fold), (s_prep, x_prep) = out
+    assert s_fold["termination"].startswith("CONVERGENCE")
+    assert s_fold["num_iterations"] == s_prep["num_iterations"] and s_fold["final_cost"] == s_prep["final_cost"]
+    assert np.array_equal(x_fold, x_prep)

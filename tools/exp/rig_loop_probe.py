@@ -9,6 +9,7 @@ from visgeom_amd import capi, synthetic as S  # noqa: E402
 import visgeom_amd as vg  # noqa: E402
 from tests.test_gpu_rig import build_rig  # noqa: E402
 
+capi.hooks_from_env()   # VG_SOLVER_NO_FOLD_FRAMES=1 etc.
 r = S.make_rig(5000, sigma=0.1)
 for mode in ("host", "device"):
     capi.debug_set("solver_device_loop", 1 if mode == "device" else 0)

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""profiling driver: full LM loop on config 5 (rig) or the mono headline set (for rocprofv3)."""
+"""profiling driver: full LM loop on config 5 (rig), config 3 (stereo) or a mono set (for rocprofv3).
+usage: python tools/prof_solve.py <rig|stereo|eucm|ucm|mei> [n]"""
 import os
 import sys
 import time
@@ -27,6 +28,15 @@ if which == "rig":
     p.add_dataset(cams[0], [(seq, 0)], r["board"], r["corners"][0])
     for k in range(3):
         p.add_dataset(cams[k + 1], [(x1k[k], 1), (seq, 0)], r["board"], r["corners"][k + 1])
+elif which == "stereo":
+    st = synthetic.make_stereo(n)
+    p = CalibrationProblem(0)
+    c1 = p.add_camera("eucm", st["init_intrinsics1"])
+    c2 = p.add_camera("eucm", st["init_intrinsics2"])
+    x12 = p.add_transform(True, st["init_xi12"])
+    seq = p.add_transform(False, st["init_poses"])
+    p.add_dataset(c1, [(seq, 0)], st["board"], st["corners1"])
+    p.add_dataset(c2, [(x12, 1), (seq, 0)], st["board"], st["corners2"])
 else:
     d = synthetic.make_mono(which, n, 1)
     p = CalibrationProblem(0)
@@ -35,7 +45,7 @@ else:
     p.add_dataset(cam, [(seq, 0)], d["board"], d["corners"])
 p.finalize()
 x0 = p.get_parameters()
-for rep in range(3):
+for rep in range(int(os.environ.get('REPS', '3'))):
     p.set_parameters(x0)
     torch.cuda.synchronize()
     t = time.perf_counter()

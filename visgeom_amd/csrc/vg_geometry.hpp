@@ -372,6 +372,23 @@ VG_HD void build_frame(int L, const int *status, MemberFn member, double *frame)
     chain_finish(s, frame);
 }
 
+// The same walk for members that do not lie in one parameter vector (the candidate point of an LM step inside the
+// back-substitution kernel: pose from registers, global members from LDS, constant members from memory): `fill(l, xi)`
+// writes the 6-vector of member l.  Same arithmetic in the same order as build_frame(): same bits.
+template <typename FillFn>
+VG_HD void build_frame_vals(int L, const int *status, FillFn fill, double *frame)
+{
+    ChainState s;
+    chain_state_init(s);
+    for (int l = 0; l < L; l++) {
+        const Quat q1 = chain_acc_quat(s);
+        double xi[6];
+        fill(l, xi);
+        chain_walk_member(s, q1, xi, status[l] != 0, frame + 12 + 21 * l);
+    }
+    chain_finish(s, frame);
+}
+
 // The frame of a chain with ONE member used DIRECT (the mono calibration case): xiAcc = identity o xi23 = xi23.
 // build_frame() gets there through the reference's rotvec -> quaternion -> rotvec round trip and a second Rodrigues
 // evaluation; that round trip is the identity up to rounding (|dR| < 1e-15, also across its first-order branches,

@@ -138,6 +138,12 @@ int launch_gram_valu(hipStream_t stream, const vg::GramValuArgs &a, int L, bool 
 
 }  // namespace
 
+bool vgi::gram_dataset_needs_frames(const vg_problem *p, int dataset_id)
+{
+    const Dataset &d = p->dss[(size_t)dataset_id];
+    return d.n_blocks && !gram_inline_chain(p, d);
+}
+
 bool vgi::gram_needs_frames(const vg_problem *p)
 {
     for (const Dataset &d : p->dss)

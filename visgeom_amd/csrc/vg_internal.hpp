@@ -33,6 +33,7 @@ enum DebugHook {
     kHookEmitEqualTiles,           // merged emit launch: contiguous XCD pieces of 1 = equal tile counts, 2 = equal bytes (default: an eighth of every dataset, widest rows first; 4: in problem order)
     kHookSchurPrivateGather,       // Schur rows kernel: every lane of a pose gathers V_i / g_i itself (the route before round 4), for A/B
     kHookSolverEventWait,          // device-resident loop: wait for an event behind every accept kernel instead of spinning on its sequence word (A/B)
+    kHookSolverNoFoldFrames,       // LM loops: launch the chain prep in front of every candidate evaluation instead of building the candidate's frames in the back-substitution kernel (A/B, bit-equality test)
     kHookGramStamps,               // measurement build (-DVG_GRAM_STAMPS) only: device address of the per-wave clock stamps of the Gram kernel
     kHookCount
 };
@@ -175,5 +176,6 @@ int gram_fused_merged_at(vg_problem *p, const double *d_params, double *const *g
                          double *const *partials /* per dataset [E][ceil(n_blocks / 8)] or NULL */);
 bool gram_merge_covers_all(const vg_problem *p);  // every non-empty dataset goes through the merged launch
 bool gram_needs_frames(const vg_problem *p);  // false when every dataset's Gram kernel walks its chain itself
+bool gram_dataset_needs_frames(const vg_problem *p, int dataset_id);  // the same question for one dataset
 int gram_sum_into(vg_problem *p, int dataset_id, const double *gram, double *sum);
 }  // namespace vgi

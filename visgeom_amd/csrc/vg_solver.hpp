@@ -421,6 +421,13 @@ struct BacksubArgs {
     double *xg;                    // [G] current values of the global columns (gathered for the host)
     const double *lo, *hi;         // [G] box of every global column (poses are unbounded)
     double *x_new;                 // clamp(x + delta, lo, hi) of the global columns and of this kernel's poses
+    // The frames of the CANDIDATE point, built here (no chain-prep launch in front of the candidate's
+    // evaluation): fold[d] describes dataset d as vg_chain_prep_multi_kernel sees it (count = 0: its Gram kernel walks the chain
+    // itself, nothing to build), fold_gcol[d * kMaxChain + l] is the first global column of chain member l (-1: the sequence
+    // member -- the pose at hand; constant transforms are columns too, with a zero step).  NULL: the caller launches the chain
+    // prep as before.
+    const PrepDataset *fold = nullptr;
+    const int *fold_gcol = nullptr;
 };
 
 // dp_i = -V_i'^-1 (g_i + W_i^T dg) = -L^-T (L^-1 g_i + (L^-1 W_i^T) dg): everything needed is already in the
@@ -446,10 +453,22 @@ __device__ __forceinline__ void backsub_body(const BacksubArgs &b, const double 
         b.xg[t] = b.x[gp];
         b.x_new[gp] = clampd(b.x[gp] + dgv[t], b.lo[t], b.hi[t]);
     }
+    // candidate frames: every workgroup needs the candidate values of the global columns (the expression above: same bits)
+    __shared__ double s_gx[kBsThreads / 2];
+    static_assert(kBsThreads / 2 >= 127, "a slot per global column");
+    if (b.fold) {
+        if ((int)threadIdx.x < a.G) {
+            const long long gp = b.gcol_param[threadIdx.x];
+            s_gx[threadIdx.x] = clampd(b.x[gp] + dgv[threadIdx.x], b.lo[threadIdx.x], b.hi[threadIdx.x]);
+        }
+        __syncthreads();
+    }
     if ((int)(blockIdx.x * kBsPosesPerBlock) >= a.n_poses) return;  // workgroups that only carry global columns
     const int gl = threadIdx.x & (kBsGroup - 1), grp = threadIdx.x >> 4;
     const int C = a.G + 1;
     double s0 = 0., s1 = 0., s2 = 0., s3 = 0., s4 = 0., s5 = 0.;
+    double xc[kBsPosesPerGroup][6] = {};   // the group's candidate poses (valid in its first lane)
+    int ref0[kBsPosesPerGroup], ref1[kBsPosesPerGroup];
 #pragma unroll
     for (int q = 0; q < kBsPosesPerGroup; q++) {
         const int i = blockIdx.x * kBsPosesPerBlock + q * (kBsThreads / kBsGroup) + grp;
@@ -461,6 +480,8 @@ __device__ __forceinline__ void backsub_body(const BacksubArgs &b, const double 
         // round trip behind the branch
         const double *rec = a.rec + (size_t)ii * kPoseRec;
         const long long pp = b.pose_param[ii];
+        ref0[q] = (b.fold && pv) ? a.ref_ptr[ii] : 0;
+        ref1[q] = (b.fold && pv) ? a.ref_ptr[ii + 1] : 0;
         double L[21], gk[6], dk[6], xk[6], y[6], yl[6];
 #pragma unroll
         for (int k = 0; k < 21; k++) L[k] = rec[k];
@@ -504,6 +525,7 @@ __device__ __forceinline__ void backsub_body(const BacksubArgs &b, const double 
                 const double v = active ? -x[c] : 0.;
                 dp[c] = v;
                 b.x_new[pp + c] = xk[c] + v;  // the candidate point (poses are unbounded)
+                xc[q][c] = xk[c] + v;
                 const double g = gk[c];
                 s0 += g * v;
                 s1 += clampd(dk[c], a.dmin, a.dmax) * v * v;
@@ -512,6 +534,35 @@ __device__ __forceinline__ void backsub_body(const BacksubArgs &b, const double 
                 s3 += v * v;
                 s5 += xk[c] * xk[c];
             }
+        }
+    }
+    if (b.fold) {
+        // The frames of the group's two poses at the candidate point, for every dataset block that refers to them: lanes 0..7 of
+        // the group take the references of the first pose, lanes 8..15 those of the second (a rig: four each), all chains of the
+        // workgroup side by side -- the walk is one dependent chain per lane, exactly what vg_chain_prep_multi_kernel runs one
+        // launch later with most of the chip idle.
+        static_assert(kBsPosesPerGroup == 2 && kBsGroup == 16, "two poses per 16-lane group");
+        const int half = gl >> 3, hl = gl & 7;
+        double xp[6];
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+            const double v0 = __shfl(xc[0][c], 0, kBsGroup), v1 = __shfl(xc[1][c], 0, kBsGroup);
+            xp[c] = half ? v1 : v0;
+        }
+        const int r_end = half ? ref1[1] : ref1[0];
+        for (int r = (half ? ref0[1] : ref0[0]) + hl; r < r_end; r += 8) {
+            const int ds = a.ref_ds[r];
+            const PrepDataset *D = b.fold + ds;
+            if (D->count == 0) continue;
+            const long long blk = a.ref_blk[r];
+            const int *gc = b.fold_gcol + ds * kMaxChain;
+            build_frame_vals(D->chain.L, D->chain.status,
+                             [&](int l, double *xi) {
+                                 const int g0 = gc[l];
+#pragma unroll
+                                 for (int c = 0; c < 6; c++) xi[c] = g0 < 0 ? xp[c] : s_gx[g0 + c];
+                             },
+                             D->frames + blk * D->frame_stride_d);
         }
     }
 #pragma unroll

@@ -356,6 +356,32 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
     VG_TRY(d_gcol_param.upload(gcol_param));
     VG_TRY(d_glo.upload(glo));
     VG_TRY(d_ghi.upload(ghi));
+    // The frames of a CANDIDATE point are built by the back-substitution kernel that computes the point (VERDICT r3 next #5:
+    // one launch less in front of every candidate evaluation): possible when every dataset whose Gram kernel reads frames hangs on
+    // a pose this solve eliminates on the device.  vg_debug_set("solver_no_fold_frames", 1): the chain prep launch, as before.
+    bool fold_frames = vgi::gram_needs_frames(p) && coupled.empty() && n_poses > 0 && !vgi::debug_hook(vgi::kHookSolverNoFoldFrames);
+    for (int d = 0; d < n_ds && fold_frames; d++)
+        if (vgi::gram_dataset_needs_frames(p, d) && seq_tf[d] < 0) fold_frames = false;
+    DevBuf<vg::PrepDataset> d_fold;
+    DevBuf<int> d_fold_gcol;
+    if (fold_frames) {
+        std::vector<vg::PrepDataset> fold((size_t)n_ds);
+        std::vector<int> fold_gcol((size_t)n_ds * vg::kMaxChain, -1);
+        for (int d = 0; d < n_ds; d++) {
+            const vgi::Dataset &D = p->dss[d];
+            vg::PrepDataset &pd = fold[(size_t)d];
+            pd.chain = D.chain;
+            pd.seq_index = D.seq_identity ? nullptr : D.d_seq;
+            pd.frames = D.d_frames;
+            pd.first = 0;
+            pd.count = vgi::gram_dataset_needs_frames(p, d) ? D.n_blocks : 0;
+            pd.frame_stride_d = D.frame_stride;
+            for (int l = 0; l < D.L; l++)
+                if (p->tfs[D.tids[l]].global) fold_gcol[(size_t)d * vg::kMaxChain + l] = tf_goff[D.tids[l]];
+        }
+        VG_TRY(d_fold.upload(fold));
+        VG_TRY(d_fold_gcol.upload(fold_gcol));
+    }
     mark("uploads");
     VG_TRY(d_sums.alloc((size_t)n_ds * Wmax * Wmax + 5));
     VG_TRY(d_x.alloc((size_t)n_params));
@@ -462,9 +488,9 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
     }
     // queue the evaluation of the Gram matrices at a device parameter buffer into gram set `set`, their fixed-order sums
     // into d_sums and the ONE collective of an evaluation (no host synchronisation)
-    auto enqueue_evaluate = [&](const double *x_dev, DevBuf<double> *set) -> int {
+    auto enqueue_evaluate = [&](const double *x_dev, DevBuf<double> *set, bool frames_ready = false) -> int {
         int r;
-        if (vgi::gram_needs_frames(p) && (r = vgi::prepare_at(p, x_dev)) != VG_OK) return r;
+        if (vgi::gram_needs_frames(p) && !frames_ready && (r = vgi::prepare_at(p, x_dev)) != VG_OK) return r;
         // several datasets: the ones the vector-pipe kernel takes share one launch
         std::vector<char> merged((size_t)n_ds, 0);
         if (n_ds > 1) {
@@ -515,10 +541,10 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
     };
     // evaluate at a device parameter buffer and assemble U / gg / cost on the host
     auto evaluate = [&](const double *x_dev, DevBuf<double> *set, std::vector<double> &Uo, std::vector<double> &go,
-                        double &cost2) -> int {
+                        double &cost2, bool frames_ready = false) -> int {
         const double t0 = now_s();
         int r;
-        if ((r = enqueue_evaluate(x_dev, set)) != VG_OK) return r;
+        if ((r = enqueue_evaluate(x_dev, set, frames_ready)) != VG_OK) return r;
         if (!host_direct) VG_HIP(hipMemcpyAsync(pin_sums.p, d_sums.p, sizeof(double) * h_sums.size(), hipMemcpyDeviceToHost, st));
         VG_HIP(hipStreamSynchronize(st));
         std::memcpy(h_sums.data(), pin_sums.p, sizeof(double) * h_sums.size());
@@ -782,6 +808,8 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             ba.lo = d_glo.p;
             ba.hi = d_ghi.p;
             ba.x_new = xbuf[1 - par];   // the step is applied where it is computed: no separate launch
+            ba.fold = fold_frames ? d_fold.p : nullptr;   // ... and so are the candidate's frames
+            ba.fold_gcol = d_fold_gcol.p;
             if (n_poses || G) {
                 const unsigned int bs_grid = n_bs_groups ? n_bs_groups : 1u;
                 if (fold_solve) {
@@ -799,7 +827,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             }
             p->gram_gate = gate;
             p->gram_gate_expect = par;
-            const int re = enqueue_evaluate(xbuf[1 - par], gset[1 - par]);
+            const int re = enqueue_evaluate(xbuf[1 - par], gset[1 - par], fold_frames && n_poses > 0);
             p->gram_gate = nullptr;
             if (re != VG_OK) return re;
             vg::LmAcceptArgs a2 = aa;
@@ -1107,6 +1135,8 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             ba.lo = d_glo.p;
             ba.hi = d_ghi.p;
             ba.x_new = d_xc.p;   // host-eliminated sequences overwrite their poses below
+            ba.fold = fold_frames ? d_fold.p : nullptr;   // the candidate's frames come out of the same launch
+            ba.fold_gcol = d_fold_gcol.p;
             if (n_poses || G) {  // G <= kBsThreads: one workgroup is enough for the global columns alone
                 const unsigned int bs_grid = n_bs_groups ? n_bs_groups : 1u;
                 if (G < 64) hipLaunchKernelGGL(vg::vg_backsub_kernel<4>, dim3(bs_grid), dim3(vg::kBsThreads), 0, st, ba);
@@ -1144,7 +1174,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             // No wait here: the candidate evaluation does not depend on these scalars, it is queued right behind the
             // step on the same stream, and its own read-back synchronises once for both (one host round trip per
             // iteration less; the wait is booked under "evaluate").
-            VG_TRY(evaluate(d_xc.p, cand, Uc, ggc, cost2_c));
+            VG_TRY(evaluate(d_xc.p, cand, Uc, ggc, cost2_c, fold_frames && n_poses > 0));
 
             // |x|^2 of this rank's pose parameters (summed over ranks below) and of the replicated global block
             for (int a2 = 0; a2 < G; a2++) h_xg[a2] = ps[1 + a2];
