@@ -402,6 +402,42 @@ __global__ __launch_bounds__(256) void vg_gram_slab_sum_kernel(const double *__r
 }
 #endif
 
+// "The launch is over" for a SPINNING host (the host-driven LM loop reads what the sum kernels stored in pinned memory): every
+// workgroup makes its stores visible system-wide and counts itself; the last one stores the sequence number the host waits
+// for (system-scope release) and re-arms the counter.  hipStreamSynchronize costs ~3.5 us more per round trip
+// (tools/exp/host_wait.hip); host_seq = NULL: nothing happens.
+struct HostSignal {
+    unsigned int *counter = nullptr;         // device word, zero between launches
+    unsigned long long *host_seq = nullptr;  // pinned word
+    unsigned long long seq = 0;
+};
+
+__device__ __forceinline__ void signal_host_when_last(const HostSignal &h)
+{
+    if (!h.host_seq) return;
+    // The results went to fine-grained host memory (uncached on the device: a store is on its way to the host once it is
+    // acknowledged): waiting for this thread's stores is all a workgroup owes before it counts itself.  A system-scope fence
+    // here writes the L2 back in EVERY workgroup -- the rig's 800-workgroup partial-sum launch took 50 us longer with it.
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int done = __hip_atomic_fetch_add(h.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == gridDim.x - 1) {
+            __hip_atomic_store(h.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(h.host_seq, h.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+// the same report from a launch of its own behind a kernel with too many workgroups to count (one atomic per workgroup of the
+// rig's 800-workgroup partial-sum launch cost more than the runtime's wait saves)
+#ifdef VG_TU_SOLVER
+__global__ void vg_host_flag_kernel(HostSignal h)
+{
+    __hip_atomic_store(h.host_seq, h.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+#endif
+
 __device__ __forceinline__ void gram_final_sum_body(const double *__restrict__ in, unsigned int n_items, int entries,
                                                     double *__restrict__ out, unsigned int block)
 {

@@ -879,12 +879,30 @@ __device__ __forceinline__ void gram_partials_sum_entry(const PartialSumDataset 
 }
 
 #ifdef VG_TU_SOLVER  // this kernel is launched by one translation unit only; the others see the header without it
-__global__ __launch_bounds__(256) void vg_gram_partials_sum_multi_kernel(const PartialSumDataset *__restrict__ ds, int n_ds)
+// Optionally the last two workgroups of the launch add the five scalar sums of the LM step that led to this point (the body of
+// vg_step_scalars_kernel: same order, same bits) -- one launch less per iteration of the loops that need those sums outside
+// the accept kernel (host-driven loop, several ranks).
+struct StepScalarsArgs {
+    const double *in = nullptr;               // [n_items][5] per-workgroup partials of the back-substitution; NULL: no such workgroups
+    unsigned int n_items = 0;
+    double *out = nullptr;                    // [5]
+    const unsigned long long *gmax_bits = nullptr;
+    unsigned long long *gmax_out = nullptr;   // may be NULL
+    unsigned int first_block = 0;             // = the number of partial-sum workgroups in front
+};
+
+__global__ __launch_bounds__(256) void vg_gram_partials_sum_multi_kernel(const PartialSumDataset *__restrict__ ds, int n_ds, StepScalarsArgs sc)
 {
-    int d = 0;
-    while (d + 1 < n_ds && blockIdx.x >= ds[d + 1].first_block) d++;
-    const PartialSumDataset D = ds[d];
-    gram_partials_sum_entry(D);
+    if (sc.in && blockIdx.x >= sc.first_block) {
+        const unsigned int idx = blockIdx.x - sc.first_block;
+        gram_final_sum_body(sc.in, sc.n_items, 5, sc.out, idx);
+        if (idx == 1 && threadIdx.x == 0 && sc.gmax_out) *sc.gmax_out = *sc.gmax_bits;
+    } else {
+        int d = 0;
+        while (d + 1 < n_ds && blockIdx.x >= ds[d + 1].first_block) d++;
+        const PartialSumDataset D = ds[d];
+        gram_partials_sum_entry(D);
+    }
 }
 #endif
 
@@ -910,7 +928,7 @@ __global__ __launch_bounds__(256) void vg_gram_partials_sum_args_kernel(PartialS
 // blocks (the Gram of the pose rows per row group) are latency, not bandwidth.
 #ifdef VG_TU_SOLVER  // this kernel is launched by one translation unit only; the others see the header without it
 __global__ __launch_bounds__(256) void vg_gram_strided_sum_kernel(const double *__restrict__ in, unsigned int n_items, int entries,
-                                                                   double *__restrict__ out)
+                                                                   double *__restrict__ out, HostSignal done)
 {
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
     const int e = blockIdx.x;
@@ -930,6 +948,7 @@ __global__ __launch_bounds__(256) void vg_gram_strided_sum_kernel(const double *
     if (lane == 0) red[wave] = s;
     __syncthreads();
     if (tid == 0) out[e] = (red[0] + red[1]) + (red[2] + red[3]);
+    signal_host_when_last(done);
 }
 #endif
 
@@ -938,7 +957,7 @@ __global__ __launch_bounds__(256) void vg_gram_strided_sum_kernel(const double *
 // partial sums of an entry are added in a fixed order.
 #ifdef VG_TU_SOLVER  // this kernel is launched by one translation unit only; the others see the header without it
 __global__ __launch_bounds__(256) void vg_gram_strided_sum_tiled_kernel(const double *__restrict__ in, unsigned int n_items, int entries,
-                                                                         double *__restrict__ out)
+                                                                         double *__restrict__ out, HostSignal done)
 {
     const int tid = threadIdx.x, el = tid & 15, il = tid >> 4;
     const int e = blockIdx.x * 16 + el;
@@ -962,14 +981,15 @@ __global__ __launch_bounds__(256) void vg_gram_strided_sum_tiled_kernel(const do
         for (int q = 0; q < 16; q++) t += red[q][tid];
         out[blockIdx.x * 16 + tid] = t;
     }
+    signal_host_when_last(done);
 }
 #endif
 
 #ifdef VG_TU_SOLVER
-inline void launch_strided_sum(hipStream_t st, const double *in, unsigned int n_items, int entries, double *out)
+inline void launch_strided_sum(hipStream_t st, const double *in, unsigned int n_items, int entries, double *out, HostSignal done = HostSignal())
 {
-    if (entries <= 256) hipLaunchKernelGGL(vg_gram_strided_sum_kernel, dim3(entries), dim3(256), 0, st, in, n_items, entries, out);
-    else hipLaunchKernelGGL(vg_gram_strided_sum_tiled_kernel, dim3((entries + 15) / 16), dim3(256), 0, st, in, n_items, entries, out);
+    if (entries <= 256) hipLaunchKernelGGL(vg_gram_strided_sum_kernel, dim3(entries), dim3(256), 0, st, in, n_items, entries, out, done);
+    else hipLaunchKernelGGL(vg_gram_strided_sum_tiled_kernel, dim3((entries + 15) / 16), dim3(256), 0, st, in, n_items, entries, out, done);
 }
 #endif
 

@@ -428,6 +428,42 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
         std::memset(pin_small.p, 0, sizeof(double) * ((size_t)2 * G + 2));
     }
     d_scal_sum.p = sums_out + n_sums;
+    // The host-driven loop on one rank does not wait through the runtime for the two read-backs of an iteration: a sequence
+    // number lands in pinned memory and the host spins on it -- hipStreamSynchronize costs ~3.5 us more per round trip
+    // (tools/exp/host_wait.hip).  The strided sum of the pose elimination (133 workgroups at G = 45) stores it when its last
+    // workgroup is done (vg::HostSignal); behind an evaluation, whose last launch has 800 workgroups at the rig's size (an atomic
+    // each cost more than the wait saves), a one-thread kernel does.  Rig, same box: 0.163-0.170 -> 0.157-0.158 ms per iteration.
+    // vg_debug_set("solver_event_wait", 1): the runtime's wait (A/B).
+    const bool host_spin = host_direct && !vgi::debug_hook(vgi::kHookSolverEventWait);
+    PinnedBuf pin_seq;
+    DevBuf<unsigned int> d_sigcnt;
+    unsigned long long seq_issued[2] = {0ull, 0ull};
+    if (host_spin) {
+        VG_TRY(pin_seq.alloc(2));
+        VG_TRY(d_sigcnt.alloc(2));
+        VG_HIP(hipMemsetAsync(d_sigcnt.p, 0, sizeof(unsigned int) * 2, st));
+        std::memset(pin_seq.p, 0, sizeof(double) * 2);
+    }
+    auto host_signal = [&](int which) {   // 0: evaluation, 1: pose elimination
+        vg::HostSignal h;
+        h.counter = d_sigcnt.p + which;
+        h.host_seq = reinterpret_cast<unsigned long long *>(pin_seq.p) + which;
+        h.seq = ++seq_issued[which];
+        return h;
+    };
+    auto host_wait = [&](int which) -> int {
+        volatile unsigned long long *w = reinterpret_cast<volatile unsigned long long *>(pin_seq.p) + which;
+        const double t_spin = now_s();
+        unsigned long spins = 0;
+        while (*w != seq_issued[which]) {
+            if ((++spins & 0xfffff) == 0 && now_s() - t_spin > 30.) {   // the device is gone or a launch failed: do not hang
+                VG_HIP(hipStreamSynchronize(st));
+                if (*w != seq_issued[which]) return fail(VG_ERR_STATE, "a sum kernel of an LM iteration never reported");
+            }
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        return VG_OK;
+    };
 
     mark("scratch + pinned allocation");
     // several datasets: their fixed-order sums run as ONE slab launch and ONE final launch (descriptor tables for
@@ -488,8 +524,16 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
     }
     // queue the evaluation of the Gram matrices at a device parameter buffer into gram set `set`, their fixed-order sums
     // into d_sums and the ONE collective of an evaluation (no host synchronisation)
-    auto enqueue_evaluate = [&](const double *x_dev, DevBuf<double> *set, bool frames_ready = false) -> int {
+    // `step_scalars`: the five scalar sums of the step that led to x_dev (+ its max |g_pose| to `gmax_out`) are wanted with this
+    // evaluation: added by two more workgroups of the partial-sum launch when there is one, by vg_step_scalars_kernel otherwise
+    auto enqueue_evaluate = [&](const double *x_dev, DevBuf<double> *set, bool frames_ready = false, bool step_scalars = false,
+                                unsigned long long *gmax_out = nullptr) -> int {
         int r;
+        if (step_scalars && !use_partials) {
+            hipLaunchKernelGGL(vg::vg_step_scalars_kernel, dim3(2), dim3(256), 0, st, (const double *)d_scal.p, n_bs_groups, d_scal_sum.p,
+                               (const unsigned long long *)d_gmax.p, gmax_out);
+            VG_HIP(hipGetLastError());
+        }
         if (vgi::gram_needs_frames(p) && !frames_ready && (r = vgi::prepare_at(p, x_dev)) != VG_OK) return r;
         // several datasets: the ones the vector-pipe kernel takes share one launch
         std::vector<char> merged((size_t)n_ds, 0);
@@ -515,8 +559,17 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             if (!sum_slab_blocks && !fused_sum && (r = vgi::gram_sum_into(p, d, set[d].p, sum_d)) != VG_OK) return r;
         }
         if (use_partials) {
-            hipLaunchKernelGGL(vg::vg_gram_partials_sum_multi_kernel, dim3(psum_blocks), dim3(256), 0, st,
-                               (const vg::PartialSumDataset *)d_psum.p, n_psum);
+            vg::StepScalarsArgs ssa;
+            if (step_scalars) {
+                ssa.in = d_scal.p;
+                ssa.n_items = n_bs_groups;
+                ssa.out = d_scal_sum.p;
+                ssa.gmax_bits = d_gmax.p;
+                ssa.gmax_out = gmax_out;
+                ssa.first_block = psum_blocks;
+            }
+            hipLaunchKernelGGL(vg::vg_gram_partials_sum_multi_kernel, dim3(psum_blocks + (step_scalars ? 2u : 0u)), dim3(256), 0, st,
+                               (const vg::PartialSumDataset *)d_psum.p, n_psum, ssa);
             VG_HIP(hipGetLastError());
         } else if (sum_slab_blocks) {
             const vg::SumDataset *tab = set == gramA ? d_sumA.p : d_sumB.p;
@@ -541,19 +594,29 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
     };
     // evaluate at a device parameter buffer and assemble U / gg / cost on the host
     auto evaluate = [&](const double *x_dev, DevBuf<double> *set, std::vector<double> &Uo, std::vector<double> &go,
-                        double &cost2, bool frames_ready = false) -> int {
+                        double &cost2, bool frames_ready = false, bool step_scalars = false, unsigned long long *gmax_out = nullptr) -> int {
         const double t0 = now_s();
         int r;
-        if ((r = enqueue_evaluate(x_dev, set, frames_ready)) != VG_OK) return r;
+        const bool spin = host_spin;   // a one-thread kernel behind the evaluation reports (see host_spin)
+        r = enqueue_evaluate(x_dev, set, frames_ready, step_scalars, gmax_out);
+        if (r != VG_OK) return r;
+        if (spin) {
+            hipLaunchKernelGGL(vg::vg_host_flag_kernel, dim3(1), dim3(1), 0, st, host_signal(0));
+            VG_HIP(hipGetLastError());
+        }
         if (!host_direct) VG_HIP(hipMemcpyAsync(pin_sums.p, d_sums.p, sizeof(double) * h_sums.size(), hipMemcpyDeviceToHost, st));
-        VG_HIP(hipStreamSynchronize(st));
-        std::memcpy(h_sums.data(), pin_sums.p, sizeof(double) * h_sums.size());
+        if (spin) {
+            if ((r = host_wait(0)) != VG_OK) return r;
+        } else {
+            VG_HIP(hipStreamSynchronize(st));
+        }
+        // (read where the device wrote it: no staging copy of the 17 KB a rig's blocks are)
         std::fill(Uo.begin(), Uo.end(), 0.);
         std::fill(go.begin(), go.end(), 0.);
         cost2 = 0.;
         for (int d = 0; d < n_ds; d++) {
             const int W = Wd[d];
-            const double *Sd = h_sums.data() + (size_t)d * Wmax * Wmax;
+            const double *Sd = pin_sums.p + (size_t)d * Wmax * Wmax;
             for (int a2 = 0; a2 < W - 1; a2++) {
                 const int ga = lmap[d][a2];
                 if (ga < 0) continue;
@@ -820,14 +883,10 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
                 else hipLaunchKernelGGL(vg::vg_backsub_kernel<8>, dim3(bs_grid), dim3(vg::kBsThreads), 0, st, ba);
                 VG_HIP(hipGetLastError());
             }
-            if (n_bs_groups && multi_rank) {  // part of the evaluation's packed all-reduce; one rank: the accept kernel sums them
-                hipLaunchKernelGGL(vg::vg_step_scalars_kernel, dim3(2), dim3(256), 0, st, (const double *)d_scal.p, n_bs_groups, d_scal_sum.p,
-                                   (const unsigned long long *)nullptr, (unsigned long long *)nullptr);   // the same fixed-order sum of 5 entries
-                VG_HIP(hipGetLastError());
-            }
             p->gram_gate = gate;
             p->gram_gate_expect = par;
-            const int re = enqueue_evaluate(xbuf[1 - par], gset[1 - par], fold_frames && n_poses > 0);
+            // several ranks: the step's scalar sums are part of the evaluation's packed all-reduce (one rank: the accept kernel sums them)
+            const int re = enqueue_evaluate(xbuf[1 - par], gset[1 - par], fold_frames && n_poses > 0, n_bs_groups && multi_rank);
             p->gram_gate = nullptr;
             if (re != VG_OK) return re;
             vg::LmAcceptArgs a2 = aa;
@@ -1006,7 +1065,12 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
         sa.rec = d_rec.p;
         sa.rows = d_rows.p;
         sa.bad = d_bad;
-        std::fill(h_rgram.begin(), h_rgram.end(), 0.);
+        // the Schur complement is read where the device wrote it when this rank's kernels deliver it straight to pinned memory;
+        // otherwise (all-reduce callback, no poses) from the staging vector
+        const bool rgram_in_place = host_direct && n_poses > 0;
+        if (!rgram_in_place) std::fill(h_rgram.begin(), h_rgram.end(), 0.);
+        const double *rg = rgram_in_place ? pin_rgram.p : h_rgram.data();
+        const bool schur_spin = host_spin && n_poses > 0 && coupled.empty();
         bool coupled_ok = true;
         if (n_poses) {
             if (coupled.empty()) {
@@ -1045,7 +1109,8 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
                 VG_HIP(hipStreamSynchronize(st));  // c2.Y may be rewritten before an async copy from pageable memory ends
             }
             if (coupled.empty()) {
-                vg::launch_strided_sum(st, d_rgroups.p, sg_wgs, C * C + 1, host_direct ? pin_rgram.p : d_rgram.p);
+                vg::launch_strided_sum(st, d_rgroups.p, sg_wgs, C * C + 1, host_direct ? pin_rgram.p : d_rgram.p,
+                                       schur_spin ? host_signal(1) : vg::HostSignal());
             } else {
                 VG_TRY(launch_dense_gram(st, d_rows.p, n_rows, C, rows_per_group, n_groups, d_rgroups.p));
                 vg::launch_strided_sum(st, d_rgroups.p, n_groups, C * C, d_rgram.p);
@@ -1059,27 +1124,28 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
                 VG_TRY(vgc::allreduce_sum(comm, d_rgram.p, h_rgram.size(), st));  // Schur complement of the poses of all ranks
                 VG_HIP(hipMemcpyAsync(pin_rgram.p, d_rgram.p, sizeof(double) * h_rgram.size(), hipMemcpyDeviceToHost, st));
             }
-            VG_HIP(hipStreamSynchronize(st));
-            std::memcpy(h_rgram.data(), pin_rgram.p, sizeof(double) * h_rgram.size());
+            if (schur_spin) VG_TRY(host_wait(1));
+            else VG_HIP(hipStreamSynchronize(st));
+            if (!rgram_in_place) std::memcpy(h_rgram.data(), pin_rgram.p, sizeof(double) * h_rgram.size());
         }
-        VG_TRY(allreduce(h_rgram));
+        if (opt.allreduce) VG_TRY(allreduce(h_rgram));   // (host_direct excludes the callback: rg stays valid)
         // poses whose damped 6 x 6 block was not positive definite (NaN / Inf in their Gram block): the step is invalid
         // as a whole -- rejected like a failed factorisation of the reduced system, and counted.  The count is the one
         // summed over ALL ranks (last slot of the buffer): a rank-local decision here would make this rank skip the
         // collectives of the candidate evaluation while the others enter them.
-        if (h_rgram[(size_t)C * C] > 0.) {
+        if (rg[(size_t)C * C] > 0.) {
             coupled_ok = false;
-            n_bad_pose_blocks += (long long)h_rgram[(size_t)C * C];
+            n_bad_pose_blocks += (long long)rg[(size_t)C * C];
         }
         t_schur += now_s() - t0;
 
         // ---- reduced system on the host
         t0 = now_s();
         for (int a2 = 0; a2 < G; a2++) {
-            for (int b2 = 0; b2 < G; b2++) S[(size_t)a2 * G + b2] = U[(size_t)a2 * G + b2] - h_rgram[(size_t)a2 * C + b2];
+            for (int b2 = 0; b2 < G; b2++) S[(size_t)a2 * G + b2] = U[(size_t)a2 * G + b2] - rg[(size_t)a2 * C + b2];
             const double dd = U[(size_t)a2 * G + a2];
             S[(size_t)a2 * G + a2] += mu * (dd < opt.min_lm_diagonal ? opt.min_lm_diagonal : (dd > opt.max_lm_diagonal ? opt.max_lm_diagonal : dd));
-            rhs[a2] = -gg[a2] + h_rgram[(size_t)a2 * C + G];
+            rhs[a2] = -gg[a2] + rg[(size_t)a2 * C + G];
         }
         // Constant blocks, and the active set of the box bounds: a parameter sitting ON a bound whose step points
         // outwards is held for this iteration (its row / column leave the reduced system -- the Schur complement of
@@ -1143,11 +1209,8 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
                 else hipLaunchKernelGGL(vg::vg_backsub_kernel<8>, dim3(bs_grid), dim3(vg::kBsThreads), 0, st, ba);
                 VG_HIP(hipGetLastError());
             }
-            if (n_bs_groups) {  // fixed-order sum of the per-workgroup partials (and, host_direct, max |g_pose| to the host)
-                hipLaunchKernelGGL(vg::vg_step_scalars_kernel, dim3(2), dim3(256), 0, st, (const double *)d_scal.p, n_bs_groups, d_scal_sum.p,
-                                   (const unsigned long long *)d_gmax.p, host_direct ? reinterpret_cast<unsigned long long *>(ps) : nullptr);
-                VG_HIP(hipGetLastError());
-            }
+            // (the fixed-order sum of the back-substitution's per-workgroup partials and, host_direct, max |g_pose| to the host:
+            //  with the candidate's evaluation below)
             double host_scal[5] = {0., 0., 0., 0., 0.};
             for (auto &c2 : coupled) {
                 std::vector<double> dp;
@@ -1174,11 +1237,12 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             // No wait here: the candidate evaluation does not depend on these scalars, it is queued right behind the
             // step on the same stream, and its own read-back synchronises once for both (one host round trip per
             // iteration less; the wait is booked under "evaluate").
-            VG_TRY(evaluate(d_xc.p, cand, Uc, ggc, cost2_c, fold_frames && n_poses > 0));
+            VG_TRY(evaluate(d_xc.p, cand, Uc, ggc, cost2_c, fold_frames && n_poses > 0, n_bs_groups > 0,
+                            host_direct ? reinterpret_cast<unsigned long long *>(ps) : nullptr));
 
             // |x|^2 of this rank's pose parameters (summed over ranks below) and of the replicated global block
             for (int a2 = 0; a2 < G; a2++) h_xg[a2] = ps[1 + a2];
-            const double *sc = h_sums.data() + n_sums;  // scalar sums of the step, already summed over ranks with an RCCL communicator
+            const double *sc = pin_sums.p + n_sums;  // scalar sums of the step, already summed over ranks with an RCCL communicator
             double xg2 = 0.;
             for (int a2 = 0; a2 < G; a2++) xg2 += h_xg[a2] * h_xg[a2];
             double gdp = sc[0] + host_scal[0], ddp = sc[1] + host_scal[1], dp2 = sc[2] + host_scal[2],
@@ -1199,6 +1263,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
                 }
             }
             {
+                if (opt.allreduce) {   // (no callback: nothing to pack, sum and unpack)
                 std::vector<double> pack(Uc);
                 pack.insert(pack.end(), ggc.begin(), ggc.end());
                 pack.push_back(cost2_c);
@@ -1218,6 +1283,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
                 dp2 = pack[o + 3];
                 gp2 = pack[o + 4];
                 xp2 = pack[o + 5];
+                }
                 // The callback only sums.  With several ranks every rank must take the same branches, so the
                 // pose part of the gradient max-norm is replaced by its (summable) 2-norm, an upper bound:
                 // the gradient test can only fire later than Ceres' max-norm test, never earlier.
