@@ -4,8 +4,10 @@
 // src/calibration/unified_calibration.cpp:42-53 for the options).  With them an iteration is a fixed sequence of
 // launches (+ two in-place RCCL all-reduces when sharded) and ONE host synchronisation -- the host only learns whether
 // the step was accepted (it swaps the current / candidate buffers) and whether the solve is over.
-// Both kernels are one workgroup: G <= 127 global columns.  Same arithmetic, in the same order, as the host versions
-// they replace (chol_solve and the loop body of vg_problem_solve), so both loops walk the same iterates.
+// Both kernels are one workgroup: G <= 127 global columns.  The acceptance logic is the host loop's; the reduced solve up to 63
+// columns is an L D L^T without square roots (lm_entry_solve_body) where the host runs a Cholesky: the two loops agree to
+// rounding, not bit for bit -- with the reference's tolerances of 1e-15 (unified_calibration.cpp:47-49, below the noise of a
+// cost summed over 10^6 residuals) the number of iterations at the tail of a solve differs between them, the optimum does not.
 #pragma once
 
 #include "vg_solver.hpp"
@@ -35,6 +37,7 @@ struct LmSolveArgs {
     int G, use_bounds;
     int gate_expect;                   // run only if st->gate == gate_expect (-1: no test)
     double dmin, dmax;
+    int one_wave = 0;                  // vg_backsub_solve_kernel: the first wave alone, a row per lane (the route before round 4; A/B hook)
 };
 
 constexpr int kLmThreads = 256;
@@ -211,7 +214,7 @@ __host__ __device__ inline size_t lm_entry_solve_lds_doubles(int G)
 #ifdef VG_SOLVE_STAMPS
 #define VG_SOLVE_STAMP(i)                                                                  \
     do {                                                                                   \
-        if (threadIdx.x == 0) reinterpret_cast<long long *>(a.S)[i] = (long long)clock64(); \
+        if (threadIdx.x == 0 && a.S) reinterpret_cast<long long *>(a.S)[i] = (long long)clock64(); \
     } while (0)
 #else
 #define VG_SOLVE_STAMP(i) \
@@ -219,13 +222,13 @@ __host__ __device__ inline size_t lm_entry_solve_lds_doubles(int G)
     } while (0)
 #endif
 
-#ifdef VG_TU_SOLVER  // this kernel is launched by one translation unit only; the others see the header without it
-__global__ __launch_bounds__(kEntryThreads) void vg_lm_reduced_solve_entries_kernel(LmSolveArgs a)
+// The solve itself, by ALL kT threads of a workgroup (kSlots entries per thread at most); returns where the step lies in LDS;
+// `publish`: also to a.dg / st->step_ok.  Used by the stand-alone kernel below (1024 threads, up to 63 columns) and by
+// vg_backsub_solve_kernel (every back-substitution workgroup solves the system itself: 256 threads, up to kFoldMaxG columns).
+template <int kT, int kSlots>
+__device__ __forceinline__ double *lm_entry_solve_body(const LmSolveArgs &a, double *sm, const bool publish)
 {
-    extern __shared__ __attribute__((aligned(16))) double sm[];
     LmState *st = a.st;
-    VG_SOLVE_STAMP(0);
-    if (st->done || (a.gate_expect >= 0 && st->gate != a.gate_expect)) return;
     const int G = a.G, C = G + 1, E = C * (C + 1) / 2, tid = threadIdx.x, P = lm_entry_solve_stride(G);
     double *A = sm, *F = A + C * P, *S = F + C * P, *x = S + E, *heldf = x + G, *flag = heldf + G;
     const double mu = st->mu;
@@ -234,17 +237,17 @@ __global__ __launch_bounds__(kEntryThreads) void vg_lm_reduced_solve_entries_ker
     // rows <= j alone, so the waves of the high thread numbers finish first -- a finished wave only joins the step's barrier
     // (the pivot arithmetic every wave repeats is a third of a step's instructions) -- and wave 0, which also runs the
     // substitution, sees every pivot.
-    int ri[kEntrySolveSlots], ck[kEntrySolveSlots], last_row[kEntrySolveSlots];   // last_row: highest row of the slot, uniform
+    int ri[kSlots], ck[kSlots], last_row[kSlots];   // last_row: highest row of the slot, uniform
 #pragma unroll
-    for (int m = 0; m < kEntrySolveSlots; m++) last_row[m] = entry_row(E - 2 - kEntryThreads * m);
+    for (int m = 0; m < kSlots; m++) last_row[m] = entry_row(E - 2 - kT * m);
     const int wave_last_row = __builtin_amdgcn_readfirstlane(entry_row(E - 2 - (tid & ~(kWave - 1))));   // highest row of this wave
     {
         // every global load of the kernel is requested before the first one is used (a slot after the other: a dependent L2 round
         // trip per slot); invalid slots load entry (0, 0)
-        double u_v[kEntrySolveSlots], r_v[kEntrySolveSlots];
+        double u_v[kSlots], r_v[kSlots];
 #pragma unroll
-        for (int m = 0; m < kEntrySolveSlots; m++) {
-            const int e = E - 2 - (tid + kEntryThreads * m);   // (G, G), entry E - 1, is not used
+        for (int m = 0; m < kSlots; m++) {
+            const int e = E - 2 - (tid + kT * m);   // (G, G), entry E - 1, is not used
             const bool valid = e >= 0;
             const int i = valid ? entry_row(e) : 0;
             const int k = e - i * (i + 1) / 2;
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(kEntryThreads) void vg_lm_reduced_solve_entries_ker
             r_v[m] = il < G ? a.rgram[(size_t)il * C + kl] : a.rgram[(size_t)kl * C + G];
         }
 #pragma unroll
-        for (int m = 0; m < kEntrySolveSlots; m++) {
+        for (int m = 0; m < kSlots; m++) {
             if (ri[m] < 0) continue;
             double v;
             if (ri[m] < G) {
@@ -264,7 +267,7 @@ __global__ __launch_bounds__(kEntryThreads) void vg_lm_reduced_solve_entries_ker
             } else {
                 v = -u_v[m] + r_v[m];
             }
-            S[tid + kEntryThreads * m] = v;
+            S[tid + kT * m] = v;
         }
     }
     // the box test of the active set, per column (first wave): everything it reads from global memory, once
@@ -283,11 +286,11 @@ __global__ __launch_bounds__(kEntryThreads) void vg_lm_reduced_solve_entries_ker
     for (int pass = 0; pass <= G; pass++) {
         // constant blocks and the active set of the box bounds leave the system (unit row / column, zero right-hand side)
 #pragma unroll
-        for (int m = 0; m < kEntrySolveSlots; m++) {
+        for (int m = 0; m < kSlots; m++) {
             if (ri[m] < 0) continue;
             const int i = ri[m], k = ck[m];
             const bool h = (i < G && heldf[i] != 0.) || heldf[k] != 0.;
-            A[i * P + k] = h ? ((i == k) ? 1. : 0.) : S[tid + kEntryThreads * m];
+            A[i * P + k] = h ? ((i == k) ? 1. : 0.) : S[tid + kT * m];
         }
         if (tid == 0) flag[0] = 0.;
         __syncthreads();
@@ -304,10 +307,10 @@ __global__ __launch_bounds__(kEntryThreads) void vg_lm_reduced_solve_entries_ker
                 continue;
             }
             const double d0 = A[j * P + j], b = A[(j + 1) * P + j], d1raw = A[(j + 1) * P + j + 1];
-            double ai0[kEntrySolveSlots], ak0[kEntrySolveSlots], oi1[kEntrySolveSlots], ok1[kEntrySolveSlots], aik[kEntrySolveSlots];
-            bool act[kEntrySolveSlots];
+            double ai0[kSlots], ak0[kSlots], oi1[kSlots], ok1[kSlots], aik[kSlots];
+            bool act[kSlots];
 #pragma unroll
-            for (int m = 0; m < kEntrySolveSlots; m++) {
+            for (int m = 0; m < kSlots; m++) {
                 act[m] = false;
                 if (last_row[m] <= j) continue;   // uniform over the workgroup
                 act[m] = ri[m] >= 0 && ck[m] > j;
@@ -327,7 +330,7 @@ __global__ __launch_bounds__(kEntryThreads) void vg_lm_reduced_solve_entries_ker
             const double r1 = d0 * rcp_pos(det > 0. ? det : 1.);
             const double l = b * r0;
 #pragma unroll
-            for (int m = 0; m < kEntrySolveSlots; m++) {
+            for (int m = 0; m < kSlots; m++) {
                 if (!act[m]) continue;
                 const double ai1 = fma(-ai0[m], l, oi1[m]);
                 if (ck[m] == j + 1) {
@@ -373,18 +376,32 @@ __global__ __launch_bounds__(kEntryThreads) void vg_lm_reduced_solve_entries_ker
         if (flag[0] == 0. || flag[1] == 0.) break;
         __syncthreads();   // everybody has read the flag before the next pass clears it
     }
-    if (tid < G) a.dg[tid] = x[tid];
-    if (tid == 0) st->step_ok = (G == 0 || ok) ? 1 : 0;
+    if (publish) {
+        if (tid < G) a.dg[tid] = x[tid];
+        if (tid == 0) st->step_ok = (G == 0 || ok) ? 1 : 0;
+    }
     VG_SOLVE_STAMP(11);
+    return x;
+}
+
+#ifdef VG_TU_SOLVER  // this kernel is launched by one translation unit only; the others see the header without it
+__global__ __launch_bounds__(kEntryThreads) void vg_lm_reduced_solve_entries_kernel(LmSolveArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    LmState *st = a.st;
+    VG_SOLVE_STAMP(0);
+    if (st->done || (a.gate_expect >= 0 && st->gate != a.gate_expect)) return;
+    lm_entry_solve_body<kEntryThreads, kEntrySolveSlots>(a, sm, true);
 }
 #endif
 
 // Narrow reduced systems (a mono or stereo calibration: G <= kFoldMaxG): EVERY workgroup of the back-substitution solves
-// the G x G system itself (its first wave, in LDS, the arithmetic of vg_lm_reduced_solve_kernel: every workgroup gets the
-// same bits) and goes on with the step in LDS -- one launch and one dependent round trip through HBM less per iteration; a
-// 6 x 6 .. 24 x 24 Cholesky is a few microseconds of one wave next to the launch it replaces.  Workgroup 0 publishes the
-// step and step_ok.
+// the G x G system itself (all 256 threads, lm_entry_solve_body in LDS: every workgroup gets the same bits) and goes on with
+// the step in LDS -- one launch and one dependent round trip through HBM less per iteration.  Workgroup 0 publishes the step
+// and step_ok.  Until round 4 the first wave did it alone with a row per lane: 17 of this kernel's 33.7 us for the stereo problem
+// (G = 18), where the 256-thread L D L^T needs ~3; same box, per LM iteration: stereo 0.111 -> 0.094 ms, Mei (G = 10) 0.101 -> 0.090.
 constexpr int kFoldMaxG = 24;
+constexpr int kFoldSlots = ((kFoldMaxG + 1) * (kFoldMaxG + 2) / 2 + kBsThreads - 1) / kBsThreads;   // 2
 
 template <int kJ>
 __global__ __launch_bounds__(kBsThreads) void vg_backsub_solve_kernel(BacksubArgs b, LmSolveArgs a)
@@ -393,9 +410,17 @@ __global__ __launch_bounds__(kBsThreads) void vg_backsub_solve_kernel(BacksubArg
     LmState *st = a.st;
     if (st->done || (a.gate_expect >= 0 && st->gate != a.gate_expect)) return;
     if (gate_closed(b.s.gate, b.s.gate_expect)) return;
-    if (threadIdx.x < kWave) lm_reduced_solve_body(a, sm, threadIdx.x, kWave, blockIdx.x == 0);
+    // (round 4: the entry-parallel L D L^T on all 256 threads; before, the first wave alone with a row per lane -- 17 of the
+    //  stereo problem's 33.7 us in this kernel at G = 18)
+    const double *step;
+    if (a.one_wave) {
+        if (threadIdx.x < kWave) lm_reduced_solve_body(a, sm, threadIdx.x, kWave, blockIdx.x == 0);
+        step = sm + (size_t)a.G * a.G + 2 * a.G;
+    } else {
+        step = lm_entry_solve_body<kBsThreads, kFoldSlots>(a, sm, blockIdx.x == 0);
+    }
     __syncthreads();
-    backsub_body<kJ>(b, sm + (size_t)a.G * a.G + 2 * a.G);
+    backsub_body<kJ>(b, step);
 }
 
 struct LmAcceptArgs {

@@ -877,8 +877,9 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
                 const unsigned int bs_grid = n_bs_groups ? n_bs_groups : 1u;
                 if (fold_solve) {
                     r2.S = nullptr;  // the damped matrix in every workgroup's own LDS
+                    r2.one_wave = vgi::debug_hook(vgi::kHookSolverOneWaveFold) ? 1 : 0;
                     hipLaunchKernelGGL(vg::vg_backsub_solve_kernel<4>, dim3(bs_grid), dim3(vg::kBsThreads),
-                                       sizeof(double) * (2 * (size_t)G * G + 4 * (size_t)G + 2), st, ba, r2);
+                                       sizeof(double) * std::max(vg::lm_entry_solve_lds_doubles(G), 2 * (size_t)G * G + 4 * (size_t)G + 2), st, ba, r2);
                 } else if (G < 64) hipLaunchKernelGGL(vg::vg_backsub_kernel<4>, dim3(bs_grid), dim3(vg::kBsThreads), 0, st, ba);
                 else hipLaunchKernelGGL(vg::vg_backsub_kernel<8>, dim3(bs_grid), dim3(vg::kBsThreads), 0, st, ba);
                 VG_HIP(hipGetLastError());
