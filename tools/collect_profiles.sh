@@ -20,6 +20,7 @@ if [ -f gpurun_out/prof_solve_rig_$T.txt ]; then
   { echo "# LM loops per kernel, rocprofv3 --kernel-trace --stats, tag $T (tools/exp/prof_solve.sh)"; echo
     echo "## config 5 (rig, 5000 frames), host-driven loop"; echo '```'; grep -v "^[EW]2026\|amdgpu.ids" gpurun_out/prof_solve_rig_$T.txt | cut -c1-140; echo '```'
     if [ -f gpurun_out/prof_solve_eucm_$T.txt ]; then echo; echo "## EUCM mono, 10000 images, device-resident loop"; echo '```'; grep -v "^[EW]2026\|amdgpu.ids" gpurun_out/prof_solve_eucm_$T.txt | cut -c1-140; echo '```'; fi
+    if [ -f gpurun_out/prof_solve_stereo_$T.txt ]; then echo; echo "## config 3 (stereo, 2000 pairs), device-resident loop"; echo '```'; grep -v "^[EW]2026\|amdgpu.ids" gpurun_out/prof_solve_stereo_$T.txt | cut -c1-140; echo '```'; fi
   } > profiles/${T}_lm_loops.md
 fi
 cat profiles/${T}_pytest_gpu_tail.txt
