@@ -71,6 +71,7 @@ struct SchurArgs {
                            // Schur Gram (rgram[(G+1)^2]), so that it is summed over ranks by that buffer's all-reduce
     const int *gate;       // speculative launches of the device loop: run only if *gate == gate_expect (NULL: always)
     int gate_expect;
+    int n_ds = 0;          // entries of `ds` (vg_schur_rows_gram_kernel keeps up to kSchurLdsDatasets of them in LDS; 0: reads them from memory)
     unsigned long long *zero_u64 = nullptr;  // vg_schur_rows_gram_kernel clears this word (the max |g_pose| of the step that
                                              // follows): no memset command between two kernels of the host-driven loop
 };
@@ -87,11 +88,12 @@ struct PoseFactor {
 
 // damping + 6 x 6 Cholesky of a pose block whose V_i (packed lower, 21) and g_i (6) have been gathered; has_refs: the pose
 // is referenced by at least one residual block
-__device__ __forceinline__ void pose_factor_from(const SchurArgs &a, int i, double (&V)[21], bool has_refs, PoseFactor &f)
+// (mode = a.pose_frozen[i] and mu are arguments so that a caller can request them with its first loads)
+__device__ __forceinline__ void pose_factor_from(const SchurArgs &a, unsigned char mode, double mu, double (&V)[21], bool has_refs, PoseFactor &f)
 {
     // pose_frozen: 0 = eliminated here, 1 = constant, 2 = belongs to a sequence coupled by OdometryPrior blocks:
     // its raw V_i / g_i go to the record and the host eliminates the whole sequence as a block-tridiagonal system
-    f.mode = a.pose_frozen[i];
+    f.mode = mode;
     f.pd = true;
     if (f.mode == 2) {
 #pragma unroll
@@ -102,7 +104,6 @@ __device__ __forceinline__ void pose_factor_from(const SchurArgs &a, int i, doub
         return;
     }
     f.active = f.mode == 0 && has_refs;
-    const double mu = a.mu_dev ? *a.mu_dev : a.mu;
 #pragma unroll
     for (int r = 0; r < 6; r++) {
         f.vd[r] = V[tri(r, r)];
@@ -146,7 +147,7 @@ __device__ __forceinline__ void pose_factor(const SchurArgs &a, int i, PoseFacto
             f.gp[r] += Gb[(o + r) * D.W + D.W - 1];
         }
     }
-    pose_factor_from(a, i, V, r1 > r0, f);
+    pose_factor_from(a, a.pose_frozen[i], a.mu_dev ? *a.mu_dev : a.mu, V, r1 > r0, f);
 }
 
 // one lane per (pose, global column): column gcol of the six rows  L^-1 W_i^T  (gcol == G: L^-1 g_i; that lane also
@@ -212,6 +213,7 @@ __global__ __launch_bounds__(256) void vg_schur_rows_kernel(SchurArgs a)
 constexpr int kSchurThreads = 256;      // lanes of one batch: (pose of the batch, column)
 constexpr int kSchurMaxBatches = 4;    // batches of a workgroup run side by side: blockDim.x = kSchurThreads * batches
 constexpr int kSchurMaxRefs = 256;     // references of a workgroup's poses resolved into LDS (beyond: read per lane from memory)
+constexpr int kSchurLdsDatasets = 32;  // dataset descriptors kept in LDS (requested with the kernel's first loads)
 
 #ifdef VG_TU_SOLVER  // this kernel is launched by one translation unit only; the others see the header without it
 __global__ __launch_bounds__(kSchurThreads * kSchurMaxBatches) void vg_schur_rows_gram_kernel(SchurArgs a, int poses_per_wg, int batches,
@@ -220,6 +222,32 @@ __global__ __launch_bounds__(kSchurThreads * kSchurMaxBatches) void vg_schur_row
 {
     extern __shared__ __attribute__((aligned(16))) double sm_rows[];  // [batches * poses_per_wg * 6][C + 1] (odd-ish stride)
     const int C = a.G + 1, CS = C + 1, tid = threadIdx.x % kSchurThreads;
+    const int pl = tid / C, gcol = tid - pl * C;        // pose of the batch, column
+    const bool lane_on = pl < poses_per_wg;
+    // every batch has its own 256 lanes (blockDim.x = kSchurThreads * batches): the chains pose -> reference list -> Gram
+    // blocks -> factorisation of the batches overlap instead of following one another (four in a row were 13 us of a wave's
+    // life, 73 % of it waiting)
+    const int bt = threadIdx.x / kSchurThreads;
+    const int i = (blockIdx.x * batches + bt) * poses_per_wg + pl;
+    const bool pose_on = lane_on && bt < batches && i < a.n_poses;
+    // ---- the kernel's FIRST round of loads, all of them requested before the gate is tested: the gate itself, the bounds of the
+    // workgroup's and of this lane's reference lists, the pose's mode, the damping parameter, the dataset descriptors (to LDS).
+    // Each used to be its own dependent round trip at the place it was needed (~1 us each with one workgroup per CU).
+    const int i_first = blockIdx.x * batches * poses_per_wg;
+    int i_end = i_first + batches * poses_per_wg;
+    i_end = i_end < a.n_poses ? i_end : a.n_poses;
+    const int q_first = a.ref_ptr[i_first < a.n_poses ? i_first : a.n_poses], q_end = a.ref_ptr[i_end > i_first ? i_end : i_first];
+    int r0 = 0, r1 = 0;
+    unsigned char pose_mode = 0;
+    if (pose_on) {
+        r0 = a.ref_ptr[i];
+        r1 = a.ref_ptr[i + 1];
+        pose_mode = a.pose_frozen[i];
+    }
+    const double mu_now = a.mu_dev ? *a.mu_dev : a.mu;
+    __shared__ SolveDatasetDev s_ds[kSchurLdsDatasets];
+    const bool ds_lds = a.n_ds > 0 && a.n_ds <= kSchurLdsDatasets;
+    if (ds_lds && (int)threadIdx.x < a.n_ds) s_ds[threadIdx.x] = a.ds[threadIdx.x];   // (straight to LDS: no registers held across the kernel)
     if (gate_closed(a.gate, a.gate_expect)) return;
     // poses of this workgroup whose damped block was not positive definite: the last entry of the workgroup's partial, so
     // that the fixed-order sum over the workgroups delivers the count next to the Gram (no atomic, no counter to clear)
@@ -229,14 +257,6 @@ __global__ __launch_bounds__(kSchurThreads * kSchurMaxBatches) void vg_schur_row
         if (a.zero_u64 && blockIdx.x == 0) *a.zero_u64 = 0ull;
     }
     __syncthreads();
-    const int pl = tid / C, gcol = tid - pl * C;        // pose of the batch, column
-    const bool lane_on = pl < poses_per_wg;
-    // every batch has its own 256 lanes (blockDim.x = kSchurThreads * batches): the chains pose -> reference list -> Gram
-    // blocks -> factorisation of the batches overlap instead of following one another (four in a row were 13 us of a wave's
-    // life, 73 % of it waiting)
-    const int bt = threadIdx.x / kSchurThreads;
-    const int i = (blockIdx.x * batches + bt) * poses_per_wg + pl;
-    const bool pose_on = lane_on && bt < batches && i < a.n_poses;
     // ---- the references of the workgroup's poses (a contiguous run of the CSR lists: the poses are consecutive), resolved ONCE
     // per workgroup into LDS: [block address | W | pose column | dataset].  Every gather below then reads addresses from LDS
     // and its global loads no longer hang off a chain pose -> reference -> dataset descriptor -> block, repeated per reference
@@ -247,15 +267,13 @@ __global__ __launch_bounds__(kSchurThreads * kSchurMaxBatches) void vg_schur_row
         int W, o, d, pad;
     };
     RefMeta *sm_ref = reinterpret_cast<RefMeta *>(sm_V + (size_t)batches * poses_per_wg * 28);   // [kSchurMaxRefs]
-    const int i_first = blockIdx.x * batches * poses_per_wg;
-    int i_end = i_first + batches * poses_per_wg;
-    i_end = i_end < a.n_poses ? i_end : a.n_poses;
-    const int q_first = a.ref_ptr[i_first < a.n_poses ? i_first : a.n_poses], q_end = a.ref_ptr[i_end > i_first ? i_end : i_first];
     const bool meta_lds = shared_gather && q_end - q_first <= kSchurMaxRefs;
     if (meta_lds) {
         for (int t = threadIdx.x; t < q_end - q_first; t += blockDim.x) {
             const int d = a.ref_ds[q_first + t];
-            const SolveDatasetDev D = a.ds[d];
+            SolveDatasetDev D;
+            if (ds_lds) D = s_ds[d];
+            else D = a.ds[d];
             RefMeta m;
             m.Gb = D.gram + (size_t)a.ref_blk[q_first + t] * D.W * D.W;
             m.W = D.W;
@@ -265,11 +283,6 @@ __global__ __launch_bounds__(kSchurThreads * kSchurMaxBatches) void vg_schur_row
             sm_ref[t] = m;
         }
         __syncthreads();
-    }
-    int r0 = 0, r1 = 0;
-    if (pose_on) {
-        r0 = a.ref_ptr[i];
-        r1 = a.ref_ptr[i + 1];
     }
     auto ref_of = [&](int q, const double *&Gb, int &W, int &o, int &d) {
         if (meta_lds) {
@@ -342,7 +355,7 @@ __global__ __launch_bounds__(kSchurThreads * kSchurMaxBatches) void vg_schur_row
                 for (int k = 0; k < 21; k++) V[k] = Vs[k];
 #pragma unroll
                 for (int k = 0; k < 6; k++) f.gp[k] = Vs[21 + k];
-                pose_factor_from(a, i, V, Vs[27] != 0., f);
+                pose_factor_from(a, pose_mode, mu_now, V, Vs[27] != 0., f);
             } else {
                 pose_factor(a, i, f);
             }
@@ -378,17 +391,43 @@ __global__ __launch_bounds__(kSchurThreads * kSchurMaxBatches) void vg_schur_row
     const int n_rows_wg = batches * poses_per_wg * 6, E = C * (C + 1) / 2;
     double *P = partials + (size_t)blockIdx.x * (C * C + 1);
     if (threadIdx.x == 0) P[C * C] = (double)s_bad;
-    for (int e = threadIdx.x; e < E; e += blockDim.x) {
-        int r = 0, rem = e;
+    // Narrow systems (28 entries at G = 6) leave most of the workgroup idle while each entry's thread walks all rows -- 216
+    // dependent multiply-adds at ~25 cycles: nch = 2, 4 or 8 lanes share an entry (rows nch apart) and add their parts in a
+    // fixed butterfly order.
+    int nch = 1;
+    while (nch < 8 && E * nch * 2 <= (int)blockDim.x) nch *= 2;
+    if (nch == 1) {   // wide systems: an entry per thread (and more), as before
+        for (int e = threadIdx.x; e < E; e += blockDim.x) {
+            int r = 0, rem = e;
+            while (rem >= C - r) {
+                rem -= C - r;
+                r++;
+            }
+            const int c = r + rem;
+            double s = 0.;
+            for (int row = 0; row < n_rows_wg; row++) s += sm_rows[(size_t)row * CS + r] * sm_rows[(size_t)row * CS + c];
+            P[r * C + c] = s;
+            P[c * C + r] = s;
+        }
+        return;
+    }
+    for (int t = threadIdx.x; t < ((E * nch + kWave - 1) / kWave) * kWave; t += blockDim.x) {   // whole waves: the butterfly needs every lane
+        const int e = t / nch, ch = t - e * nch;
+        const bool on = e < E;
+        int r = 0, rem = on ? e : 0;
         while (rem >= C - r) {
             rem -= C - r;
             r++;
         }
         const int c = r + rem;
         double s = 0.;
-        for (int row = 0; row < n_rows_wg; row++) s += sm_rows[(size_t)row * CS + r] * sm_rows[(size_t)row * CS + c];
-        P[r * C + c] = s;
-        P[c * C + r] = s;
+        if (on)
+            for (int row = ch; row < n_rows_wg; row += nch) s += sm_rows[(size_t)row * CS + r] * sm_rows[(size_t)row * CS + c];
+        for (int off = 1; off < nch; off <<= 1) s += __shfl_xor(s, off, kWave);
+        if (on && ch == 0) {
+            P[r * C + c] = s;
+            P[c * C + r] = s;
+        }
     }
 }
 #endif

@@ -677,6 +677,11 @@ __global__ __launch_bounds__(kLmThreads) void vg_lm_accept_kernel(LmAcceptArgs a
         } else if (sqrt(step2) <= a.ptol * (sqrt(xg2 + xp2) + a.ptol)) {
             S.term = VG_TERM_CONVERGENCE_PARAMETER;
             S.done = 1;
+        } else if (model_change > 0. && isfinite(cost2_c) && fabs(S.cost2 - cost2_c) <= a.ftol * S.cost2) {
+            // Ceres tests the function tolerance on every evaluated candidate of a valid step, BEFORE the step is accepted or
+            // rejected, and returns at the current point (see the host loop)
+            S.term = VG_TERM_CONVERGENCE_FUNCTION;
+            S.done = 1;
         }
     }
     S.rho = rho;
@@ -695,16 +700,11 @@ __global__ __launch_bounds__(kLmThreads) void vg_lm_accept_kernel(LmAcceptArgs a
         S.accepted = 1;
         S.ucur = 1 - S.ucur;
         for (int k = tid; k < G; k += kWave) a.xcur[k] = clampd(s_x[k] + s_dg[k], s_lo[k], s_hi[k]);  // what the step kernel wrote
-        const double prev = S.cost2;
         S.cost2 = cost2_c;
         const double t = 2. * rho - 1.;
         const double f = 1. - t * t * t;
         S.radius = fmin(S.radius / fmax(f, 1. / 3.), a.max_radius);
         S.decrease_factor = 2.;
-        if (fabs(prev - cost2_c) <= a.ftol * prev) {
-            S.term = VG_TERM_CONVERGENCE_FUNCTION;
-            S.done = 1;
-        }
     } else {
         S.radius /= S.decrease_factor;
         S.decrease_factor *= 2.;

@@ -826,6 +826,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             sa.ref_ds = d_ref_ds.p;
             sa.ref_blk = d_ref_blk.p;
             sa.pose_frozen = d_pf.p;
+            sa.n_ds = n_ds;
             sa.G = G;
             sa.n_poses = (int)n_poses;
             sa.mu = 0.;
@@ -965,7 +966,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
         else if (term == VG_TERM_CONVERGENCE_PARAMETER) std::snprintf(msg, sizeof msg, "parameter tolerance reached: |step| %.3e", S.step_norm);
         else if (term == VG_TERM_CONVERGENCE_FUNCTION)
             std::snprintf(msg, sizeof msg, "function tolerance reached: |cost change| / cost = %.3e",
-                          S.cost2 > 0 ? std::fabs(2. * S.cost_change) / (S.cost2 + 2. * S.cost_change) : 0.);
+                          S.cost2 > 0 ? std::fabs(2. * S.cost_change) / S.cost2 : 0.);   // (the solve ends at the current point: cost2 is its cost)
         else if (term == VG_TERM_RADIUS_TOO_SMALL) std::snprintf(msg, sizeof msg, "trust region radius below %.1e", opt.min_trust_region_radius);
         else if (term == VG_TERM_FAILURE) {
             iter = 0;
@@ -1055,6 +1056,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
         sa.ref_ds = d_ref_ds.p;
         sa.ref_blk = d_ref_blk.p;
         sa.pose_frozen = d_pf.p;
+        sa.n_ds = n_ds;
         sa.G = G;
         sa.n_poses = (int)n_poses;
         sa.mu = mu;
@@ -1325,6 +1327,17 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
                 std::snprintf(msg, sizeof msg, "parameter tolerance reached: |step| %.3e", std::sqrt(step2));
                 break;
             }
+            // Function tolerance: Ceres tests |cost change| of EVERY evaluated candidate of a valid step, before it decides whether
+            // the step is accepted (trust_region_minimizer.cc: the "function tolerance reached" block / FunctionToleranceReached()
+            // sits in front of the relative-decrease test), and returns at the CURRENT point.  With the reference's 1e-15 this is
+            // what ends the cascade of rejected noise-level steps at the tail of a solve after three or four radius reductions
+            // instead of the eight the parameter tolerance needs; until round 4 the test ran for accepted steps only.
+            if (model_change > 0. && std::isfinite(cost2_c) && std::fabs(cost2 - cost2_c) <= opt.function_tolerance * cost2) {
+                term = VG_TERM_CONVERGENCE_FUNCTION;
+                std::snprintf(msg, sizeof msg, "function tolerance reached: |cost change| / cost = %.3e",
+                              cost2 > 0 ? std::fabs(cost2 - cost2_c) / cost2 : 0.);
+                break;
+            }
         }
         const bool success = step_ok && std::isfinite(cost2_c) && rho > opt.min_relative_decrease;
         if (opt.verbose)
@@ -1342,18 +1355,11 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             }
             U.swap(Uc);
             gg.swap(ggc);
-            const double prev = cost2;
             cost2 = cost2_c;
             const double f = 1. - std::pow(2. * rho - 1., 3);
             radius = radius / (f > 1. / 3. ? f : 1. / 3.);
             radius = radius > opt.max_trust_region_radius ? opt.max_trust_region_radius : radius;
             decrease_factor = 2.;
-            if (std::fabs(prev - cost2) <= opt.function_tolerance * prev) {
-                term = VG_TERM_CONVERGENCE_FUNCTION;
-                std::snprintf(msg, sizeof msg, "function tolerance reached: |cost change| / cost = %.3e",
-                              prev > 0 ? std::fabs(prev - cost2) / prev : 0.);
-                break;
-            }
         } else {
             radius /= decrease_factor;
             decrease_factor *= 2.;
