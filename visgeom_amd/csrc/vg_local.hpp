@@ -502,8 +502,11 @@ __device__ __forceinline__ void sparse_point(const SparseArgs &a, const double *
 // The host takes this route when the grid is small and no workgroup touches more than kSparseWgBlocks blocks.
 constexpr int kSparseWgBlocks = 40;
 
+#ifndef VG_SPARSE_WAVES
+#define VG_SPARSE_WAVES 4   // waves per SIMD the register allocation aims at (experiment switch; see profiles/NOTES.md)
+#endif
 template <int MODEL, bool FUSED>
-__global__ __launch_bounds__(kEmitThreads) void vg_sparse_reproject_kernel(SparseArgs a)
+__global__ __launch_bounds__(kEmitThreads) __attribute__((amdgpu_waves_per_eu(VG_SPARSE_WAVES, 8))) void vg_sparse_reproject_kernel(SparseArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
