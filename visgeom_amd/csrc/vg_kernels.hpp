@@ -306,7 +306,13 @@ __device__ __forceinline__ void emit_tile(const EmitArgs &a, const unsigned int 
 }
 
 template <int MODEL, bool WANT_JAC, bool FRAMES_LDS, bool INLINE_CHAIN = false>
-__global__ __launch_bounds__(kEmitThreads) void vg_emit_kernel(EmitArgs a)
+#ifndef VG_EMIT_WAVES
+#define VG_EMIT_WAVES 4    // waves per SIMD the register allocation of the emit kernels aims at (experiment switch, profiles/NOTES.md)
+#endif
+#ifndef VG_EMIT_MULTI_WAVES
+#define VG_EMIT_MULTI_WAVES 4
+#endif
+__global__ __launch_bounds__(kEmitThreads) __attribute__((amdgpu_waves_per_eu(VG_EMIT_WAVES, 8))) void vg_emit_kernel(EmitArgs a)
 {
     emit_tile<MODEL, WANT_JAC, FRAMES_LDS, INLINE_CHAIN>(a, xcd_contiguous_block(blockIdx.x, gridDim.x) * (unsigned)kEmitThreads);
 }
@@ -342,7 +348,7 @@ __device__ __forceinline__ void emit_tile_route(const EmitArgs &a, unsigned int 
 }
 
 #ifdef VG_TU_CORE  // this kernel is launched by one translation unit only; the others see the header without it
-__global__ __launch_bounds__(kEmitThreads) void vg_emit_multi_kernel(EmitMultiArgs m)
+__global__ __launch_bounds__(kEmitThreads) __attribute__((amdgpu_waves_per_eu(VG_EMIT_MULTI_WAVES, 8))) void vg_emit_multi_kernel(EmitMultiArgs m)
 {
     const unsigned int x = blockIdx.x & 7u;   // workgroup b runs on XCD b % 8 (observed dispatch order)
     unsigned int j = blockIdx.x >> 3, t;
