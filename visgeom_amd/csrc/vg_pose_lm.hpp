@@ -204,6 +204,10 @@ __global__ __launch_bounds__(kValuThreads) void vg_pose_lm_kernel(PoseLmArgs a)
             active = false;
             continue;
         }
+        // (Unlike vg_lm_accept_kernel the function tolerance is tested AFTER a step has been accepted: Ceres tests it before
+        //  it decides about the step and returns at the point in front of it -- with this solve's tolerance of 1e-6 that leaves
+        //  the pose up to ~1e-5 short of the per-image optimum the tests hold it to; the accepted last step is at least as good
+        //  a seed for the global solve.)
         const bool success = pd && isfinite(cost_c) && gain > a.min_rel_decrease;
         if (success) {
 #pragma unroll
