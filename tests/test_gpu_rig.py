@@ -387,3 +387,39 @@ def test_candidate_frames_from_the_back_substitution_equal_the_chain_prep_launch
     assert s_fold["termination"].startswith("CONVERGENCE")
     assert s_fold["num_iterations"] == s_prep["num_iterations"] and s_fold["final_cost"] == s_prep["final_cost"]
     assert np.array_equal(x_fold, x_prep)
+
+
+def test_hundreds_of_datasets_solve_to_the_optimum_of_one(vg):
+    """260 datasets (one image each, one camera, one pose sequence) are one problem cut into pieces: the device-resident loop
+    keeps at most 256 block widths in LDS (kLmMaxDatasets), beyond that the host-driven loop takes over -- either way the optimum
+    is that of the single dataset holding the same 260 images (the reference adds one residual block per image whatever the
+    grouping: src/calibration/unified_calibration.cpp:514-630)."""
+    from visgeom_amd import synthetic as S
+
+    n = 260
+    d = S.make_mono("eucm", n, 2)
+    one = vg.CalibrationProblem(0)
+    cam = one.add_camera("eucm", d["init_intrinsics"])
+    seq = one.add_transform(False, d["init_poses"])
+    one.add_dataset(cam, [(seq, 0)], d["board"], d["corners"])
+    one.finalize()
+    s1 = one.solve(max_num_iterations=100)
+    x1 = one.get_parameters()
+    one.close()
+    out = {}
+    for n_ds in (200, 260):   # below and above the device-resident loop's limit
+        many = vg.CalibrationProblem(0)
+        cam = many.add_camera("eucm", d["init_intrinsics"])
+        seq = many.add_transform(False, d["init_poses"])
+        edges = np.linspace(0, n, n_ds + 1).astype(int)
+        for j in range(n_ds):
+            idx = np.arange(edges[j], edges[j + 1], dtype=np.int32)
+            many.add_dataset(cam, [(seq, 0)], d["board"], d["corners"][idx], image_index=idx)
+        many.finalize()
+        s = many.solve(max_num_iterations=100)
+        out[n_ds] = (s, many.get_parameters())
+        many.close()
+    for n_ds, (s, x) in out.items():
+        assert s["termination"].startswith("CONVERGENCE"), (n_ds, s)
+        assert abs(s["final_cost"] - s1["final_cost"]) <= 1e-9 * s1["final_cost"], (n_ds, s["final_cost"], s1["final_cost"])
+        assert np.max(np.abs(x - x1) / np.maximum(np.abs(x1), 1.0)) < 1e-6, n_ds
