@@ -222,7 +222,7 @@ def hooks_from_env():
     legacy = {"VG_INLINE_CHAIN_MAX_BYTES": "inline_chain_max_bytes", "VG_GRAM_FORCE_MFMA": "gram_force_mfma", "VG_GRAM_CH1": "gram_ch1",
               "VG_GRAM_NO_MERGE": "gram_no_merge", "VG_MAX_OBS_PER_LAUNCH": "max_obs_per_launch", "VG_SOLVER_TIMING": "solver_timing",
               "VG_SOLVER_HOST_LOOP": "solver_host_loop", "VG_SOLVER_DEVICE_LOOP": "solver_device_loop",
-              "VG_SOLVER_NO_SPECULATION": "solver_no_speculation", "VG_EMIT_EQUAL_TILES": "emit_equal_tiles", "VG_SCHUR_PRIVATE_GATHER": "schur_private_gather", "VG_SOLVER_EVENT_WAIT": "solver_event_wait", "VG_SOLVER_NO_FOLD_FRAMES": "solver_no_fold_frames", "VG_SOLVER_ONE_WAVE_FOLD": "solver_one_wave_fold"}
+              "VG_SOLVER_NO_SPECULATION": "solver_no_speculation", "VG_EMIT_EQUAL_TILES": "emit_equal_tiles", "VG_SCHUR_PRIVATE_GATHER": "schur_private_gather", "VG_SOLVER_EVENT_WAIT": "solver_event_wait", "VG_SOLVER_NO_FOLD_FRAMES": "solver_no_fold_frames", "VG_SOLVER_ONE_WAVE_FOLD": "solver_one_wave_fold", "VG_SOLVER_FOLD_MAX_GROUPS": "solver_fold_max_groups"}
     for env, name in legacy.items():
         if env in os.environ:
             v = os.environ[env]

@@ -35,6 +35,7 @@ enum DebugHook {
     kHookSolverEventWait,          // device-resident loop: wait for an event behind every accept kernel instead of spinning on its sequence word (A/B)
     kHookSolverNoFoldFrames,       // LM loops: launch the chain prep in front of every candidate evaluation instead of building the candidate's frames in the back-substitution kernel (A/B, bit-equality test)
     kHookSolverOneWaveFold,        // vg_backsub_solve_kernel: the reduced system by the first wave alone, a row per lane (the route before the entry-parallel L D L^T; A/B)
+    kHookSolverFoldMaxGroups,      // largest number of back-substitution workgroups whose launch also solves the reduced system (each workgroup redundantly); beyond: a one-workgroup solve launch in front (0 = the default, kFoldMaxGroups)
     kHookGramStamps,               // measurement build (-DVG_GRAM_STAMPS) only: device address of the per-wave clock stamps of the Gram kernel
     kHookCount
 };

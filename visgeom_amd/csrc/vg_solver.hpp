@@ -481,7 +481,10 @@ constexpr int kBsPosesPerGroup = 2;
 constexpr int kBsPosesPerBlock = (kBsThreads / kBsGroup) * kBsPosesPerGroup;
 
 // dgv: the global step, in global memory (b.dg) or in the workgroup's LDS (the kernel that solves the reduced system itself)
-template <int kJ>
+// kFrames: the instantiation that also builds the candidate's frames (b.fold != NULL).  A template parameter because the chain
+// walk is what sets the kernel's register count (202: two waves per SIMD); without it a mono problem's launch keeps more waves
+// resident -- at 100 k poses the launch is bound by how many workgroups a CU holds, not by their latency.
+template <int kJ, bool kFrames>
 __device__ __forceinline__ void backsub_body(const BacksubArgs &b, const double *dgv)
 {
     const SchurArgs &a = b.s;
@@ -495,7 +498,7 @@ __device__ __forceinline__ void backsub_body(const BacksubArgs &b, const double 
     // candidate frames: every workgroup needs the candidate values of the global columns (the expression above: same bits)
     __shared__ double s_gx[kBsThreads / 2];
     static_assert(kBsThreads / 2 >= 127, "a slot per global column");
-    if (b.fold) {
+    if (kFrames && b.fold) {
         if ((int)threadIdx.x < a.G) {
             const long long gp = b.gcol_param[threadIdx.x];
             s_gx[threadIdx.x] = clampd(b.x[gp] + dgv[threadIdx.x], b.lo[threadIdx.x], b.hi[threadIdx.x]);
@@ -519,8 +522,8 @@ __device__ __forceinline__ void backsub_body(const BacksubArgs &b, const double 
         // round trip behind the branch
         const double *rec = a.rec + (size_t)ii * kPoseRec;
         const long long pp = b.pose_param[ii];
-        ref0[q] = (b.fold && pv) ? a.ref_ptr[ii] : 0;
-        ref1[q] = (b.fold && pv) ? a.ref_ptr[ii + 1] : 0;
+        ref0[q] = (kFrames && b.fold && pv) ? a.ref_ptr[ii] : 0;
+        ref1[q] = (kFrames && b.fold && pv) ? a.ref_ptr[ii + 1] : 0;
         double L[21], gk[6], dk[6], xk[6], y[6], yl[6];
 #pragma unroll
         for (int k = 0; k < 21; k++) L[k] = rec[k];
@@ -575,7 +578,7 @@ __device__ __forceinline__ void backsub_body(const BacksubArgs &b, const double 
             }
         }
     }
-    if (b.fold) {
+    if (kFrames && b.fold) {
         // The frames of the group's two poses at the candidate point, for every dataset block that refers to them: lanes 0..7 of
         // the group take the references of the first pose, lanes 8..15 those of the second (a rig: four each), all chains of the
         // workgroup side by side -- the walk is one dependent chain per lane, exactly what vg_chain_prep_multi_kernel runs one
@@ -635,11 +638,31 @@ __device__ __forceinline__ void backsub_body(const BacksubArgs &b, const double 
     }
 }
 
-template <int kJ>
+template <int kJ, bool kFrames>
 __global__ __launch_bounds__(kBsThreads) void vg_backsub_kernel(BacksubArgs b)
 {
     if (gate_closed(b.s.gate, b.s.gate_expect)) return;
-    backsub_body<kJ>(b, b.dg);
+    backsub_body<kJ, kFrames>(b, b.dg);
+}
+
+// kJ = columns per lane of a pose's 16-lane group: the narrowest instantiation that covers G columns (registers: 202 at kJ = 4,
+// two waves per SIMD; a mono problem needs one column per lane)
+inline void launch_backsub(hipStream_t st, int G, unsigned int grid, const BacksubArgs &ba)
+{
+    const bool fr = ba.fold != nullptr;
+    if (G < 16) {
+        if (fr) hipLaunchKernelGGL((vg_backsub_kernel<1, true>), dim3(grid), dim3(kBsThreads), 0, st, ba);
+        else hipLaunchKernelGGL((vg_backsub_kernel<1, false>), dim3(grid), dim3(kBsThreads), 0, st, ba);
+    } else if (G < 32) {
+        if (fr) hipLaunchKernelGGL((vg_backsub_kernel<2, true>), dim3(grid), dim3(kBsThreads), 0, st, ba);
+        else hipLaunchKernelGGL((vg_backsub_kernel<2, false>), dim3(grid), dim3(kBsThreads), 0, st, ba);
+    } else if (G < 64) {
+        if (fr) hipLaunchKernelGGL((vg_backsub_kernel<4, true>), dim3(grid), dim3(kBsThreads), 0, st, ba);
+        else hipLaunchKernelGGL((vg_backsub_kernel<4, false>), dim3(grid), dim3(kBsThreads), 0, st, ba);
+    } else {
+        if (fr) hipLaunchKernelGGL((vg_backsub_kernel<8, true>), dim3(grid), dim3(kBsThreads), 0, st, ba);
+        else hipLaunchKernelGGL((vg_backsub_kernel<8, false>), dim3(grid), dim3(kBsThreads), 0, st, ba);
+    }
 }
 
 // x_new = x + delta (pose parameters: unbounded)

@@ -401,9 +401,10 @@ __global__ __launch_bounds__(kEntryThreads) void vg_lm_reduced_solve_entries_ker
 // and step_ok.  Until round 4 the first wave did it alone with a row per lane: 17 of this kernel's 33.7 us for the stereo problem
 // (G = 18), where the 256-thread L D L^T needs ~3; same box, per LM iteration: stereo 0.111 -> 0.094 ms, Mei (G = 10) 0.101 -> 0.090.
 constexpr int kFoldMaxG = 24;
+constexpr int kFoldMaxGroups = 480;    // back-substitution workgroups (32 poses each) up to which each of them repeats the reduced solve
 constexpr int kFoldSlots = ((kFoldMaxG + 1) * (kFoldMaxG + 2) / 2 + kBsThreads - 1) / kBsThreads;   // 2
 
-template <int kJ>
+template <int kJ, bool kFrames>
 __global__ __launch_bounds__(kBsThreads) void vg_backsub_solve_kernel(BacksubArgs b, LmSolveArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -420,7 +421,7 @@ __global__ __launch_bounds__(kBsThreads) void vg_backsub_solve_kernel(BacksubArg
         step = lm_entry_solve_body<kBsThreads, kFoldSlots>(a, sm, blockIdx.x == 0);
     }
     __syncthreads();
-    backsub_body<kJ>(b, step);
+    backsub_body<kJ, kFrames>(b, step);
 }
 
 struct LmAcceptArgs {

@@ -851,7 +851,11 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             VG_TRY(vgc::allreduce_sum(comm, d_rgram.p, h_rgram.size(), st));  // Schur complement of the poses of all ranks
             vg::LmSolveArgs r2 = ra;
             r2.gate_expect = gated ? par : -1;
-            const bool fold_solve = G > 0 && G <= vg::kFoldMaxG;   // every back-substitution workgroup solves the reduced system itself
+            // every back-substitution workgroup solves the reduced system itself -- while there are few enough of them: the
+            // redundant solves are SIMD time (~1 500 instructions per wave and workgroup), at 100 k poses (3 125 workgroups) they
+            // made the launch 82 us where a one-workgroup solve launch + the plain back-substitution take 30
+            const long long fold_max_groups = vgi::debug_hook(vgi::kHookSolverFoldMaxGroups) ? vgi::debug_hook(vgi::kHookSolverFoldMaxGroups) : vg::kFoldMaxGroups;
+            const bool fold_solve = G > 0 && G <= vg::kFoldMaxG && (long long)n_bs_groups <= fold_max_groups;
             if (!fold_solve) {
                 if (G <= vg::kEntrySolveMaxG)
                     hipLaunchKernelGGL(vg::vg_lm_reduced_solve_entries_kernel, dim3(1), dim3(vg::kEntryThreads), sizeof(double) * vg::lm_entry_solve_lds_doubles(G), st, r2);
@@ -879,10 +883,17 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
                 if (fold_solve) {
                     r2.S = nullptr;  // the damped matrix in every workgroup's own LDS
                     r2.one_wave = vgi::debug_hook(vgi::kHookSolverOneWaveFold) ? 1 : 0;
-                    hipLaunchKernelGGL(vg::vg_backsub_solve_kernel<4>, dim3(bs_grid), dim3(vg::kBsThreads),
-                                       sizeof(double) * std::max(vg::lm_entry_solve_lds_doubles(G), 2 * (size_t)G * G + 4 * (size_t)G + 2), st, ba, r2);
-                } else if (G < 64) hipLaunchKernelGGL(vg::vg_backsub_kernel<4>, dim3(bs_grid), dim3(vg::kBsThreads), 0, st, ba);
-                else hipLaunchKernelGGL(vg::vg_backsub_kernel<8>, dim3(bs_grid), dim3(vg::kBsThreads), 0, st, ba);
+                    // kJ = columns per lane of a pose's 16-lane group: 1 up to 15 global columns (every mono problem), 2 up to 31
+                    const size_t fold_lds = sizeof(double) * std::max(vg::lm_entry_solve_lds_doubles(G), 2 * (size_t)G * G + 4 * (size_t)G + 2);
+                    const bool fr = ba.fold != nullptr;   // the instantiation that also builds the candidate's frames
+                    if (G < 16) {
+                        if (fr) hipLaunchKernelGGL((vg::vg_backsub_solve_kernel<1, true>), dim3(bs_grid), dim3(vg::kBsThreads), fold_lds, st, ba, r2);
+                        else hipLaunchKernelGGL((vg::vg_backsub_solve_kernel<1, false>), dim3(bs_grid), dim3(vg::kBsThreads), fold_lds, st, ba, r2);
+                    } else {
+                        if (fr) hipLaunchKernelGGL((vg::vg_backsub_solve_kernel<2, true>), dim3(bs_grid), dim3(vg::kBsThreads), fold_lds, st, ba, r2);
+                        else hipLaunchKernelGGL((vg::vg_backsub_solve_kernel<2, false>), dim3(bs_grid), dim3(vg::kBsThreads), fold_lds, st, ba, r2);
+                    }
+                } else vg::launch_backsub(st, G, bs_grid, ba);
                 VG_HIP(hipGetLastError());
             }
             p->gram_gate = gate;
@@ -1208,8 +1219,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
             ba.fold_gcol = d_fold_gcol.p;
             if (n_poses || G) {  // G <= kBsThreads: one workgroup is enough for the global columns alone
                 const unsigned int bs_grid = n_bs_groups ? n_bs_groups : 1u;
-                if (G < 64) hipLaunchKernelGGL(vg::vg_backsub_kernel<4>, dim3(bs_grid), dim3(vg::kBsThreads), 0, st, ba);
-                else hipLaunchKernelGGL(vg::vg_backsub_kernel<8>, dim3(bs_grid), dim3(vg::kBsThreads), 0, st, ba);
+                vg::launch_backsub(st, G, bs_grid, ba);
                 VG_HIP(hipGetLastError());
             }
             // (the fixed-order sum of the back-substitution's per-workgroup partials and, host_direct, max |g_pose| to the host:
