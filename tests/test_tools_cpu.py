@@ -42,3 +42,26 @@ def test_benchlib_prices_the_passes_as_design_states():
     assert B.emit_bytes_per_obs("eucm", 2) == 320
     assert B.gram_flops_per_obs("eucm", 1) == 564 and B.gram_flops_per_obs("mei", 1) == 958
     assert B.gram_flops_per_obs("eucm", 2) == 1008 and B.gram_flops_per_obs("mei", 2) == 1498 and B.gram_flops_per_obs("ucm", 1) == 509
+
+
+def test_trace_gaps_groups_the_idle_time_between_dispatches_by_kernel_pair(tmp_path):
+    """tools/exp/trace_gaps.py found the 5-6 us the event marker cost behind every accept kernel and the rig loop's two 26 us
+    read-backs: gaps of a rocprofv3 kernel trace, grouped by (kernel, next kernel)"""
+    import subprocess
+    import sys
+
+    p = tmp_path / "t_kernel_trace.csv"
+    rows = ["Kernel_Name,Start_Timestamp,End_Timestamp"]
+    t = 1000000
+    for it in range(6):
+        for name, dur, gap in (("vg::vg_a_kernel(Args)", 10000, 0), ("void vg::vg_b_kernel<4>(Args)", 5000, 6000)):
+            rows.append('"%s",%d,%d' % (name, t, t + dur))
+            t += dur + gap
+    p.write_text("\n".join(rows) + "\n")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "exp", "trace_gaps.py"), str(p)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.splitlines()
+    ab = [l for l in lines if l.startswith("vg_a_kernel") and "-> vg_b_kernel<4>" in l][0].split()
+    ba = [l for l in lines if l.startswith("vg_b_kernel<4>") and "-> vg_a_kernel" in l][0].split()
+    assert float(ab[-2]) == 0.0 and abs(float(ba[-2]) - 6.0) < 1e-9      # mean gap in microseconds
+    assert any(l.startswith("vg_a_kernel") and "mean    10.00 us" in l for l in lines)
