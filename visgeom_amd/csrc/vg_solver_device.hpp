@@ -24,6 +24,45 @@ struct LmState {
     double cost2_init;                 // twice the cost at the starting point
 };
 
+// Everything a solve clears or copies before its first evaluation, in ONE launch: four memset commands, two device-to-device
+// copies and a pageable host-to-device copy of the initial state used to be seven blit operations of ~4.3 us each in front of the
+// first kernel of every solve (rocprofv3: `fillBufferAligned` / `copyBuffer`, 40 us of a 0.52 ms solve).
+struct SolverInitArgs {
+    static constexpr int kZero = 6;
+    double *zero[kZero] = {};            // ranges to clear (in doubles)
+    unsigned long long n_zero[kZero] = {};
+    const double *src = nullptr;         // the starting point ...
+    double *dst0 = nullptr, *dst1 = nullptr;   // ... copied to the current and (device loop) the candidate buffer
+    unsigned long long n_copy = 0;
+    LmState *state = nullptr;            // device loop: the initial trust-region state, by value
+    LmState h0;
+    void add_zero(double *p, size_t n)
+    {
+        for (int k = 0; k < kZero; k++)
+            if (!zero[k]) {
+                zero[k] = p;
+                n_zero[k] = n;
+                return;
+            }
+    }
+};
+
+#ifdef VG_TU_SOLVER
+__global__ __launch_bounds__(256) void vg_solver_init_kernel(SolverInitArgs a)
+{
+    const unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x, step = (unsigned long long)gridDim.x * blockDim.x;
+#pragma unroll
+    for (int k = 0; k < SolverInitArgs::kZero; k++)
+        for (unsigned long long i = t; i < a.n_zero[k]; i += step) a.zero[k][i] = 0.;
+    for (unsigned long long i = t; i < a.n_copy; i += step) {
+        const double v = a.src[i];
+        a.dst0[i] = v;
+        if (a.dst1) a.dst1[i] = v;
+    }
+    if (t == 0 && a.state) *a.state = a.h0;
+}
+#endif
+
 struct LmSolveArgs {
     LmState *st;
     const double *U;      // [2][G*G]

@@ -405,12 +405,25 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
     struct { unsigned long long *p; } d_gmax{nullptr};
     VG_TRY(d_scal.alloc((size_t)n_bs_groups * 5));
     VG_TRY(d_small.alloc((size_t)1 + (size_t)(G ? G : 1)));
-    VG_HIP(hipMemsetAsync(d_small.p, 0, sizeof(double) * (1 + (size_t)(G ? G : 1)), st));
-    VG_HIP(hipMemsetAsync(d_sums.p, 0, sizeof(double) * n_pack, st));
+    // what is cleared / copied before the first evaluation: collected here, done by ONE launch at the head of the loop that runs
+    vg::SolverInitArgs init;
+    std::memset(&init.h0, 0, sizeof init.h0);
+    init.add_zero(d_small.p, 1 + (size_t)(G ? G : 1));
+    init.add_zero(d_sums.p, n_pack);
     d_gmax.p = reinterpret_cast<unsigned long long *>(d_small.p);
     d_xg.p = d_small.p + 1;
-    VG_HIP(hipMemsetAsync(d_delta.p, 0, sizeof(double) * (size_t)(n_params ? n_params : 1), st));
-    VG_HIP(hipMemcpyAsync(d_x.p, p->d_params, sizeof(double) * (size_t)n_params, hipMemcpyDeviceToDevice, st));
+    init.add_zero(d_delta.p, (size_t)(n_params ? n_params : 1));
+    init.src = p->d_params;
+    init.dst0 = d_x.p;
+    init.n_copy = (unsigned long long)n_params;
+    auto launch_init = [&]() -> int {
+        unsigned long long n_max = init.n_copy;
+        for (int k = 0; k < vg::SolverInitArgs::kZero; k++) n_max = init.n_zero[k] > n_max ? init.n_zero[k] : n_max;
+        const unsigned int grid = (unsigned int)std::min<unsigned long long>(std::max<unsigned long long>((n_max + 255) / 256, 1ull), 1024ull);
+        hipLaunchKernelGGL(vg::vg_solver_init_kernel, dim3(grid), dim3(256), 0, st, init);
+        VG_HIP(hipGetLastError());
+        return VG_OK;
+    };
 
     std::vector<double> h_sums((size_t)n_ds * Wmax * Wmax + 5), h_rgram((size_t)C * C + 1);
     std::vector<double> U((size_t)G * G), gg(G), Uc((size_t)G * G), ggc(G), S((size_t)G * G), rhs(G), dg(G), h_xg(G);
@@ -441,7 +454,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
     if (host_spin) {
         VG_TRY(pin_seq.alloc(2));
         VG_TRY(d_sigcnt.alloc(2));
-        VG_HIP(hipMemsetAsync(d_sigcnt.p, 0, sizeof(unsigned int) * 2, st));
+        init.add_zero(reinterpret_cast<double *>(d_sigcnt.p), 1);   // two 32-bit counters
         std::memset(pin_seq.p, 0, sizeof(double) * 2);
     }
     auto host_signal = [&](int which) {   // 0: evaluation, 1: pose elimination
@@ -681,14 +694,14 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
         VG_TRY(d_xcur.alloc((size_t)G));
         VG_TRY(d_Wd.upload(Wd));
         VG_TRY(d_gfrozen.upload(gfrozen));
-        vg::LmState h0;
-        std::memset(&h0, 0, sizeof h0);
+        vg::LmState &h0 = init.h0;
         h0.radius = opt.initial_trust_region_radius;
         h0.decrease_factor = 2.;
         h0.mu = 1. / h0.radius;
         h0.term = VG_TERM_NO_CONVERGENCE;
-        VG_HIP(hipMemcpyAsync(d_state.p, &h0, sizeof h0, hipMemcpyHostToDevice, st));
-        VG_HIP(hipMemsetAsync(d_rgram.p, 0, sizeof(double) * h_rgram.size(), st));  // also the bad-pose counter behind it
+        init.state = d_state.p;
+        init.add_zero(d_rgram.p, h_rgram.size());  // also the bad-pose counter behind it
+        init.dst1 = d_xc.p;
         vg::LmState final_state;
 
         vg::LmAcceptArgs aa;
@@ -929,7 +942,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
         if (t_arena) VG_TRY(t_arena->flush(st));  // every table of the set-up in one asynchronous copy
         mark("device-loop state");
         const double t_loop = now_s();  // everything before: allocation and upload of the problem's solver state
-        VG_HIP(hipMemcpyAsync(d_xc.p, d_x.p, sizeof(double) * (size_t)n_params, hipMemcpyDeviceToDevice, st));
+        VG_TRY(launch_init());   // clears, starting point into both parameter buffers, initial state
         VG_TRY(enqueue_evaluate(xbuf[0], gset[0]));
         int parity = 0, pending = next_slot(), iter = 0;
         arm_slot(pending, aa);
@@ -1010,6 +1023,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
     }
 
     if (t_arena) VG_TRY(t_arena->flush(st));
+    VG_TRY(launch_init());
     // values of the global columns at the starting point
     // (ONE copy of the span they lie in -- the global blocks are neighbours in the parameter vector -- not a blocking copy per
     // column: 45 x 20 us in front of the rig's first iteration, rocprofv3 trace)
