@@ -780,7 +780,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
         // 0.115 ms per iteration, Mei 0.119 vs 0.126 -- the iteration is bound by its eight dependent launches on the GPU.
         // Replaying the gated iteration as a hipGraph (one per parity) was slower than queueing its launches: 0.120 /
         // 0.126 ms (profiles/NOTES.md).  vg_debug_set("solver_no_speculation", 1) queues one iteration at a time.
-        const bool speculate = opt.soft_l1_scale <= 0. && !vgi::debug_hook(vgi::kHookSolverNoSpeculation);
+        const bool speculate = opt.soft_l1_scale <= 0. && vgi::debug_hook(vgi::kHookSolverNoSpeculation) != 1;
         DevBuf<double> *gset[2] = {gramA, gramB};
         vg::SolveDatasetDev *dset[2] = {d_dsA.p, d_dsB.p};
         double *xbuf[2] = {d_x.p, d_xc.p};
@@ -953,12 +953,21 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
         else VG_TRY(queue_state(pending));
         const vg::LmState *Sp = slots.p + pending;
         bool printed_header = false;
+        // Near the end no iteration is queued ahead: the iteration queued behind the LAST one still runs its six launches as
+        // closed-gate kernels (27 us at 10 k images, in front of the copy of the result: 5 % of the solve).  LM converges
+        // quadratically at the tail, so once the last known step changed the cost by less than 1e-9 of it the iteration in flight
+        // is the last or the one before it; not speculating past it costs one launch latency (~8 us) if it was not.
+        // (vg_debug_set("solver_no_speculation", 2): always speculate, for A/B.)
+        const bool always_speculate = vgi::debug_hook(vgi::kHookSolverNoSpeculation) == 2;
+        double last_rel_change = 1.;
         for (iter = 1; iter <= opt.max_num_iterations; iter++) {
             int spec = -1;
-            if (speculate && iter < opt.max_num_iterations) VG_TRY(queue_iteration(parity ^ 1, true, spec));
+            const bool near_end = !always_speculate && last_rel_change <= 1e-9;
+            if (speculate && !near_end && iter < opt.max_num_iterations) VG_TRY(queue_iteration(parity ^ 1, true, spec));
             VG_TRY(wait_state(pending));  // the one wait of the iteration; the GPU already holds the next one
             Sp = slots.p + pending;
             const vg::LmState &S = *Sp;
+            last_rel_change = (S.step_ok && S.cost2 > 0.) ? std::fabs(2. * S.cost_change) / S.cost2 : 1.;
             if (opt.verbose) {
                 if (!printed_header)
                     std::printf("iter      cost      cost_change  |gradient|   |step|    tr_ratio  tr_radius\n%4d  %.6e\n", 0, 0.5 * S.cost2_init);
