@@ -29,32 +29,50 @@ double now_s()
 }
 
 // Cholesky solve of a dense SPD system, row-major; returns false when not positive definite
-bool chol_solve(int n, const double *A, const double *b, double *x)
+// Cholesky solve of a small dense SPD system on the host (the reduced system of the host-driven loop: 45 x 45 for the rig, once
+// or twice per iteration).  Right-looking: column j is scaled, copied to a contiguous buffer, and every row's remaining entries
+// lose L_ij L_kj in ONE pass over contiguous memory -- a loop the compiler vectorises without reassociating anything, where the
+// dot-product form (s -= L_rk L_ck over k) is a serial reduction under -ffp-contract=off / no fast-math: 7 us -> ~3 us per
+// iteration of the rig.  Every entry still sees its subtractions in increasing column order: the same bits as that form.
+// `ws`: n * n + 2 n doubles of workspace (grown here, kept by the caller: no allocation per call).
+bool chol_solve(int n, const double *A, const double *b, double *x, std::vector<double> &ws)
 {
-    std::vector<double> L((size_t)n * n, 0.);
+    if (ws.size() < (size_t)n * n + 2 * (size_t)n) ws.resize((size_t)n * n + 2 * (size_t)n);
+    double *L = ws.data(), *col = L + (size_t)n * n, *y = col + n;
     for (int r = 0; r < n; r++)
-        for (int c = 0; c <= r; c++) {
-            double s = A[(size_t)r * n + c];
-            for (int k = 0; k < c; k++) s -= L[(size_t)r * n + k] * L[(size_t)c * n + k];
-            if (r == c) {
-                if (!(s > 0.) || !std::isfinite(s)) return false;
-                L[(size_t)r * n + r] = std::sqrt(s);
-            } else {
-                L[(size_t)r * n + c] = s / L[(size_t)c * n + c];
-            }
+        for (int c = 0; c <= r; c++) L[(size_t)r * n + c] = A[(size_t)r * n + c];
+    for (int j = 0; j < n; j++) {
+        const double d = L[(size_t)j * n + j];
+        if (!(d > 0.) || !std::isfinite(d)) return false;
+        const double ljj = std::sqrt(d);
+        L[(size_t)j * n + j] = ljj;
+        for (int i = j + 1; i < n; i++) {
+            L[(size_t)i * n + j] /= ljj;
+            col[i] = L[(size_t)i * n + j];
         }
-    std::vector<double> y(n);
+        for (int i = j + 1; i < n; i++) {
+            const double lij = col[i];
+            double *row = L + (size_t)i * n;
+            for (int k = j + 1; k <= i; k++) row[k] -= lij * col[k];
+        }
+    }
     for (int r = 0; r < n; r++) {
-        double s = b[r];
-        for (int c = 0; c < r; c++) s -= L[(size_t)r * n + c] * y[c];
-        y[r] = s / L[(size_t)r * n + r];
+        double s2 = b[r];
+        for (int c = 0; c < r; c++) s2 -= L[(size_t)r * n + c] * y[c];
+        y[r] = s2 / L[(size_t)r * n + r];
     }
     for (int r = n - 1; r >= 0; r--) {
-        double s = y[r];
-        for (int c = r + 1; c < n; c++) s -= L[(size_t)c * n + r] * x[c];
-        x[r] = s / L[(size_t)r * n + r];
+        double s2 = y[r];
+        for (int c = r + 1; c < n; c++) s2 -= L[(size_t)c * n + r] * x[c];
+        x[r] = s2 / L[(size_t)r * n + r];
     }
     return true;
+}
+
+bool chol_solve(int n, const double *A, const double *b, double *x)
+{
+    std::vector<double> ws;
+    return chol_solve(n, A, b, x, ws);
 }
 
 int launch_dense_gram(hipStream_t st, const double *X, unsigned n_rows, int C, unsigned rows_per_group, unsigned n_groups,
@@ -630,16 +648,22 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
         for (int d = 0; d < n_ds; d++) {
             const int W = Wd[d];
             const double *Sd = pin_sums.p + (size_t)d * Wmax * Wmax;
+            // (the lower triangle only, mirrored: the blocks are symmetric bit for bit, and what the device wrote into pinned
+            //  memory is a cache miss per line on the host -- reading the 17 KB of a rig's blocks was most of this loop's time)
+            const double *last = Sd + (size_t)(W - 1) * W;   // the residual row: J^T r and r^T r in one contiguous run
             for (int a2 = 0; a2 < W - 1; a2++) {
                 const int ga = lmap[d][a2];
                 if (ga < 0) continue;
-                for (int b2 = 0; b2 < W - 1; b2++) {
+                for (int b2 = 0; b2 <= a2; b2++) {
                     const int gb = lmap[d][b2];
-                    if (gb >= 0) Uo[(size_t)ga * G + gb] += Sd[a2 * W + b2];
+                    if (gb < 0) continue;
+                    const double v = Sd[a2 * W + b2];
+                    Uo[(size_t)ga * G + gb] += v;
+                    if (a2 != b2) Uo[(size_t)gb * G + ga] += v;
                 }
-                go[ga] += Sd[a2 * W + W - 1];
+                go[ga] += last[a2];
             }
-            cost2 += Sd[W * W - 1];
+            cost2 += last[W - 1];
         }
         t_eval += now_s() - t0;
         return VG_OK;
@@ -1079,6 +1103,8 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
         term = VG_TERM_FAILURE;
         std::snprintf(msg, sizeof msg, "the cost at the starting point is not finite (NaN / Inf in the residuals)");
     }
+    std::vector<unsigned char> held;
+    std::vector<double> Sw, rw, chol_ws;
     for (iter = 1; term != VG_TERM_FAILURE && iter <= opt.max_num_iterations; iter++) {
         const double mu = 1. / radius;
         // ---- eliminate the poses: rows -> Gram -> S_sub, c
@@ -1178,18 +1204,23 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
 
         // ---- reduced system on the host
         t0 = now_s();
+        // (rows 0 .. G - 1 of the Schur complement's lower triangle and its last ROW, which is its last column: half the cache
+        //  lines of what the device wrote)
         for (int a2 = 0; a2 < G; a2++) {
-            for (int b2 = 0; b2 < G; b2++) S[(size_t)a2 * G + b2] = U[(size_t)a2 * G + b2] - rg[(size_t)a2 * C + b2];
+            for (int b2 = 0; b2 <= a2; b2++) {
+                const double r2 = rg[(size_t)a2 * C + b2];
+                S[(size_t)a2 * G + b2] = U[(size_t)a2 * G + b2] - r2;
+                if (a2 != b2) S[(size_t)b2 * G + a2] = U[(size_t)b2 * G + a2] - r2;
+            }
             const double dd = U[(size_t)a2 * G + a2];
             S[(size_t)a2 * G + a2] += mu * (dd < opt.min_lm_diagonal ? opt.min_lm_diagonal : (dd > opt.max_lm_diagonal ? opt.max_lm_diagonal : dd));
-            rhs[a2] = -gg[a2] + rg[(size_t)a2 * C + G];
+            rhs[a2] = -gg[a2] + rg[(size_t)G * C + a2];
         }
         // Constant blocks, and the active set of the box bounds: a parameter sitting ON a bound whose step points
         // outwards is held for this iteration (its row / column leave the reduced system -- the Schur complement of
         // the constrained problem is exactly that sub-matrix).  Without this the projected step keeps "spending" its
         // decrease on a coordinate that cannot move, the gain ratio collapses and the radius shrinks to nothing.
-        std::vector<unsigned char> held(gfrozen.begin(), gfrozen.end());
-        std::vector<double> Sw, rw;
+        held.assign(gfrozen.begin(), gfrozen.end());   // (held, Sw, rw, chol_ws: allocated once, in front of the loop)
         bool step_ok = coupled_ok;
         for (int pass = 0; step_ok && pass <= G; pass++) {
             Sw = S;
@@ -1200,7 +1231,7 @@ int vg_problem_solve(vg_problem *p, const vg_solve_options *opt_in, vg_solve_sum
                     Sw[(size_t)a2 * G + a2] = 1.;
                     rw[a2] = 0.;
                 }
-            step_ok = G == 0 || chol_solve(G, Sw.data(), rw.data(), dg.data());
+            step_ok = G == 0 || chol_solve(G, Sw.data(), rw.data(), dg.data(), chol_ws);
             bool changed = false;
             if (step_ok && opt.use_bounds)
                 for (int a2 = 0; a2 < G; a2++) {
