@@ -428,9 +428,35 @@ int64_t vg_calibration_log(vg_calibration *c, char *buf, int64_t size);
 int vg_calibration_num_datasets(const vg_calibration *c);
 int vg_calibration_get_intrinsics(vg_calibration *c, const char *camera, double *out, int *count);
 int vg_calibration_get_transform(vg_calibration *c, const char *name, int64_t index, double *out6, int64_t *count);
+/* The corner list of one image of a dataset as parsed (detectedCornersVec[image], unified_calibration.h:86): *count = number
+ * of doubles (2 per board point, 0 for an image without corners); out (may be NULL) receives them. */
+int vg_calibration_get_corners(const vg_calibration *c, int dataset, int64_t image, double *out, int64_t *count);
+int64_t vg_calibration_num_images(const vg_calibration *c, int dataset);
 /* writeImageResidual(dataVec[dataset], path), :1186-1292.  sigma_out: one value per image of the dataset (NULL ok). */
 int vg_calibration_write_residuals(vg_calibration *c, int dataset, const char *path, double *sigma_out,
                                    int64_t *outliers_out);
+/* Where the front end's wall-clock time went, in seconds, accumulated over every vg_calibration_add_file / _compute /
+ * _write_residuals call on this handle (the reference's program is `calib a.json`: parse -> estimateInitialGrid per image ->
+ * ceres::Solve -> report; tools/bench_calib.py and bench.py's calib_e2e section print this table). */
+typedef struct vg_calibration_timings {
+    double read_files_s;        /* reading the JSON files into memory */
+    double parse_json_s;        /* JSON text -> values (calibration file, corner / wheel files) */
+    double geometric_init_s;    /* 4-corner pose construction (:1066-1135) + getInitTransform (:311-348), host */
+    double refine_total_s;      /* vg_refine_poses calls as seen by the host: staging, H2D, kernel, D2H */
+    double refine_kernel_s;     /* ... the vg_pose_lm_kernel launches alone (HIP events) */
+    double global_init_s;       /* initGlobalTransform refinements (:358-429): a batched solve per global transform */
+    double assemble_s;          /* compute(): problem assembly, uploads, vg_problem_finalize */
+    double solve_s;             /* compute(): vg_problem_solve */
+    double readback_s;          /* compute(): parameters back into the maps */
+    double residual_eval_s;     /* write_residuals: chain composition + projection of every image (GPU) */
+    double residual_format_s;   /* write_residuals: statistics, formatting and writing image_error_<i>.txt */
+    int64_t refine_images;      /* images refined by vg_refine_poses */
+    int64_t refine_iterations;  /* sum of their LM iterations */
+    int64_t refine_max_iterations; /* the slowest image's iteration count */
+    int64_t json_bytes;         /* bytes of JSON text parsed */
+    int64_t residual_lines;     /* lines written by write_residuals */
+} vg_calibration_timings;
+int vg_calibration_get_timings(const vg_calibration *c, vg_calibration_timings *out);
 /* Host-only pieces of the pose initialisation, exported so that they can be checked block by block without a GPU (the
  * front end calls the same code):
  *   vg_reconstruct_point  ICamera::reconstructPoint (eucm.h:85-106, ucm.h:81-103, mei.h:90-112): uv[2] -> X[3] = (xn, yn, z);

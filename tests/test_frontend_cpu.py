@@ -257,3 +257,144 @@ def test_odometry_intrinsic_entry_parses_and_initialises_the_sequence(tmp_path):
         xi = vgo.compose(xi, vgo.OdometryCost(0.05, 0.05, 0.05, d["delta_q"][i], d["init_wheels"]).zeta)
         assert np.max(np.abs(seq[i + 1] - xi)) < 1e-14
     c.close()
+
+
+def test_text_to_double_conversion_equals_strtod(tmp_path):
+    """the corner files are read without strtod (vg_json.hpp, Cursor::number: exact 128-bit integer arithmetic for the common
+    shapes); a compiled host check holds every conversion to strtod's bits on 600 000 generated numbers incl. exact ties"""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "json_number_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", os.path.join(root, "tests", "host", "json_number_check.cpp"), "-o", exe])
+    r = subprocess.run([exe], stdout=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stdout.decode()
+    assert b"bad 0" in r.stdout
+
+
+def test_corner_file_is_read_exactly_and_frames_keep_their_order(tmp_path):
+    """readCorners (unified_calibration.cpp:252-277) through the streaming reader: every corner equals the value written
+    (repr round trip), frames without an entry for the camera are empty, entries of other cameras and unknown keys are skipped,
+    the FIRST matching entry of a frame counts; 300 frames so that several host threads share the file"""
+    import json
+
+    d = S.make_mono("eucm", 300, 1)
+    skip = {3, 17, 299}
+    frames = []
+    for i in range(300):
+        fr = [{"camera": "other", "points": [[1.0, 2.0]], "extra": {"a": [1, {"b": "]"}], "s": 'x"y\\'}}]
+        if i not in skip:
+            fr.append({"points": d["corners"][i].tolist(), "note": "first", "camera": "cam"})   # keys in another order
+            fr.append({"camera": "cam", "points": (d["corners"][i] + 1).tolist()})                # a second match is ignored
+        frames.append(fr)
+    path = S.write_calibration_json(str(tmp_path), d, "eucm", prior=True)
+    json.dump(frames, open(tmp_path / "calib_corners.json", "w"), indent=1)
+    c = GenericCameraCalibration()
+    c.addResiduals(path)
+    got = c.corners(0)
+    assert len(got) == 300
+    for i in range(300):
+        if i in skip:
+            assert got[i] is None
+        else:
+            assert np.array_equal(got[i], d["corners"][i]), i
+    assert c.timings()["json_bytes"] > 0 and c.timings()["parse_json_s"] > 0
+    c.close()
+
+
+@pytest.mark.parametrize("what, msg", [
+    ("short", "a frame has 95 corners, the board has 96"),
+    ("one_coordinate", "a corner needs two coordinates"),
+    ("no_camera_key", "No such node (camera)"),
+    ("no_points_key", "No such node (points)"),
+    ("trailing", "JSON parse error"),
+    ("unterminated", "JSON parse error"),
+])
+def test_corner_file_errors(tmp_path, what, msg):
+    import json
+
+    d = S.make_mono("eucm", 130, 1)
+    path = S.write_calibration_json(str(tmp_path), d, "eucm", prior=True)
+    frames = [[{"camera": "cam", "points": d["corners"][i].tolist()}] for i in range(130)]
+    text = None
+    if what == "short":
+        frames[77][0]["points"] = frames[77][0]["points"][:-1]
+    elif what == "one_coordinate":
+        frames[101][0]["points"][5] = [3.0]
+    elif what == "no_camera_key":
+        del frames[5][0]["camera"]
+    elif what == "no_points_key":
+        del frames[129][0]["points"]
+    elif what == "trailing":
+        text = json.dumps(frames) + " ]"
+    elif what == "unterminated":
+        text = json.dumps(frames)[:-1]
+    with open(tmp_path / "calib_corners.json", "w") as f:
+        f.write(text if text is not None else json.dumps(frames))
+    c = GenericCameraCalibration()
+    with pytest.raises(capi.VisgeomError) as e:
+        c.addResiduals(path)
+    assert msg in str(e.value), str(e.value)
+    c.close()
+
+
+def test_corner_file_survives_mutated_input(tmp_path):
+    """byte flips, deletions and insertions in a corner file: an error code or a parse, never a crash -- whichever thread meets it"""
+    import json
+
+    d = S.make_mono("eucm", 200, 1)
+    path = S.write_calibration_json(str(tmp_path), d, "eucm", prior=True)
+    text = json.dumps([[{"camera": "cam", "points": d["corners"][i].tolist()}] for i in range(200)])
+    rng = np.random.default_rng(11)
+    ok = bad = 0
+    for trial in range(80):
+        b = bytearray(text.encode())
+        for _ in range(int(rng.integers(1, 4))):
+            pos = int(rng.integers(0, len(b)))
+            op = int(rng.integers(0, 3))
+            if op == 0:
+                b[pos] = int(rng.integers(32, 127))
+            elif op == 1:
+                del b[pos:pos + int(rng.integers(1, 50))]
+            else:
+                b.insert(pos, int(rng.choice(list(b'{}[]",:0-9eE.tfn \\'))))
+        if trial % 10 == 0:
+            b = b[:int(rng.integers(0, len(b)))]
+        with open(tmp_path / "calib_corners.json", "wb") as f:
+            f.write(bytes(b))
+        c = GenericCameraCalibration()
+        try:
+            c.addResiduals(path)
+            ok += 1
+        except capi.VisgeomError:
+            bad += 1
+        finally:
+            c.close()
+    assert ok + bad == 80 and bad > 20
+
+
+def test_report_numbers_are_printed_like_the_stream_default(tmp_path):
+    """the report and image_error files print numbers the way `ostream << double` does (6 significant digits, "%g"); the fast
+    conversion behind them (std::to_chars) must give printf's text for every magnitude"""
+    rng = np.random.default_rng(5)
+    d = S.make_mono("eucm", 400, 1)
+    vals = rng.standard_normal((400, 6)) * 10.0 ** rng.integers(-12, 12, (400, 6))
+    vals[0] = [0.0, -0.0, 1e15, 999999.5, 0.0001, 0.00001234]
+    vals[1] = [123456.5, 1234567.0, 1e-300, -1e300, 0.1, 100000.0]
+    d["init_poses"] = vals
+    path = S.write_calibration_json(str(tmp_path), d, "eucm", prior=True)
+    c = GenericCameraCalibration()
+    c.addResiduals(path)
+    lines = [ln for ln in c.report().splitlines() if " : " in ln and ln.split(" : ")[0].isdigit()]
+    assert len(lines) == 400
+
+    def row(v):
+        s = ["%g" % x for x in v]
+        w = max(len(x) for x in s)
+        return " ".join(x.rjust(w) for x in s)
+
+    for i, ln in enumerate(lines):
+        x = c.transform("xiCamBoard")[i]
+        assert ln == "%d : %s %s" % (i, row(x[:3]), row(x[3:])), (i, ln)
+    c.close()

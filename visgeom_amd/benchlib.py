@@ -171,3 +171,143 @@ def section(cfg, reps=200, device=0, images=None, solve_runs=2, comm=None, allre
     }
     p.close()
     return row
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The product entry point end to end: `calib a.json` (test/calibration/generic_calibration.cpp:32-44 -> addResiduals ->
+# compute, unified_calibration.cpp:350-356,39-89) on a generated calibration file, phase by phase.
+
+CALIB_PHASES = ("read_files_s", "parse_json_s", "geometric_init_s", "refine_total_s", "global_init_s", "assemble_s", "solve_s",
+                "readback_s", "residual_eval_s", "residual_format_s")
+# phases whose time is GPU work (kernels + the copies they need); the rest is host work
+CALIB_GPU_PHASES = ("refine_total_s", "global_init_s", "solve_s", "residual_eval_s")
+
+
+def write_calib_workload(directory, workload, images):
+    """write the calibration JSON of a workload ('mono_eucm' / 'mono_mei': one camera, ir_data corners, poses initialised from
+    scratch; 'stereo': the shape of data/calib_stereo_example.json) -> (path, dict of what was generated)"""
+    import os
+
+    from . import synthetic
+
+    os.makedirs(directory, exist_ok=True)
+    if workload in ("mono_eucm", "mono_mei"):
+        model = workload.split("_")[1]
+        d = synthetic.make_mono(model, images, 1)
+        path = synthetic.write_calibration_json(directory, d, model, name=workload)
+        n_obs = images * N_CORNERS
+        gt = {"cam": d["gt_intrinsics"]}
+    elif workload == "stereo":
+        d = synthetic.make_stereo(images)
+        path = synthetic.write_stereo_json(directory, d, name=workload)
+        n_obs = 2 * images * N_CORNERS
+        gt = {"camera1": d["gt_intrinsics1"], "camera2": d["gt_intrinsics2"]}
+    else:
+        raise ValueError(workload)
+    size = sum(os.path.getsize(os.path.join(directory, f)) for f in os.listdir(directory) if f.startswith(workload) and f.endswith(".json"))
+    return path, {"observations": n_obs, "json_bytes": size, "gt": gt}
+
+
+def calib_e2e(workload="mono_eucm", images=10000, directory=None, runs=2, cli=True, device=0):
+    """One calibration through the library's front end (vg_calibration_*: the code `calib` runs) with its per-phase clock, best of
+    `runs` by total; optionally the `calib` executable itself under a wall clock.  Returns a JSON-able dict."""
+    import os
+    import shutil
+    import subprocess
+    import tempfile
+    import time
+
+    from .calibration import GenericCameraCalibration
+
+    own = directory is None
+    directory = directory or tempfile.mkdtemp(prefix="vg_calib_")
+    try:
+        t0 = time.perf_counter()
+        path, info = write_calib_workload(directory, workload, images)
+        t_write = time.perf_counter() - t0
+        best = None
+        for _ in range(max(1, runs)):
+            c = GenericCameraCalibration(device)
+            t0 = time.perf_counter()
+            c.addResiduals(path)
+            c.compute()
+            n_ds = c.num_datasets()
+            for i in range(n_ds):
+                c.writeImageResidual(i, os.path.join(directory, "image_error_%d.txt" % i))
+            total = time.perf_counter() - t0
+            tm = c.timings()
+            row = {"total_s": total, "phases": {k: tm[k] for k in CALIB_PHASES}, "refine_kernel_s": tm["refine_kernel_s"],
+                   "refine_images": tm["refine_images"], "refine_iterations_mean": tm["refine_iterations"] / max(tm["refine_images"], 1),
+                   "refine_iterations_max": tm["refine_max_iterations"], "residual_lines": tm["residual_lines"],
+                   "solve": {k: c.summary[k] for k in ("num_iterations", "termination", "final_cost", "total_seconds")},
+                   "max_rel_intrinsics_error_vs_generating": max(
+                       float(np.max(np.abs(c.intrinsics(name) - g) / np.maximum(np.abs(g), 1.0))) for name, g in info["gt"].items())}
+            c.close()
+            if best is None or row["total_s"] < best["total_s"]:
+                best = row
+        gpu = sum(best["phases"][k] for k in CALIB_GPU_PHASES)
+        host = sum(v for k, v in best["phases"].items() if k not in CALIB_GPU_PHASES)
+        out = {"workload": "%s, %d images x %d corners, poses from scratch (estimateInitialGrid), JSON -> report + image_error files"
+                           % (workload, images, N_CORNERS),
+               "observations": info["observations"], "json_megabytes": info["json_bytes"] / 1e6, "generate_and_write_json_s": t_write,
+               **best, "gpu_phases_s": gpu, "host_phases_s": host,
+               "dominant_phase": max(best["phases"].items(), key=lambda kv: kv[1])[0],
+               "images_per_second_end_to_end": images / best["total_s"]}
+        if cli:
+            exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bin", "calib")
+            walls = []
+            for _ in range(max(1, runs)):
+                t0 = time.perf_counter()
+                r = subprocess.run([exe, path], cwd=directory, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=600)
+                walls.append(time.perf_counter() - t0)
+                if r.returncode != 0:
+                    raise RuntimeError("calib failed: %s" % r.stderr.decode("utf-8", "replace")[-500:])
+            out["cli_wall_s"] = min(walls)   # process start, HIP initialisation and module load included
+        return out
+    finally:
+        if own:
+            shutil.rmtree(directory, ignore_errors=True)
+
+
+def pose_init(model="eucm", images=10000, reps=5, device=0, keep_inputs=False):
+    """f2: the 4-corner geometric pose of every image (host) and vg_refine_poses (vg_pose_lm_kernel: one independent LM per image,
+    SoftLOneLoss(25), in one launch) from those poses at the initial intrinsics -- what estimateInitialGrid does per image
+    (unified_calibration.cpp:1066-1158).  Kernel time = HIP events around the launch (vg_calibration_timings.refine_kernel_s of a
+    front-end run carries the same clock); priced against the FP64 vector peak with
+    (iterations + 1) x N x (EVAL_FLOPS + 2 x 7 x 8) flops per image (one [J | r] evaluation + 7 x 7 Gram per LM iteration)."""
+    import ctypes
+    import time
+
+    from . import capi, synthetic
+    from .calibration import refine_poses
+
+    L = capi.load()
+    d = synthetic.make_mono(model, images, 1)
+    intr = d["init_intrinsics"]
+    board, corners = d["board"], d["corners"]
+    N = board.shape[0]
+    idx = [0, synthetic.BOARD_COLS - 1, synthetic.BOARD_COLS * (synthetic.BOARD_ROWS - 1), N - 1]
+    dp = ctypes.POINTER(ctypes.c_double)
+    b4 = np.ascontiguousarray(board[idx])
+    start = np.zeros((images, 6))
+    t0 = time.perf_counter()
+    for i in range(images):
+        c4 = np.ascontiguousarray(corners[i, idx])
+        capi.check(L.vg_initial_grid_pose(capi.MODELS[model], intr.ctypes.data_as(dp), b4.ctypes.data_as(dp), c4.ctypes.data_as(dp),
+                                          start[i].ctypes.data_as(dp)))
+    t_geo_py = time.perf_counter() - t0   # through ctypes, one call per image: an upper bound of the host loop in the library
+    best, it = None, None
+    for _ in range(max(1, reps)):
+        t0 = time.perf_counter()
+        poses, it, cost, term = refine_poses(model, intr, board, corners, start, device=device)
+        dt = time.perf_counter() - t0
+        best = dt if best is None or dt < best else best
+    flops = float(np.sum((it.astype(np.float64) + 1) * N * (EVAL_FLOPS[model] + 2 * 7 * 8)))
+    out = {"workload": "%s, %d images x %d corners, start = 4-corner pose at the initial intrinsics" % (model, images, N),
+           "refine_call_ms": best * 1e3, "iterations_mean": float(it.mean()), "iterations_p99": float(np.percentile(it, 99)),
+           "iterations_max": int(it.max()), "converged": int(np.sum(term <= 2)), "algorithmic_flops": flops,
+           "max_pose_error_vs_generating": float(np.max(np.abs(poses - d["gt_poses"]))),
+           "geometric_init_through_ctypes_ms": t_geo_py * 1e3}
+    if keep_inputs:   # for the caller's CPU baseline leg (bench.py: the checker is only ever timed there, never from this package)
+        out["_inputs"] = {"model": model, "intrinsics": intr, "board": board, "corners": corners, "start": start}
+    return out

@@ -46,6 +46,26 @@ class GenericCameraCalibration:
     def log(self):
         return self._text(self._lib.vg_calibration_log)
 
+    def corners(self, dataset):
+        """the corner lists of a dataset as parsed: a list with one [N, 2] array (or None: no corners) per image"""
+        out = []
+        for i in range(self._lib.vg_calibration_num_images(self._h, dataset)):
+            n = ctypes.c_int64(0)
+            capi.check(self._lib.vg_calibration_get_corners(self._h, dataset, i, None, ctypes.byref(n)))
+            if n.value == 0:
+                out.append(None)
+                continue
+            a = np.empty(n.value)
+            capi.check(self._lib.vg_calibration_get_corners(self._h, dataset, i, a.ctypes.data_as(capi._dp), None))
+            out.append(a.reshape(-1, 2))
+        return out
+
+    def timings(self):
+        """vg_calibration_timings as a dict: where the wall-clock time of this object went, phase by phase (seconds)"""
+        t = capi.CalibrationTimings()
+        capi.check(self._lib.vg_calibration_get_timings(self._h, ctypes.byref(t)))
+        return {name: getattr(t, name) for name, _ in capi.CalibrationTimings._fields_}
+
     def num_datasets(self):
         return self._lib.vg_calibration_num_datasets(self._h)
 

@@ -54,6 +54,14 @@ class SolveSummary(ctypes.Structure):
                 ("message", ctypes.c_char * 160)]
 
 
+class CalibrationTimings(ctypes.Structure):
+    """struct vg_calibration_timings"""
+    _fields_ = [(n, ctypes.c_double) for n in ("read_files_s", "parse_json_s", "geometric_init_s", "refine_total_s", "refine_kernel_s",
+                                               "global_init_s", "assemble_s", "solve_s", "readback_s", "residual_eval_s",
+                                               "residual_format_s")] + \
+               [(n, ctypes.c_int64) for n in ("refine_images", "refine_iterations", "refine_max_iterations", "json_bytes", "residual_lines")]
+
+
 TERMINATION = {0: "CONVERGENCE_FUNCTION", 1: "CONVERGENCE_GRADIENT", 2: "CONVERGENCE_PARAMETER", 3: "NO_CONVERGENCE",
                4: "RADIUS_TOO_SMALL", 5: "FAILURE"}
 
@@ -145,6 +153,9 @@ SIGNATURES = {
     "vg_calibration_get_intrinsics": (ctypes.c_int, [_vp, ctypes.c_char_p, _dp, _ip]),
     "vg_calibration_get_transform": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_int64, _dp, _i64p]),
     "vg_calibration_write_residuals": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_char_p, _dp, _i64p]),
+    "vg_calibration_get_corners": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int64, _dp, _i64p]),
+    "vg_calibration_num_images": (ctypes.c_int64, [_vp, ctypes.c_int]),
+    "vg_calibration_get_timings": (ctypes.c_int, [_vp, ctypes.POINTER(CalibrationTimings)]),
     "vg_reconstruct_point": (ctypes.c_int, [ctypes.c_int, _dp, _dp, _dp]),
     "vg_initial_grid_pose": (ctypes.c_int, [ctypes.c_int, _dp, _dp, _dp, _dp]),
     "vg_init_transform": (ctypes.c_int, [ctypes.c_int, _ip, ctypes.c_int, _dp, _dp, _dp]),

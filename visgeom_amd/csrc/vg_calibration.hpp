@@ -19,15 +19,19 @@
 
 #include <algorithm>
 #include <array>
+#include <charconv>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
 #include <map>
+#include <memory>
 #include <sstream>
 #include <string>
 #include <vector>
 
+#include "vg_host_parallel.hpp"
 #include "vg_internal.hpp"
 #include "vg_json.hpp"
 #include "vg_transf_host.hpp"
@@ -113,23 +117,38 @@ struct ImageData {  // unified_calibration.h:46-87 (the fields the grid residual
     }
 };
 
-// Eigen's default stream format of a row vector: "%g"-style 6 significant digits, coefficients right-aligned to
-// the widest one, separated by one space
+// Eigen's default stream format of a row vector: the stream's default notation with 6 significant digits (what printf's
+// "%g" prints; std::to_chars in general notation with precision 6 is specified as exactly that conversion and is three
+// times faster than snprintf -- 75 against 250 ns per number, identical text on 4 M test values, profiles/NOTES.md round 5),
+// coefficients right-aligned to the widest one, separated by one space
+inline int fmt_g6(double v, char *buf, size_t size)
+{
+    const std::to_chars_result r = std::to_chars(buf, buf + size, v, std::chars_format::general, 6);
+    if (r.ec != std::errc()) return std::snprintf(buf, size, "%g", v);
+    return (int)(r.ptr - buf);
+}
+
+inline void fmt_vec_append(std::string &out, const double *v, int n)
+{
+    char buf[8][32];
+    int len[8];
+    if (n > 8) n = 8;  // the front end prints 2- and 3-vectors
+    int w = 0;
+    for (int i = 0; i < n; i++) {
+        len[i] = fmt_g6(v[i], buf[i], sizeof(buf[i]));
+        w = len[i] > w ? len[i] : w;
+    }
+    for (int i = 0; i < n; i++) {
+        if (i) out += ' ';
+        out.append((size_t)(w - len[i]), ' ');
+        out.append(buf[i], (size_t)len[i]);
+    }
+}
+
 inline std::string fmt_vec(const double *v, int n)
 {
-    std::vector<std::string> s(n);
-    size_t w = 0;
-    for (int i = 0; i < n; i++) {
-        std::ostringstream o;
-        o << v[i];
-        s[i] = o.str();
-        w = s[i].size() > w ? s[i].size() : w;
-    }
     std::string out;
-    for (int i = 0; i < n; i++) {
-        if (i) out += " ";
-        out += std::string(w - s[i].size(), ' ') + s[i];
-    }
+    fmt_vec_append(out, v, n);
     return out;
 }
 
@@ -167,6 +186,7 @@ struct vg_calibration {
     };
     std::vector<OdometryIntrinsic> odometryIntrinsic;
     std::string log;  // what the reference prints to stdout while parsing / solving
+    vg_calibration_timings timings = {};  // where the wall-clock time of this handle went (vg_calibration_get_timings)
 
     vgcal::Array6d &getTransformData(const std::string &name, int idx)  // unified_calibration.h:161-165
     {
@@ -180,6 +200,14 @@ namespace vgcal {
 struct Error {
     int code;
     std::string msg;
+};
+
+// adds the life time of the object to one field of vg_calibration_timings
+struct PhaseClock {
+    double &acc;
+    std::chrono::steady_clock::time_point t0;
+    explicit PhaseClock(double &field) : acc(field), t0(std::chrono::steady_clock::now()) {}
+    ~PhaseClock() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
 };
 
 // One sub-problem on the GPU through the public C ABI: the dataset's chain with a chosen set of constant blocks.
@@ -355,8 +383,12 @@ inline Array6d get_init_transform(vg_calibration *c, Array6d xi, const std::stri
 inline std::vector<Array6d> estimate_initial_grids(vg_calibration *c, const ImageData &data, const std::vector<int> &images)
 {
     std::vector<Array6d> cam_pose(data.detectedCornersVec.size(), Array6d{0, 0, 1, 0, 0, 0});
-    for (int img : images) cam_pose[(size_t)img] = estimate_initial_grid_geometric(c, data, img);
+    {
+        PhaseClock clk(c->timings.geometric_init_s);
+        for (int img : images) cam_pose[(size_t)img] = estimate_initial_grid_geometric(c, data, img);
+    }
     if (!data.doNotSolve && !images.empty()) {
+        PhaseClock clk(c->timings.refine_total_s);
         const int N = (int)data.board.size();
         std::vector<double> board, corners, poses;
         for (auto &pt : data.board) board.insert(board.end(), pt.begin(), pt.end());
@@ -364,10 +396,18 @@ inline std::vector<Array6d> estimate_initial_grids(vg_calibration *c, const Imag
             corners.insert(corners.end(), data.detectedCornersVec[(size_t)img].begin(), data.detectedCornersVec[(size_t)img].end());
             poses.insert(poses.end(), cam_pose[(size_t)img].begin(), cam_pose[(size_t)img].end());
         }
-        const int rc = vg_refine_poses(c->device, nullptr, c->cameraModelMap[data.cameraName], c->intrinsicMap[data.cameraName].data(),
-                                       N, board.data(), (int64_t)images.size(), corners.data(), poses.data(), nullptr, nullptr,
-                                       nullptr, nullptr);
+        std::vector<int32_t> iters(images.size(), 0);
+        double kernel_s = 0.;
+        const int rc = vgi::refine_poses(c->device, nullptr, c->cameraModelMap[data.cameraName], c->intrinsicMap[data.cameraName].data(), N,
+                                         board.data(), (int64_t)images.size(), corners.data(), poses.data(), nullptr, iters.data(), nullptr,
+                                         nullptr, &kernel_s);
         if (rc != VG_OK) throw Error{rc, vg_last_error()};
+        c->timings.refine_kernel_s += kernel_s;
+        c->timings.refine_images += (int64_t)images.size();
+        for (int32_t it : iters) {
+            c->timings.refine_iterations += it;
+            if (it > c->timings.refine_max_iterations) c->timings.refine_max_iterations = it;
+        }
         for (size_t i = 0; i < images.size(); i++)
             for (int k = 0; k < 6; k++) cam_pose[(size_t)images[i]][k] = poses[6 * i + k];
     }
@@ -401,6 +441,7 @@ inline void init_transforms(vg_calibration *c, ImageData &data, const std::strin
             if (transfIdx < seq.size() && !data.detectedCornersVec[transfIdx].empty() && !done[transfIdx]) todo.push_back((int)transfIdx);
         }
         const std::vector<Array6d> cam_pose = estimate_initial_grids(c, data, todo);
+        PhaseClock clk(c->timings.geometric_init_s);
         for (int transfIdx : todo) {
             seq[(size_t)transfIdx] = get_init_transform(c, cam_pose[(size_t)transfIdx], initName, data, transfIdx);
             done[(size_t)transfIdx] = true;
@@ -433,7 +474,10 @@ inline void init_transforms(vg_calibration *c, ImageData &data, const std::strin
                     vals.push_back(&glob_store[l]);
                 }
             }
-            refine_on_gpu(c, data, images, data.transNameVec, data.transStatusVec, vals, is_seq, is_const, 500, 1.);  // SoftLOneLoss(1) :379-401
+            {
+                PhaseClock clk(c->timings.global_init_s);
+                refine_on_gpu(c, data, images, data.transNameVec, data.transStatusVec, vals, is_seq, is_const, 500, 1.);  // SoftLOneLoss(1) :379-401
+            }
             for (size_t l = 0; l < data.transNameVec.size(); l++)
                 if (data.transNameVec[l] == initName) c->globalTransformMap[initName] = glob_store[l][0];
         }
@@ -526,27 +570,91 @@ inline void init_chain_info(vg_calibration *c, ImageData &data, const vgjson::Va
     c->log += "\n";
 }
 
-// readCorners :252-277 : a JSON array of frames, each an array of {camera, points}
-inline void read_corners(ImageData &data, const std::string &file, const std::string &cameraID)
+// readCorners :252-277 : a JSON array of frames, each an array of {camera, points}.  The first entry of a frame whose
+// camera is `cameraID` supplies the frame's corner list (the reference breaks out of its loop there); entries in front of
+// it must name a camera.  Read straight from the text (no value tree), the frames split over the host's threads.
+inline void read_frame_corners(vgjson::Cursor &cur, const std::string &cameraID, size_t n_board, std::vector<double> &cv)
 {
-    const vgjson::Value df = vgjson::parse_file(file);
-    for (auto &frame : df.arr) {
-        data.detectedCornersVec.emplace_back();
-        auto &cv = data.detectedCornersVec.back();
-        for (auto &x : frame.arr)
-            if (x.at("camera").as_string() == cameraID) {
-                for (auto &y : x.at("points").arr) {
-                    const std::vector<double> pt = y.as_vector();
-                    cv.push_back(pt.at(0));
-                    cv.push_back(pt.at(1));
-                }
-                break;
-            }
-        // a non-empty list must have exactly one entry per board point
-        if (!cv.empty() && cv.size() != 2 * data.board.size())
-            throw Error{VG_ERR_INVALID_ARGUMENT, "a frame has " + std::to_string(cv.size() / 2) + " corners, the board has " +
-                                                     std::to_string(data.board.size())};
+    if (cur.peek() != '[') {  // not a list: no entry for any camera
+        cur.skip();
+        return;
     }
+    if (!cur.open('[', ']')) return;
+    bool found = false;
+    do {
+        if (found || cur.peek() != '{') {
+            if (!found) throw std::runtime_error("No such node (camera)");
+            cur.skip();
+            continue;
+        }
+        // one {camera, points} entry; keys in any order, the first occurrence of a key counts (as a lookup by name does)
+        bool has_camera = false, has_points = false, is_mine = false;
+        std::vector<double> pts;
+        if (cur.open('{', '}')) {
+            do {
+                const std::string key = cur.string();
+                cur.colon();
+                if (key == "camera" && !has_camera) {
+                    has_camera = true;
+                    if (cur.peek() != '"') throw std::runtime_error("conversion of data to string failed");
+                    is_mine = cur.string() == cameraID;
+                } else if (key == "points" && !has_points) {
+                    has_points = true;
+                    pts.reserve(2 * n_board);
+                    if (cur.peek() != '[') {
+                        cur.skip();
+                    } else if (cur.open('[', ']')) {
+                        do {  // one [u, v, ...] point: the first two values count
+                            int k = 0;
+                            if (cur.peek() != '[') cur.skip();
+                            else if (cur.open('[', ']')) {
+                                do {
+                                    if (k < 2) pts.push_back(cur.number());
+                                    else (void)cur.number();
+                                    k++;
+                                } while (cur.next(']'));
+                            }
+                            if (k < 2) throw std::runtime_error("a corner needs two coordinates");
+                        } while (cur.next(']'));
+                    }
+                } else {
+                    cur.skip();
+                }
+            } while (cur.next('}'));
+        }
+        if (!has_camera) throw std::runtime_error("No such node (camera)");
+        if (is_mine) {
+            if (!has_points) throw std::runtime_error("No such node (points)");
+            cv.swap(pts);
+            found = true;
+        }
+    } while (cur.next(']'));
+}
+
+inline void read_corners(vg_calibration *c, ImageData &data, const std::string &file, const std::string &cameraID)
+{
+    std::string text;
+    {
+        PhaseClock clk(c->timings.read_files_s);
+        text = vgjson::read_text_file(file);
+    }
+    c->timings.json_bytes += (int64_t)text.size();
+    PhaseClock clk(c->timings.parse_json_s);
+    const std::vector<std::pair<size_t, size_t>> frames = vgjson::element_spans(text);
+    const size_t first = data.detectedCornersVec.size(), n_board = data.board.size();
+    data.detectedCornersVec.resize(first + frames.size());
+    vgpar::parallel_ranges(frames.size(), 64, [&](size_t b, size_t e, int) {
+        for (size_t f = b; f < e; f++) {
+            vgjson::Cursor cur(text.c_str(), frames[f].first, frames[f].second);
+            std::vector<double> &cv = data.detectedCornersVec[first + f];
+            read_frame_corners(cur, cameraID, n_board, cv);
+            if (!cur.at_end()) cur.fail("expected ',' or ']'");
+            // a non-empty list must have exactly one entry per board point
+            if (!cv.empty() && cv.size() != 2 * n_board)
+                throw Error{VG_ERR_INVALID_ARGUMENT, "a frame has " + std::to_string(cv.size() / 2) + " corners, the board has " +
+                                                         std::to_string(n_board)};
+        }
+    });
 }
 
 inline std::string dirname_of(const std::string &path)
@@ -596,7 +704,7 @@ inline void parse_data(vg_calibration *c, const vgjson::Value &root, const std::
             for (int idx : {data.idxUL, data.idxUR, data.idxBL, data.idxBR})
                 if (idx < 0 || idx >= nb) throw Error{VG_ERR_INVALID_ARGUMENT, "board corner index out of range"};
             if (!file.empty() && file[0] != '/') file = base_dir + file;
-            read_corners(data, file, data.cameraName);
+            read_corners(c, data, file, data.cameraName);
             if (type == "images") {
                 // extractGridProjections :996-1023: when the chain's sequence has already been initialised through another
                 // dataset, an image whose counterpart there had no pattern is skipped here as well
@@ -633,7 +741,8 @@ inline void parse_data(vg_calibration *c, const vgjson::Value &root, const std::
             c->intrinsicMap[od.transform] = od.prior;
             std::string file = di.at("data_file").as_string();
             if (!file.empty() && file[0] != '/') file = base_dir + file;
-            const vgjson::Value dataFile = vgjson::parse_file(file);  // the odometry increment measurements
+            const vgjson::Value dataFile = vgjson::parse_file(file, &c->timings.read_files_s, &c->timings.parse_json_s,
+                                                              &c->timings.json_bytes);  // the odometry increment measurements
             for (auto &dataPoint : dataFile.arr) {
                 od.deltaQ.emplace_back();
                 for (auto &x : dataPoint.arr) {
@@ -771,7 +880,7 @@ int vg_calibration_add_file(vg_calibration *c, const char *json_path)  // addRes
 {
     if (!c || !json_path) return vgi::fail(VG_ERR_INVALID_ARGUMENT, "NULL argument");
     try {
-        const vgjson::Value root = vgjson::parse_file(json_path);
+        const vgjson::Value root = vgjson::parse_file(json_path, &c->timings.read_files_s, &c->timings.parse_json_s, &c->timings.json_bytes);
         vgcal::parse_transforms(c, root);
         vgcal::parse_cameras(c, root);
         vgcal::parse_data(c, root, vgcal::dirname_of(json_path));
@@ -787,6 +896,7 @@ int vg_calibration_compute(vg_calibration *c, const vg_solve_options *options, v
 {
     if (!c) return vgi::fail(VG_ERR_INVALID_ARGUMENT, "calibration is NULL");
     vg_problem *p = nullptr;
+    std::unique_ptr<vgcal::PhaseClock> clk(new vgcal::PhaseClock(c->timings.assemble_s));
     int rc = vg_problem_create(&p, c->device, nullptr);
     if (rc != VG_OK) return rc;
     auto bail = [&](int code) {
@@ -850,7 +960,9 @@ int vg_calibration_compute(vg_calibration *c, const vg_solve_options *options, v
         if ((rc = vg_problem_add_transformation_prior(p, tfId[pr.first], pr.second.data())) != VG_OK) return bail(rc);
     if ((rc = vg_problem_finalize(p)) != VG_OK) return bail(rc);
     vg_solve_summary local;
+    clk.reset(new vgcal::PhaseClock(c->timings.solve_s));
     if ((rc = vg_problem_solve(p, options, summary ? summary : &local)) != VG_OK) return bail(rc);
+    clk.reset(new vgcal::PhaseClock(c->timings.readback_s));
     std::vector<double> x((size_t)vg_problem_num_parameters(p));
     if ((rc = vg_problem_get_parameters(p, x.data())) != VG_OK) return bail(rc);
     for (auto &kv : c->intrinsicMap) {
@@ -915,6 +1027,31 @@ int64_t vg_calibration_log(vg_calibration *c, char *buf, int64_t size)
 
 int vg_calibration_num_datasets(const vg_calibration *c) { return c ? (int)c->dataVec.size() : -1; }
 
+int64_t vg_calibration_num_images(const vg_calibration *c, int dataset)
+{
+    if (!c || dataset < 0 || dataset >= (int)c->dataVec.size()) return -1;
+    return (int64_t)c->dataVec[(size_t)dataset].detectedCornersVec.size();
+}
+
+int vg_calibration_get_corners(const vg_calibration *c, int dataset, int64_t image, double *out, int64_t *count)
+{
+    if (!c) return vgi::fail(VG_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (dataset < 0 || dataset >= (int)c->dataVec.size()) return vgi::fail(VG_ERR_INVALID_ARGUMENT, "dataset index out of range");
+    const auto &all = c->dataVec[(size_t)dataset].detectedCornersVec;
+    if (image < 0 || image >= (int64_t)all.size()) return vgi::fail(VG_ERR_INVALID_ARGUMENT, "image index out of range");
+    const std::vector<double> &cv = all[(size_t)image];
+    if (count) *count = (int64_t)cv.size();
+    if (out && !cv.empty()) std::memcpy(out, cv.data(), sizeof(double) * cv.size());
+    return VG_OK;
+}
+
+int vg_calibration_get_timings(const vg_calibration *c, vg_calibration_timings *out)
+{
+    if (!c || !out) return vgi::fail(VG_ERR_INVALID_ARGUMENT, "NULL argument");
+    *out = c->timings;
+    return VG_OK;
+}
+
 int vg_calibration_get_intrinsics(vg_calibration *c, const char *camera, double *out, int *count)
 {
     if (!c || !camera) return vgi::fail(VG_ERR_INVALID_ARGUMENT, "NULL argument");
@@ -942,56 +1079,98 @@ int vg_calibration_get_transform(vg_calibration *c, const char *name, int64_t in
 
 /* writeImageResidual, unified_calibration.cpp:1186-1292: one line per corner of every image that has corners,
  *   err.x err.y   proj.x proj.y   tx ty tz rx ry rz        (err = detected - projected, :1210-1213)
- * The residuals come from the GPU (vg_block_evaluate on the composed chain).  sigma_out[n_images] (may be NULL)
- * receives sqrt(sum |err|^2 / (N - 2)) per image (:1217), 0 for skipped images. */
+ * The projections come from the GPU: the images' composed chains (computeTransforms :1160-1183, host) form the sequence
+ * of ONE resident problem whose observations are zero, so that its residuals r = proj - 0 are the projections of every
+ * image in one launch (round 4 evaluated one block per image: 10 000 launches and copies, 0.5 s; formatting through
+ * iostreams another 3 s -- profiles/NOTES.md round 5).  The text is produced by the host's threads, image ranges side by
+ * side, and written in one piece.  sigma_out[n_images] (may be NULL) receives sqrt(sum |err|^2 / (N - 2)) per image
+ * (:1217), 0 for skipped images. */
 int vg_calibration_write_residuals(vg_calibration *c, int dataset, const char *path, double *sigma_out, int64_t *outliers_out)
 {
     if (!c || !path) return vgi::fail(VG_ERR_INVALID_ARGUMENT, "NULL argument");
     if (dataset < 0 || dataset >= (int)c->dataVec.size()) return vgi::fail(VG_ERR_INVALID_ARGUMENT, "dataset index out of range");
     const vgcal::ImageData &data = c->dataVec[(size_t)dataset];
-    std::ofstream f(path);
+    std::FILE *f = std::fopen(path, "wb");
     if (!f) return vgi::fail(VG_ERR_INVALID_ARGUMENT, std::string("cannot write ") + path);
+    struct Closer {
+        std::FILE *f;
+        ~Closer() { if (f) std::fclose(f); }
+    } closer{f};
     const int N = (int)data.board.size();
-    std::vector<double> board;
-    for (auto &pt : data.board) board.insert(board.end(), pt.begin(), pt.end());
-    const int st[1] = {VG_TRANSFORM_DIRECT};
-    std::vector<double> res(2 * (size_t)N), zeros(2 * (size_t)N, 0.);
-    int64_t outliers = 0;
-    vg_block *blk = nullptr;
-    // projecting = evaluating the residual against zero observations: r = proj - 0
-    int rc = vg_block_create(&blk, c->device, c->cameraModelMap[data.cameraName], 1, st, N, board.data(), zeros.data());
-    if (rc != VG_OK) return rc;
-    for (size_t transfIdx = 0; transfIdx < data.detectedCornersVec.size(); transfIdx++) {
+    const size_t n_all = data.detectedCornersVec.size();
+    std::vector<size_t> images;  // the images that have corners (:1198)
+    for (size_t transfIdx = 0; transfIdx < n_all; transfIdx++) {
         if (sigma_out) sigma_out[transfIdx] = 0.;
-        if (data.detectedCornersVec[transfIdx].empty()) continue;
-        vgcal::Array6d xi = {0, 0, 0, 0, 0, 0};  // computeTransforms :1160-1183
-        for (size_t i = 0; i < data.transNameVec.size(); i++) {
-            const vgcal::Array6d &t = c->getTransformData(data.transNameVec[i], (int)transfIdx);
-            xi = data.transStatusVec[i] == VG_TRANSFORM_DIRECT ? vgcal::compose(xi, t) : vgcal::compose_inverse(xi, t);
-        }
-        const double *params[2] = {c->intrinsicMap[data.cameraName].data(), xi.data()};
-        if ((rc = vg_block_evaluate(blk, params, res.data(), nullptr)) != VG_OK) {
-            vg_block_destroy(blk);
-            return rc;
-        }
-        double stdAcc = 0;
-        const std::vector<double> &det = data.detectedCornersVec[transfIdx];
-        for (int i = 0; i < N; i++) {
-            const double proj[2] = {res[2 * (size_t)i], res[2 * (size_t)i + 1]};
-            const double err[2] = {det[2 * (size_t)i] - proj[0], det[2 * (size_t)i + 1] - proj[1]};
-            f << vgcal::fmt_vec(err, 2) << "   " << vgcal::fmt_vec(proj, 2) << "   " << vgcal::fmt_transf(xi) << "\n";
-            stdAcc += err[0] * err[0] + err[1] * err[1];
-        }
-        const double sigma = std::sqrt(stdAcc / (N - 2));
-        if (sigma_out) sigma_out[transfIdx] = sigma;
-        for (int i = 0; i < N; i++) {
-            const double ex = det[2 * (size_t)i] - res[2 * (size_t)i], ey = det[2 * (size_t)i + 1] - res[2 * (size_t)i + 1];
-            const double en = std::sqrt(ex * ex + ey * ey);
-            if (!(en < 3.6 * sigma && en < 1.)) outliers++;  // :1222
-        }
+        if (!data.detectedCornersVec[transfIdx].empty()) images.push_back(transfIdx);
     }
-    vg_block_destroy(blk);
-    if (outliers_out) *outliers_out = outliers;
+    if (outliers_out) *outliers_out = 0;
+    if (images.empty() || N == 0) return VG_OK;
+    const size_t n = images.size();
+    std::vector<double> xi(6 * n), proj(2 * (size_t)N * n);
+    {
+        vgcal::PhaseClock clk(c->timings.residual_eval_s);
+        for (size_t k = 0; k < n; k++) {  // computeTransforms :1160-1183
+            vgcal::Array6d acc = {0, 0, 0, 0, 0, 0};
+            for (size_t i = 0; i < data.transNameVec.size(); i++) {
+                const vgcal::Array6d &t = c->getTransformData(data.transNameVec[i], (int)images[k]);
+                acc = data.transStatusVec[i] == VG_TRANSFORM_DIRECT ? vgcal::compose(acc, t) : vgcal::compose_inverse(acc, t);
+            }
+            std::memcpy(&xi[6 * k], acc.data(), sizeof(double) * 6);
+        }
+        std::vector<double> board;
+        for (auto &pt : data.board) board.insert(board.end(), pt.begin(), pt.end());
+        const std::vector<double> zeros(2 * (size_t)N * n, 0.);
+        vg_problem *p = nullptr;
+        int rc = vg_problem_create(&p, c->device, nullptr);
+        if (rc != VG_OK) return rc;
+        int cam = -1, seq = -1, ds = -1;
+        const int st[1] = {VG_TRANSFORM_DIRECT};
+        if ((rc = vg_problem_add_camera(p, c->cameraModelMap[data.cameraName], c->intrinsicMap[data.cameraName].data(), 1, &cam)) == VG_OK &&
+            (rc = vg_problem_add_transform(p, 0, 1, (int64_t)n, xi.data(), &seq)) == VG_OK &&
+            (rc = vg_problem_add_dataset(p, cam, 1, &seq, st, N, board.data(), (int64_t)n, nullptr, zeros.data(), &ds)) == VG_OK &&
+            (rc = vg_problem_finalize(p)) == VG_OK)
+            rc = vg_dataset_evaluate_to_host(p, ds, proj.data(), nullptr, nullptr);  // projecting = the residual against zero observations
+        vg_problem_destroy(p);
+        if (rc != VG_OK) return rc;
+    }
+    vgcal::PhaseClock clk(c->timings.residual_format_s);
+    std::vector<std::string> text((size_t)vgpar::host_threads());
+    std::vector<int64_t> outliers(text.size(), 0);
+    const int parts = vgpar::parallel_ranges(n, 64, [&](size_t b, size_t e, int part) {
+        std::string &out = text[(size_t)part];
+        out.reserve((e - b) * (size_t)N * 100);
+        for (size_t k = b; k < e; k++) {
+            const std::vector<double> &det = data.detectedCornersVec[images[k]];
+            const double *pr = &proj[2 * (size_t)N * k];
+            const std::string pose = "   " + vgcal::fmt_vec(&xi[6 * k], 3) + " " + vgcal::fmt_vec(&xi[6 * k + 3], 3) + "\n";
+            double stdAcc = 0;
+            for (int i = 0; i < N; i++) {
+                const double err[2] = {det[2 * (size_t)i] - pr[2 * i], det[2 * (size_t)i + 1] - pr[2 * i + 1]};
+                vgcal::fmt_vec_append(out, err, 2);
+                out += "   ";
+                vgcal::fmt_vec_append(out, pr + 2 * i, 2);
+                out += pose;
+                stdAcc += err[0] * err[0] + err[1] * err[1];
+            }
+            const double sigma = std::sqrt(stdAcc / (N - 2));
+            if (sigma_out) sigma_out[images[k]] = sigma;
+            for (int i = 0; i < N; i++) {
+                const double ex = det[2 * (size_t)i] - pr[2 * i], ey = det[2 * (size_t)i + 1] - pr[2 * i + 1];
+                const double en = std::sqrt(ex * ex + ey * ey);
+                if (!(en < 3.6 * sigma && en < 1.)) outliers[(size_t)part]++;  // :1222
+            }
+        }
+    });
+    int64_t total = 0;
+    for (int k = 0; k < parts; k++) {
+        if (!text[(size_t)k].empty() && std::fwrite(text[(size_t)k].data(), 1, text[(size_t)k].size(), f) != text[(size_t)k].size())
+            return vgi::fail(VG_ERR_INVALID_ARGUMENT, std::string("cannot write ") + path);
+        total += outliers[(size_t)k];
+    }
+    closer.f = nullptr;
+    if (std::fclose(f) != 0) return vgi::fail(VG_ERR_INVALID_ARGUMENT, std::string("cannot write ") + path);
+    c->timings.residual_lines += (int64_t)n * N;
+    if (outliers_out) *outliers_out = total;
     return VG_OK;
 }
 

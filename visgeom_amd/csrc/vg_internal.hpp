@@ -180,4 +180,9 @@ bool gram_merge_covers_all(const vg_problem *p);  // every non-empty dataset goe
 bool gram_needs_frames(const vg_problem *p);  // false when every dataset's Gram kernel walks its chain itself
 bool gram_dataset_needs_frames(const vg_problem *p, int dataset_id);  // the same question for one dataset
 int gram_sum_into(vg_problem *p, int dataset_id, const double *gram, double *sum);
+// vg_refine_poses with a clock (vg_refine_impl.hpp): kernel_seconds (may be NULL) receives the duration of the
+// vg_pose_lm_kernel launch alone, measured with HIP events on the launch stream
+int refine_poses(int device, void *hip_stream, int model, const double *intrinsics, int n_points, const double *board, int64_t n_images,
+                 const double *corners, double *poses, const vg_solve_options *options, int32_t *iterations, double *final_cost,
+                 int32_t *termination, double *kernel_seconds);
 }  // namespace vgi

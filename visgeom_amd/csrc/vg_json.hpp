@@ -5,7 +5,11 @@
 #pragma once
 
 #include <cctype>
+#include <cmath>
+#include <chrono>
+#include <cstdint>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <memory>
 #include <sstream>
@@ -193,14 +197,357 @@ private:
     }
 };
 
-inline Value parse_file(const std::string &path)
+// ---------------------------------------------------------------------------------------------------------------
+// Streaming access for the bulk files (a 10 000-image corner file is 40 MB of text = 2 M numbers): the same grammar as
+// Parser, read straight out of the text without building Values (the tree of such a file is 3 M nodes of 100 bytes;
+// building it was 1.5 of the 1.7 s the front end spent on the file, profiles/NOTES.md round 5).  A Cursor validates
+// what it skips; element_spans() cuts a top-level array into its elements so that they can be read by several threads.
+class Cursor {
+public:
+    Cursor(const char *text, size_t begin, size_t end) : s(text), i(begin), n(end) {}
+    size_t pos() const { return i; }
+    bool at_end()
+    {
+        ws();
+        return i >= n;
+    }
+    [[noreturn]] void fail(const std::string &m) const
+    {
+        throw std::runtime_error("JSON parse error at offset " + std::to_string(i) + ": " + m);
+    }
+    void ws()
+    {
+        while (i < n && (s[i] == ' ' || s[i] == '\n' || s[i] == '\t' || s[i] == '\r' || s[i] == '\f' || s[i] == '\v')) i++;
+    }
+    char peek()
+    {
+        ws();
+        if (i >= n) fail("unexpected end");
+        return s[i];
+    }
+    // '[' ... : returns false for an empty array (the closing bracket is consumed)
+    bool open(char bracket, char closing)
+    {
+        if (peek() != bracket) fail(std::string("expected '") + bracket + "'");
+        i++;
+        ws();
+        if (i < n && s[i] == closing) {
+            i++;
+            return false;
+        }
+        return true;
+    }
+    // after an element: true = another one follows (the comma is consumed), false = the container is closed
+    bool next(char closing)
+    {
+        ws();
+        if (i < n && s[i] == ',') {
+            i++;
+            return true;
+        }
+        if (i < n && s[i] == closing) {
+            i++;
+            return false;
+        }
+        fail(std::string("expected ',' or '") + closing + "'");
+    }
+    void colon()
+    {
+        ws();
+        if (i >= n || s[i] != ':') fail("expected ':'");
+        i++;
+    }
+    std::string string()
+    {
+        if (peek() != '"') fail("expected a string");
+        // the escapes are rare (camera names): take the slow path through Parser's routine only when one shows up
+        size_t j = i + 1;
+        while (j < n && s[j] != '"' && s[j] != '\\') j++;
+        if (j < n && s[j] == '"') {
+            std::string out(s + i + 1, j - i - 1);
+            i = j + 1;
+            return out;
+        }
+        std::string out;
+        i++;
+        while (i < n && s[i] != '"') {
+            if (s[i] == '\\') {
+                i++;
+                if (i >= n) fail("bad escape");
+                switch (s[i]) {
+                case 'n': out += '\n'; break;
+                case 't': out += '\t'; break;
+                case 'r': out += '\r'; break;
+                case 'b': out += '\b'; break;
+                case 'f': out += '\f'; break;
+                case 'u': {
+                    if (i + 4 >= n) fail("bad \\u escape");
+                    const unsigned cp = (unsigned)std::strtoul(std::string(s + i + 1, 4).c_str(), nullptr, 16);
+                    i += 4;
+                    if (cp < 0x80) out += (char)cp;
+                    else if (cp < 0x800) { out += (char)(0xC0 | (cp >> 6)); out += (char)(0x80 | (cp & 0x3F)); }
+                    else { out += (char)(0xE0 | (cp >> 12)); out += (char)(0x80 | ((cp >> 6) & 0x3F)); out += (char)(0x80 | (cp & 0x3F)); }
+                    break;
+                }
+                default: out += s[i];
+                }
+            } else {
+                out += s[i];
+            }
+            i++;
+        }
+        if (i >= n) fail("unterminated string");
+        i++;
+        return out;
+    }
+    // a value used as a number: Value::as_number's conversions (a number, a numeric string, a boolean)
+    double number()
+    {
+        const char c = peek();
+        if (c == '"') {
+            const std::string t = string();
+            char *end = nullptr;
+            const double v = std::strtod(t.c_str(), &end);
+            if (end != t.c_str() && *end == 0) return v;
+            throw std::runtime_error("conversion of data to number failed");
+        }
+        if (c == 't' && n - i >= 4 && std::memcmp(s + i, "true", 4) == 0) { i += 4; return 1.; }
+        if (c == 'f' && n - i >= 5 && std::memcmp(s + i, "false", 5) == 0) { i += 5; return 0.; }
+        if (c == '[' || c == '{' || c == 'n') throw std::runtime_error("conversion of data to number failed");
+        return raw_number();
+    }
+    // validates and skips one value of any kind
+    void skip(int depth = 0)
+    {
+        if (depth > 256) fail("nesting too deep");
+        const char c = peek();
+        if (c == '{') {
+            if (!open('{', '}')) return;
+            do {
+                if (peek() != '"') fail("expected a key");
+                (void)string();
+                colon();
+                skip(depth + 1);
+            } while (next('}'));
+        } else if (c == '[') {
+            if (!open('[', ']')) return;
+            do skip(depth + 1);
+            while (next(']'));
+        } else if (c == '"') {
+            (void)string();
+        } else if (c == 't' && n - i >= 4 && std::memcmp(s + i, "true", 4) == 0) {
+            i += 4;
+        } else if (c == 'f' && n - i >= 5 && std::memcmp(s + i, "false", 5) == 0) {
+            i += 5;
+        } else if (c == 'n' && n - i >= 4 && std::memcmp(s + i, "null", 4) == 0) {
+            i += 4;
+        } else {
+            (void)raw_number();
+        }
+    }
+
+private:
+    const char *s;  // NUL-terminated behind `n` or beyond (std::string storage): strtod may look one character past a number
+    size_t i, n;
+    // decimal text -> double, correctly rounded (the value strtod returns), without calling into libc for the common shapes
+    // (glibc's strtod does not scale over threads in this image -- 2 M conversions take 0.2 s on one thread and on eight,
+    // profiles/NOTES.md round 5 -- and the corner files are 2 M numbers of 16-17 digits):
+    //   * up to 15 significant digits and a decimal exponent within +-22: the digits and the power of ten are exact
+    //     doubles, one IEEE multiplication or division rounds once (Clinger's fast path);
+    //   * up to 19 digits (a 64-bit integer m) and a decimal exponent e within +-19: m * 10^e is an exact 128-bit integer
+    //     (e >= 0), or the 128-bit quotient (m << s) / 10^-e with the remainder as a sticky bit carries >= 63 significant
+    //     bits (e < 0); the integer -> double conversion rounds to nearest even once.  Values there lie in [1e-19, 2e38]:
+    //     no subnormals, no overflow;
+    //   * anything else (longer digit strings, large exponents, "inf", hex floats ...): strtod, as Parser does.
+    double raw_number()
+    {
+        static const double kPow10[23] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11,
+                                          1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+        static const unsigned long long kIntPow10[20] = {1ull, 10ull, 100ull, 1000ull, 10000ull, 100000ull, 1000000ull, 10000000ull,
+                                                         100000000ull, 1000000000ull, 10000000000ull, 100000000000ull,
+                                                         1000000000000ull, 10000000000000ull, 100000000000000ull,
+                                                         1000000000000000ull, 10000000000000000ull, 100000000000000000ull,
+                                                         1000000000000000000ull, 10000000000000000000ull};
+        const size_t start = i;
+        size_t j = i;
+        bool neg = false;
+        if (j < n && (s[j] == '-' || s[j] == '+')) neg = s[j++] == '-';
+        unsigned long long m = 0;
+        int digits = 0, exp10 = 0;
+        bool any = false, simple = true;
+        auto digit = [&](char ch) {
+            any = true;
+            if (digits || ch != '0') {
+                if (digits < 19) m = m * 10 + (unsigned)(ch - '0');
+                else simple = false;  // a twentieth significant digit: strtod
+                digits++;
+            }
+        };
+        while (j < n && s[j] >= '0' && s[j] <= '9') digit(s[j++]);
+        if (j < n && s[j] == '.') {
+            j++;
+            while (j < n && s[j] >= '0' && s[j] <= '9') {
+                digit(s[j++]);
+                exp10--;
+            }
+        }
+        if (!any) simple = false;  // "inf", "nan", ".": whatever strtod makes of it, as Parser does
+        if (simple && j < n && (s[j] == 'e' || s[j] == 'E')) {
+            size_t k = j + 1;
+            bool eneg = false;
+            if (k < n && (s[k] == '-' || s[k] == '+')) eneg = s[k++] == '-';
+            int e = 0;
+            bool edig = false;
+            while (k < n && s[k] >= '0' && s[k] <= '9') {
+                edig = true;
+                if (e < 10000) e = e * 10 + (s[k] - '0');
+                k++;
+            }
+            if (edig) {
+                exp10 += eneg ? -e : e;
+                j = k;
+            }
+        }
+        if (simple && j < n && (s[j] == 'x' || s[j] == 'X' || s[j] == 'p' || s[j] == 'P')) simple = false;  // hex float
+        if (simple && m == 0) {
+            i = j;
+            return neg ? -0. : 0.;
+        }
+        if (simple && digits <= 15 && exp10 >= -22 && exp10 <= 22) {
+            double v = (double)m;
+            v = exp10 < 0 ? v / kPow10[-exp10] : v * kPow10[exp10];
+            i = j;
+            return neg ? -v : v;
+        }
+        if (simple && exp10 >= -19 && exp10 <= 19) {
+            typedef unsigned __int128 u128;
+            double v;
+            if (exp10 >= 0) {
+                v = (double)((u128)m * kIntPow10[exp10]);  // < 2^64 * 2^63.2: exact
+            } else {
+                const int shift = 63 + __builtin_clzll(m);  // m << shift has its leading bit at position 126
+                const u128 num = (u128)m << shift;
+                const u128 den = kIntPow10[-exp10];
+                const u128 q = num / den;  // >= 2^126 / 2^63.2: at least 63 significant bits
+                const u128 q2 = (q << 1) | (u128)(num % den != 0);  // the remainder as a sticky bit below them
+                v = std::ldexp((double)q2, -(shift + 1));
+            }
+            i = j;
+            return neg ? -v : v;
+        }
+        char *end = nullptr;
+        const double v = std::strtod(s + start, &end);
+        if (end == s + start) fail("unexpected character");
+        i = (size_t)(end - s);
+        if (i > n) fail("unexpected end");
+        return v;
+    }
+};
+
+// the [begin, end) spans of the elements of the top-level array of `text` (one structural pass: brackets outside strings)
+inline std::vector<std::pair<size_t, size_t>> element_spans(const std::string &text)
 {
-    std::ifstream f(path);
+    std::vector<std::pair<size_t, size_t>> spans;
+    Cursor c(text.c_str(), 0, text.size());
+    if (c.peek() != '[') c.fail("expected '['");
+    const char *s = text.c_str();
+    const size_t n = text.size();
+    size_t i = c.pos() + 1;
+    int depth = 1;
+    size_t start = std::string::npos;
+    bool closed = false;
+    // bytes that cannot change the state once an element has begun (digits, signs, letters, blanks ...): skipped in a tight loop
+    static const std::vector<unsigned char> structural = [] {
+        std::vector<unsigned char> t(256, 0);
+        for (unsigned char ch : {'"', '[', ']', '{', '}', ','}) t[ch] = 1;
+        return t;
+    }();
+    const unsigned char *special = structural.data();
+    for (; i < n && !closed; i++) {
+        if (start != std::string::npos)
+            while (i < n && !special[(unsigned char)s[i]]) i++;
+        if (i >= n) break;
+        const char ch = s[i];
+        switch (ch) {
+        case '"': {
+            if (depth == 1 && start == std::string::npos) start = i;
+            size_t j = i + 1;
+            for (;;) {
+                const char *q = (const char *)std::memchr(s + j, '"', n - j);
+                if (!q) throw std::runtime_error("JSON parse error at offset " + std::to_string(i) + ": unterminated string");
+                j = (size_t)(q - s);
+                size_t b = j;
+                while (b > i + 1 && s[b - 1] == '\\') b--;
+                if (((j - b) & 1) == 0) break;  // an even number of backslashes in front: the quote closes the string
+                j++;
+            }
+            i = j;
+            break;
+        }
+        case '[':
+        case '{':
+            if (depth == 1 && start == std::string::npos) start = i;
+            if (++depth > 257) throw std::runtime_error("JSON parse error at offset " + std::to_string(i) + ": nesting too deep");
+            break;
+        case ']':
+        case '}':
+            if (--depth == 0) {
+                if (ch != ']') throw std::runtime_error("JSON parse error at offset " + std::to_string(i) + ": expected ',' or ']'");
+                if (start != std::string::npos) spans.emplace_back(start, i);
+                else if (!spans.empty()) throw std::runtime_error("JSON parse error at offset " + std::to_string(i) + ": unexpected character");
+                closed = true;
+            }
+            break;
+        case ',':
+            if (depth == 1) {
+                if (start == std::string::npos) throw std::runtime_error("JSON parse error at offset " + std::to_string(i) + ": unexpected character");
+                spans.emplace_back(start, i);
+                start = std::string::npos;
+            }
+            break;
+        case ' ': case '\n': case '\t': case '\r': case '\f': case '\v': break;
+        default:
+            if (depth == 1 && start == std::string::npos) start = i;
+        }
+    }
+    if (!closed) throw std::runtime_error("JSON parse error at offset " + std::to_string(n) + ": unexpected end");
+    Cursor rest(text.c_str(), i, n);
+    if (!rest.at_end()) rest.fail("trailing characters");
+    return spans;
+}
+
+inline std::string read_text_file(const std::string &path)
+{
+    std::string text;
+    std::ifstream f(path, std::ios::binary);
     if (!f) throw std::runtime_error("cannot open " + path);
-    std::stringstream ss;
-    ss << f.rdbuf();
-    const std::string text = ss.str();
-    return Parser(text).parse();
+    f.seekg(0, std::ios::end);
+    const std::streamoff n = f.tellg();
+    f.seekg(0, std::ios::beg);
+    if (n > 0) {
+        text.resize((size_t)n);
+        f.read(&text[0], n);
+        text.resize((size_t)f.gcount());
+    } else {  // not seekable: stream it
+        std::stringstream ss;
+        ss << f.rdbuf();
+        text = ss.str();
+    }
+    return text;
+}
+
+// read_seconds / parse_seconds / bytes (each may be NULL) are ADDED to: the front end's phase clock
+inline Value parse_file(const std::string &path, double *read_seconds = nullptr, double *parse_seconds = nullptr, int64_t *bytes = nullptr)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    const std::string text = read_text_file(path);
+    const auto t1 = std::chrono::steady_clock::now();
+    Value v = Parser(text).parse();
+    const auto t2 = std::chrono::steady_clock::now();
+    if (read_seconds) *read_seconds += std::chrono::duration<double>(t1 - t0).count();
+    if (parse_seconds) *parse_seconds += std::chrono::duration<double>(t2 - t1).count();
+    if (bytes) *bytes += (int64_t)text.size();
+    return v;
 }
 
 }  // namespace vgjson

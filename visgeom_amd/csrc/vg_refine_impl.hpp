@@ -4,10 +4,11 @@
 #include "vg_internal.hpp"
 #include "vg_pose_lm.hpp"
 
-extern "C" int vg_refine_poses(int device, void *hip_stream, int model, const double *intrinsics, int n_points, const double *board,
-                               int64_t n_images, const double *corners, double *poses, const vg_solve_options *options,
-                               int32_t *iterations, double *final_cost, int32_t *termination)
+int vgi::refine_poses(int device, void *hip_stream, int model, const double *intrinsics, int n_points, const double *board, int64_t n_images,
+                      const double *corners, double *poses, const vg_solve_options *options, int32_t *iterations, double *final_cost,
+                      int32_t *termination, double *kernel_seconds)
 {
+    if (kernel_seconds) *kernel_seconds = 0.;
     using vgi::fail;
     const int K = vg::num_intrinsics(model);
     if (K < 0) return fail(VG_ERR_INVALID_ARGUMENT, "unknown camera model");
@@ -75,16 +76,43 @@ extern "C" int vg_refine_poses(int device, void *hip_stream, int model, const do
     a.dmin = o.min_lm_diagonal;
     a.dmax = o.max_lm_diagonal;
     const dim3 grid((unsigned int)((n_images + vg::kValuImagesPerBlock - 1) / vg::kValuImagesPerBlock)), blk(vg::kValuThreads);
+    struct Events {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        ~Events()
+        {
+            if (e0) (void)hipEventDestroy(e0);
+            if (e1) (void)hipEventDestroy(e1);
+        }
+    } ev;
+    if (kernel_seconds) {
+        VG_HIP(hipEventCreate(&ev.e0));
+        VG_HIP(hipEventCreate(&ev.e1));
+        VG_HIP(hipEventRecord(ev.e0, st));
+    }
     switch (model) {
     case VG_MODEL_EUCM: hipLaunchKernelGGL(vg::vg_pose_lm_kernel<vg::kEUCM>, grid, blk, 0, st, a); break;
     case VG_MODEL_UCM: hipLaunchKernelGGL(vg::vg_pose_lm_kernel<vg::kUCM>, grid, blk, 0, st, a); break;
     default: hipLaunchKernelGGL(vg::vg_pose_lm_kernel<vg::kMEI>, grid, blk, 0, st, a); break;
     }
     VG_HIP(hipGetLastError());
+    if (kernel_seconds) VG_HIP(hipEventRecord(ev.e1, st));
     VG_HIP(hipMemcpyAsync(poses, d.poses, sizeof(double) * 6 * n, hipMemcpyDeviceToHost, st));
     if (iterations) VG_HIP(hipMemcpyAsync(iterations, d.it, sizeof(int) * n, hipMemcpyDeviceToHost, st));
     if (final_cost) VG_HIP(hipMemcpyAsync(final_cost, d.cost, sizeof(double) * n, hipMemcpyDeviceToHost, st));
     if (termination) VG_HIP(hipMemcpyAsync(termination, d.term, sizeof(int) * n, hipMemcpyDeviceToHost, st));
     VG_HIP(hipStreamSynchronize(st));
+    if (kernel_seconds) {
+        float ms = 0.f;
+        VG_HIP(hipEventElapsedTime(&ms, ev.e0, ev.e1));
+        *kernel_seconds = 1e-3 * (double)ms;
+    }
     return VG_OK;
+}
+
+extern "C" int vg_refine_poses(int device, void *hip_stream, int model, const double *intrinsics, int n_points, const double *board,
+                               int64_t n_images, const double *corners, double *poses, const vg_solve_options *options,
+                               int32_t *iterations, double *final_cost, int32_t *termination)
+{
+    return vgi::refine_poses(device, hip_stream, model, intrinsics, n_points, board, n_images, corners, poses, options, iterations,
+                             final_cost, termination, nullptr);
 }

@@ -427,6 +427,54 @@ def write_calibration_json(directory, d, model, name="calib", camera="cam", sequ
     return path
 
 
+def _dump_corner_frames(path, cameras_and_corners):
+    """the ir_data "data_file" layout (unified_calibration.cpp:252-277): a list of frames, each a list of {camera, points};
+    cameras_and_corners = [(camera name, corners [n, N, 2])], all with the same n.  Written row by row ('%.17g' round-trips a
+    double) -- json.dump of 10 000 x 96 nested lists takes four seconds, this takes one."""
+    n = cameras_and_corners[0][1].shape[0]
+    per_cam = []
+    for name, arr in cameras_and_corners:
+        flat = np.ascontiguousarray(arr, dtype=np.float64).reshape(n, -1, 2)
+        rows = ["[%s, %s]" % (repr(float(u)), repr(float(v))) for u, v in flat.reshape(-1, 2)]
+        N = flat.shape[1]
+        per_cam.append(['{"camera": "%s", "points": [%s]}' % (name, ", ".join(rows[i * N:(i + 1) * N])) for i in range(n)])
+    with open(path, "w") as f:
+        f.write("[")
+        for i in range(n):
+            f.write(("" if i == 0 else ", ") + "[" + ", ".join(pc[i] for pc in per_cam) + "]")
+        f.write("]")
+
+
+def write_stereo_json(directory, d, name="stereo"):
+    """Config 3 as a calibration file in the shape of data/calib_stereo_example.json: two EUCM cameras, the pair's pose sequence
+    initialised from scratch through camera 1 ("init": "xiCamBoard"), the global xiCam12 WITHOUT a prior, initialised through
+    camera 2's dataset ("init": "xiCam12": the 4-corner pose of the first frame, then initGlobalTransform over all frames,
+    unified_calibration.cpp:358-429), chain [xiCam12 inverse, xiCamBoard direct] (:51-53,88-91).  One corner file holds both
+    cameras' entries of every frame."""
+    import json
+    import os
+
+    corners_file = name + "_corners.json"
+    _dump_corner_frames(os.path.join(directory, corners_file), [("camera1", d["corners1"]), ("camera2", d["corners2"])])
+    obj = {"points": d["board"].tolist(), "corner_ul": 0, "corner_ur": BOARD_COLS - 1,
+           "corner_bl": BOARD_COLS * (BOARD_ROWS - 1), "corner_br": BOARD_COLS * BOARD_ROWS - 1}
+
+    def entry(cam, init, chain):
+        return {"type": "ir_data", "camera": cam, "init": init, "parameters": [], "object": obj, "image_width": IMAGE_W,
+                "image_height": IMAGE_H, "transform_chain": [{"name": n, "direct": dr} for n, dr in chain], "data_file": corners_file}
+
+    root = {"transformations": [{"name": "xiCamBoard", "global": False, "constant": False, "prior": False},
+                                {"name": "xiCam12", "global": True, "constant": False, "prior": False}],
+            "cameras": [{"name": "camera1", "type": "eucm", "constant": False, "value": d["init_intrinsics1"].tolist()},
+                        {"name": "camera2", "type": "eucm", "constant": False, "value": d["init_intrinsics2"].tolist()}],
+            "data": [entry("camera1", "xiCamBoard", [("xiCamBoard", True)]),
+                     entry("camera2", "xiCam12", [("xiCam12", False), ("xiCamBoard", True)])]}
+    path = os.path.join(directory, name + ".json")
+    with open(path, "w") as f:
+        json.dump(root, f, indent=1)
+    return path
+
+
 def write_handeye_json(directory, d, name="handeye", err_v=0.05, err_w=0.05, lam=0.05, anchor=True, odometry_first=True):
     """A calibration file using the "odometry" data type (README.md odometry section, parse at
     unified_calibration.cpp:743-807) for a set made by make_handeye: the sequence xiOdomBase is initialised from
