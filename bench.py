@@ -146,6 +146,29 @@ def cpu_baseline(d, model, budget_s):
             "jtj_ms_per_iter": n * N / vc * 1e3 + gram_ms, "jtj_gram_only_ms": gram_ms}
 
 
+def pose_init_cpu_baseline(inp, sample=48):
+    """CPU baseline of the pose initialisation (f2): the same per-image problem -- one GenericProjectionJac block, chain {DIRECT},
+    intrinsics constant, from the same 4-corner start -- solved one image at a time by scipy's trust-region least squares on the
+    oracle's residuals and Jacobian rows (the checker, timed here as the baseline only; tests/test_gpu_refine.py holds the GPU
+    result to this solve).  The reference does the same with one Ceres problem per image, sequentially
+    (unified_calibration.cpp:1137-1155)."""
+    from scipy.optimize import least_squares
+
+    from oracle import vgo
+
+    m = vgo.MODELS[inp["model"]]
+    board, corners, intr, start = inp["board"], inp["corners"], inp["intrinsics"], inp["start"]
+    sample = min(sample, corners.shape[0])
+    t0 = time.perf_counter()
+    for b in range(sample):
+        least_squares(lambda x: vgo.eval_block(m, [0], board, corners[b], [intr, x], want_jac=False)[0], start[b],
+                      jac=lambda x: vgo.eval_block(m, [0], board, corners[b], [intr, x])[1][1], method="trf", x_scale="jac",
+                      xtol=1e-8, ftol=1e-6, gtol=1e-10, max_nfev=500)
+    dt = time.perf_counter() - t0
+    return {"kind": "port", "what": "scipy TRF on the oracle's rows, one image at a time", "cores": 1, "sample": "%d images" % sample,
+            "value": sample / dt, "unit": "images/s"}
+
+
 def respawn(n):
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, one per GPU, and pass rank 0's JSON
     line through.  (`--gpus 1` never comes here: it runs in this process, exactly as before.)"""
@@ -344,7 +367,7 @@ def main():
             try:
                 snap = dict(out)
                 snap["secondary_sections"] = "not finished within %.0f s: %s missing" % (
-                    limit, ", ".join(k for k in ("roofline", "jtj", "sharded_mei", "sharded_solve", "solve", "pcie_inclusive", "config3_stereo", "config5_rig", "eucm_100k") if k not in snap))
+                    limit, ", ".join(k for k in ("roofline", "jtj", "sharded_mei", "sharded_solve", "solve", "pcie_inclusive", "config3_stereo", "config5_rig", "eucm_100k", "calib_e2e", "pose_init") if k not in snap))
                 line = json.dumps(snap)
                 break
             except RuntimeError:   # the main thread added a key meanwhile
@@ -625,6 +648,7 @@ def main():
     # rank these are plain solves; the communicator is passed whenever one exists.
     sharded_solve = {}
     stream_100k = None
+    emit_sweep = None
 
     def beyond_l3_stream(dd, model_b, n_b):
         """The emit step on a working set far beyond the 256 MiB Infinity Cache (100 000 images: 2.15 GB of output per step):
@@ -696,6 +720,14 @@ def main():
                 psh.close()
             if key == "eucm_100k" and not a.no_secondary_configs:
                 stream_100k = beyond_l3_stream(dsh, model_s, hi - lo)
+                if rank == 0:   # the Infinity-Cache knee between the headline size and this one, on slices of the same set
+                    try:
+                        from visgeom_amd import benchlib as _bl
+
+                        emit_sweep = _bl.emit_sweep(dsh, model_s, [s_ for s_ in (2500, 5000, 10000, 12500, 15000, 20000, 25000, 50000, 100000)
+                                                                    if s_ <= hi - lo], device=local_rank)
+                    except Exception as e:
+                        emit_sweep = {"error": repr(e)}
             Ksh = dsh["init_intrinsics"].size
             sharded_solve[key] = {
                 "workload": "%s mono, %d images x %d corners in total over %d rank(s), full LM solve" % (model_s.upper(), n_total, N, world),
@@ -724,9 +756,42 @@ def main():
             except Exception as e:  # never take the headline down
                 out[key] = {"error": repr(e)}
         out["eucm_100k"] = stream_100k if stream_100k is not None else {"skipped": "no 100 k-image set in this run (--sharded-solve-images 0)"}
+        if emit_sweep is not None:
+            out["emit_sweep"] = emit_sweep
+        # ---- the product entry point end to end: `calib a.json` (test/calibration/generic_calibration.cpp:32-44)
+        # on a generated calibration file of the headline size -- JSON text in, poses from scratch (estimateInitialGrid,
+        # unified_calibration.cpp:1066-1158: 4-corner construction + one independent LM per image), global solve, report and
+        # image_error files out -- with the library's per-phase clock; and the pose-initialisation kernel (f2) on its own.
+        # Host-heavy: rank 0 only.
+        if rank == 0:
+            try:
+                e2e_images = small or n_img
+                out["calib_e2e"] = benchlib.calib_e2e("mono_%s" % a.model, e2e_images, runs=2, cli=True, device=local_rank)
+            except Exception as e:
+                out["calib_e2e"] = {"error": repr(e)}
+            try:
+                pi = benchlib.pose_init(a.model, small or n_img, reps=5, device=local_rank, keep_inputs=True)
+                inputs = pi.pop("_inputs")
+                kernel_s = out["calib_e2e"].get("refine_kernel_s") if isinstance(out.get("calib_e2e"), dict) else None
+                if kernel_s:
+                    # the launch alone, HIP events inside the library (the front-end run above refines the same images from the
+                    # same 4-corner poses); rocprofv3: vg_pose_lm_kernel in profiles/r05*_calib_kernel_stats.csv
+                    pi["kernel"] = "vg_pose_lm_kernel<%s>" % a.model
+                    pi["kernel_ms"] = kernel_s * 1e3
+                    pi["roofline"] = {"bound": "fp64", "achieved": pi["algorithmic_flops"] / kernel_s / 1e12, "peak": 78.6, "unit": "TFLOP/s",
+                                      "frac": pi["algorithmic_flops"] / kernel_s / 78.6e12,
+                                      "note": "latency bound: every half-wave runs its image's whole LM (mean %.1f, max %d iterations of a dependent "
+                                              "evaluate -> 32-lane sum -> 6x6 Cholesky chain); 0.2 %% of the calibration's wall clock" % (
+                                                  pi["iterations_mean"], pi["iterations_max"])}
+                if not a.no_cpu_baseline:
+                    pi["cpu_baseline"] = pose_init_cpu_baseline(inputs)
+                    pi["images_per_s"] = (small or n_img) / (pi["refine_call_ms"] * 1e-3)
+                out["pose_init"] = pi
+            except Exception as e:
+                out["pose_init"] = {"error": repr(e)}
     # key order of the line as before: headline fields, then the sections
     out = {k: out[k] for k in list(out)[:13] + ["roofline", "jtj", "sharded_mei", "sharded_solve", "solve", "pcie_inclusive"] +
-           [k for k in ("config3_stereo", "config5_rig", "eucm_100k") if k in out]}
+           [k for k in ("config3_stereo", "config5_rig", "eucm_100k", "emit_sweep", "calib_e2e", "pose_init") if k in out]}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(d, a.model, a.cpu_seconds)
         out["gpu_over_cpu_allcores"] = value / out["cpu_baseline"]["value"]

@@ -39,6 +39,43 @@ def timed(fn, reps):
     return e0.elapsed_time(e1) / reps * 1e-3
 
 
+def emit_sweep(d, model, sizes, device=0, reps=60):
+    """The emit step over the first n images of one generated set, n in `sizes` (where the 256 MiB Infinity
+    Cache stops holding the output -- 10 k images write 215 MB, 15 k 322 MB): per size the route (one launch with the chain walked
+    in the emit kernel, or chain prep + emit on prepared frames), kernel microseconds (back-to-back launches, HIP events) and the
+    fraction of the 8 TB/s HBM peak at the algorithmic byte count."""
+    from . import CalibrationProblem, capi
+
+    rows = []
+    K = KOF[model]
+    for n in sizes:
+        if n > d["corners"].shape[0]:
+            continue
+        p = CalibrationProblem(device)
+        cam = p.add_camera(model, d["init_intrinsics"])
+        seq = p.add_transform(False, d["init_poses"][:n])
+        ds = p.add_dataset(cam, [(seq, 0)], d["board"], d["corners"][:n])
+        p.finalize()
+        res, ji, jm = p.alloc_outputs(ds)
+
+        def step():
+            p.prepare()
+            p.evaluate_dataset(ds, res, ji, jm)
+
+        def emit():
+            p.evaluate_dataset(ds, res, ji, jm)
+
+        t_step, t_emit = timed(step, reps), timed(emit, reps)
+        nbytes = n * N_CORNERS * emit_bytes_per_obs(model, 1)
+        one = capi.load().vg_dataset_single_launch(p._h, ds) == 1
+        rows.append({"images": n, "output_MB": n * N_CORNERS * 16 * (K + 7) / 1e6, "route": "inline-chain" if one else "prep + emit",
+                     "kernel_us": t_emit * 1e6, "step_us": t_step * 1e6, "frac": nbytes / t_emit / HBM_PEAK,
+                     "frac_whole_step": nbytes / t_step / HBM_PEAK})
+        p.close()
+        del res, ji, jm
+    return rows
+
+
 def build(cfg, device=0, images=None):
     """BASELINE.json config `cfg` (2..5) -> (problem, [(dataset id, model, chain length, images)], generating intrinsics, name).
     `images` scales the image count down (rehearsals); None = the configuration's own size."""

@@ -79,14 +79,31 @@ size_t emit_lds_bytes(bool want_jac, bool frames_lds, int N, int frame_stride)
 }
 
 // Largest evaluation (bytes of residuals + Jacobian rows + observations per launch) for which the emit kernel walks a
-// single-member chain itself.  While the output fits the 256 MiB Infinity Cache the in-kernel walk beats the extra
-// launch (EUCM 12 k images, 258 MB: 40.7 vs 54.1 us; 10 k: 35.4 vs 39.9 us); once the launch streams to HBM the
-// walk slows the store stream by more than the ~6.5 us launch it saves (15 k images, 322 MB: 76.0 vs 70.2 us).
-// tools/exp/inline_chain_probe.py
+// single-member chain itself.  The in-kernel walk saves the ~6.5 us chain-prep launch and costs the store stream a little per
+// workgroup; with the non-temporal output stores of round 5 the walk wins up to ~30 k EUCM images (step, same box,
+// profiles/r05c_emit_sweep_ab.txt: 20 k images 68.0 vs 75.5 us, 25 k 90.8 vs 92.7, 35 k 128.0 vs 127.0, 50 k 176.8 vs 172.7).
+// (Rounds 3-4, plain stores: the crossover sat at the 256 MiB Infinity Cache, 288 MB.)  tools/exp/emit_sweep_probe.py
 int64_t inline_chain_max_bytes()
 {
     const long long h = vgi::debug_hook(vgi::kHookInlineChainMaxBytes);
-    return h ? (int64_t)h : (int64_t)288000000;
+    return h ? (int64_t)h : (int64_t)600000000;
+}
+
+// Smallest output of a launch (bytes of residuals + Jacobian rows) that is written with non-temporal stores: everything that
+// does not fit the 256 MiB Infinity Cache next to the observations it reads (stream_store16 in vg_kernels.hpp).
+int64_t emit_nt_min_bytes()
+{
+    const long long h = vgi::debug_hook(vgi::kHookEmitNtMinBytes);
+    return h ? (int64_t)h : (int64_t)230000000;
+}
+
+int64_t emit_output_bytes(const vg::EmitArgs &a, int K)
+{
+    int64_t per_obs = 16;
+    if (a.jac_intr) per_obs += 16 * K;
+    for (int l = 0; l < a.L; l++)
+        if (a.jac_member[l]) per_obs += 96;
+    return per_obs * (int64_t)a.n_obs;
 }
 
 bool emit_frames_in_lds(int N, int frame_stride)
@@ -157,6 +174,7 @@ void fill_emit_args(const vg_problem *p, const Dataset &d, vg::EmitArgs &a, int6
     a.chain_stride = d.L ? d.chain.stride[0] : 0;
     a.seq_index = d.seq_identity ? nullptr : d.d_seq + b0;
     a.first_block = b0;
+    a.nt_stores = emit_output_bytes(a, cam.K) >= emit_nt_min_bytes() ? 1 : 0;  // a merged launch decides for all its datasets together
 }
 
 }  // namespace
@@ -166,7 +184,7 @@ void fill_emit_args(const vg_problem *p, const Dataset &d, vg::EmitArgs &a, int6
 namespace {
 long long g_debug_hooks[vgi::kHookCount] = {0};
 const char *const kDebugHookNames[vgi::kHookCount] = {"inline_chain_max_bytes", "gram_force_mfma", "gram_ch1", "gram_no_merge", "max_obs_per_launch",
-                                                      "solver_timing", "solver_host_loop", "solver_device_loop", "solver_no_speculation", "emit_equal_tiles", "schur_private_gather", "solver_event_wait", "solver_no_fold_frames", "solver_one_wave_fold", "solver_fold_max_groups", "gram_stamps"};
+                                                      "solver_timing", "solver_host_loop", "solver_device_loop", "solver_no_speculation", "emit_equal_tiles", "schur_private_gather", "solver_event_wait", "solver_no_fold_frames", "solver_one_wave_fold", "solver_fold_max_groups", "emit_nt_min_bytes", "gram_stamps"};
 }  // namespace
 long long vgi::debug_hook(vgi::DebugHook h) { return g_debug_hooks[h]; }
 #endif
@@ -243,8 +261,8 @@ void vg_problem_destroy(vg_problem *p)
     if (!p) return;
     (void)hipSetDevice(p->device);
     for (auto &d : p->dss) free_dataset(d);
-    if (p->d_params) (void)hipFree(p->d_params);
     if (p->d_prep) (void)hipFree(p->d_prep);
+    if (p->d_params) (void)hipFree(p->d_params);
     delete p;
 }
 
@@ -497,9 +515,9 @@ int vg_problem_finalize(vg_problem *p)
         prep.push_back(pd);
         first += d.n_blocks;
     }
-    p->n_prep = (int)prep.size();
+    p->prep = prep;  // up to kPrepMax datasets travel by value in the arguments of vg_chain_prep_multi_kernel
     p->prep_blocks = first;
-    if (!prep.empty()) {
+    if (prep.size() > (size_t)vg::kPrepMax) {  // more: one launch over a descriptor table in global memory
         VG_HIP(hipMalloc(&p->d_prep, sizeof(vg::PrepDataset) * prep.size()));
         VG_HIP(hipMemcpy(p->d_prep, prep.data(), sizeof(vg::PrepDataset) * prep.size(), hipMemcpyHostToDevice));
     }
@@ -574,10 +592,26 @@ int vgi::prepare_at(vg_problem *p, const double *d_params)
     // whatever point this is, the frames no longer belong to an earlier vg_problem_prepare
     p->frames_stale = d_params != p->d_params;
     if (!p->prep_blocks) return VG_OK;
-    const unsigned int grid = (unsigned int)((p->prep_blocks + 63) / 64);
-    hipLaunchKernelGGL(vg::vg_chain_prep_multi_kernel, dim3(grid), dim3(64), 0, p->stream, d_params,
-                       (const vg::PrepDataset *)p->d_prep, p->n_prep, (long long)p->prep_blocks);
-    VG_HIP(hipGetLastError());
+    if (p->d_prep) {
+        const unsigned int grid = (unsigned int)((p->prep_blocks + 63) / 64);
+        hipLaunchKernelGGL(vg::vg_chain_prep_table_kernel, dim3(grid), dim3(64), 0, p->stream, d_params, (const vg::PrepDataset *)p->d_prep,
+                           (int)p->prep.size(), (long long)p->prep_blocks);
+        VG_HIP(hipGetLastError());
+        return VG_OK;
+    }
+    for (size_t g0 = 0; g0 < p->prep.size(); g0 += vg::kPrepMax) {
+        vg::PrepMultiArgs m;
+        m.n = (int)(p->prep.size() - g0 < (size_t)vg::kPrepMax ? p->prep.size() - g0 : (size_t)vg::kPrepMax);
+        unsigned int waves = 0;
+        for (int k = 0; k < m.n; k++) {
+            m.ds[k] = p->prep[g0 + (size_t)k];
+            m.first_wave[k] = waves;
+            waves += (unsigned int)((m.ds[k].count + 63) / 64);
+        }
+        for (int k = m.n; k <= vg::kPrepMax; k++) m.first_wave[k] = waves;
+        hipLaunchKernelGGL(vg::vg_chain_prep_multi_kernel, dim3(waves), dim3(64), 0, p->stream, d_params, m);
+        VG_HIP(hipGetLastError());
+    }
     return VG_OK;
 }
 
@@ -723,6 +757,11 @@ int vg_problem_evaluate(vg_problem *p, const vg_dataset_outputs *outs)
             lds = need > lds ? need : lds;
         }
         for (int k = m.n; k <= vg::kEmitMultiMax; k++) m.first_tile[k] = tiles;
+        {   // one store policy for the whole launch: its datasets share the Infinity Cache
+            int64_t launch_bytes = 0;
+            for (int k = 0; k < m.n; k++) launch_bytes += emit_output_bytes(m.ds[k], p->cams[p->dss[shared[g0 + k]].camera].K);
+            for (int k = 0; k < m.n; k++) m.ds[k].nt_stores = launch_bytes >= emit_nt_min_bytes() ? 1 : 0;
+        }
         // pieces of equal bytes per XCD: a tile of dataset k weighs its bytes per observation -- once the pass is large
         // enough to be bound by the write stream (past the 256 MiB Infinity Cache); a small pass (a stereo pair: 104 MB in
         // 21 us) is bound by the latency of a tile, the same for every dataset, and keeps equal counts (measured: 20.9 us

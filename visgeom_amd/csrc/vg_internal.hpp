@@ -36,6 +36,7 @@ enum DebugHook {
     kHookSolverNoFoldFrames,       // LM loops: launch the chain prep in front of every candidate evaluation instead of building the candidate's frames in the back-substitution kernel (A/B, bit-equality test)
     kHookSolverOneWaveFold,        // vg_backsub_solve_kernel: the reduced system by the first wave alone, a row per lane (the route before the entry-parallel L D L^T; A/B)
     kHookSolverFoldMaxGroups,      // largest number of back-substitution workgroups whose launch also solves the reduced system (each workgroup redundantly); beyond: a one-workgroup solve launch in front (0 = the default, kFoldMaxGroups)
+    kHookEmitNtMinBytes,           // smallest launch output (bytes) written with non-temporal stores (0 = the default; 1 = always; a huge value = never)
     kHookGramStamps,               // measurement build (-DVG_GRAM_STAMPS) only: device address of the per-wave clock stamps of the Gram kernel
     kHookCount
 };
@@ -120,8 +121,8 @@ struct vg_problem {
     std::vector<std::pair<int, int64_t>> const_poses;     // (sequence transform, index) held constant ("anchor")
     int64_t n_params = 0;
     double *d_params = nullptr;
-    vg::PrepDataset *d_prep = nullptr;  // one descriptor per non-empty dataset (vg_chain_prep_multi_kernel)
-    int n_prep = 0;
+    std::vector<vg::PrepDataset> prep;  // one descriptor per non-empty dataset (vg_chain_prep_multi_kernel takes them by value)
+    vg::PrepDataset *d_prep = nullptr;  // the same as a table in global memory, only for problems of more than kPrepMax datasets
     int64_t prep_blocks = 0;
     // vg_problem_prepare marks the frames stale; they are rebuilt on demand (chain-prep kernel) by whoever reads
     // them from HBM -- or never, when every consumer derives them in-kernel (single-member DIRECT chains)

@@ -50,13 +50,27 @@ struct PrepDataset {
     ChainDesc chain;
     const int *seq_index;
     double *frames;
-    long long first;   // global index of the dataset's first block
+    long long first;   // global index of the dataset's first block (host bookkeeping)
     long long count;
     int frame_stride_d;
 };
 
+// Up to kPrepMax datasets travel BY VALUE in the kernel arguments and every wave belongs to ONE dataset (each dataset's lanes
+// are padded to whole waves): the wave finds its dataset with scalar compares and reads the descriptor -- chain length,
+// directions, bases, strides, frame pointer -- with scalar loads from the kernel-argument segment.  Round 4's kernel read a
+// descriptor TABLE in global memory per lane: `first` of the next dataset -> the descriptor's pointers -> seq_index[b] ->
+// base / stride -> the parameters were five dependent memory round trips in front of a two-microsecond walk (8.4-11.9 us per
+// launch, SQ "wait any" 0.56); now the parameters are the first vector load.
+constexpr int kPrepMax = 8;
+struct PrepMultiArgs {
+    PrepDataset ds[kPrepMax];
+    unsigned int first_wave[kPrepMax + 1];  // first wave (= 64-thread workgroup) of each dataset in this launch
+    int n;
+};
+
 #ifdef VG_TU_CORE  // this kernel is launched by one translation unit only; the others see the header without it
-__global__ __launch_bounds__(64) void vg_chain_prep_multi_kernel(const double *__restrict__ params,
+// problems of more than kPrepMax datasets: the descriptors in a table in global memory, one lane per block across all datasets
+__global__ __launch_bounds__(64) void vg_chain_prep_table_kernel(const double *__restrict__ params,
                                                                   const PrepDataset *__restrict__ dsets, int n_dsets,
                                                                   long long total_blocks)
 {
@@ -64,8 +78,6 @@ __global__ __launch_bounds__(64) void vg_chain_prep_multi_kernel(const double *_
     if (t >= total_blocks) return;
     int d = 0;
     while (d + 1 < n_dsets && t >= dsets[d + 1].first) d++;
-    // the descriptor is read in place: a private copy of its arrays would be indexed dynamically by the chain loop and land
-    // in scratch memory (152 bytes per lane; removing it changed no measured time, the kernel is latency bound)
     const PrepDataset *D = dsets + d;
     const long long b = t - D->first;
     const int *seq = D->seq_index;
@@ -73,6 +85,19 @@ __global__ __launch_bounds__(64) void vg_chain_prep_multi_kernel(const double *_
     const long long *base = D->chain.base, *stride = D->chain.stride;
     build_frame(D->chain.L, D->chain.status, [&](int l) { return params + base[l] + stride[l] * si; },
                 D->frames + b * D->frame_stride_d);
+}
+
+__global__ __launch_bounds__(64) void vg_chain_prep_multi_kernel(const double *__restrict__ params, PrepMultiArgs m)
+{
+    int d = 0;
+    while (d + 1 < m.n && blockIdx.x >= m.first_wave[d + 1]) d++;
+    const PrepDataset &D = m.ds[d];
+    const long long b = (long long)(blockIdx.x - m.first_wave[d]) * 64 + threadIdx.x;
+    if (b >= D.count) return;
+    const int *seq = D.seq_index;
+    const long long si = seq ? (long long)seq[b] : b;
+    build_frame(D.chain.L, D.chain.status, [&](int l) { return params + D.chain.base[l] + D.chain.stride[l] * si; },
+                D.frames + b * D.frame_stride_d);
 }
 #endif
 
@@ -99,15 +124,32 @@ struct EmitArgs {
     unsigned int N;
     int L;
     int frame_stride_d;
+    int nt_stores;         // 1: the launch's output streams past the Infinity Cache -> non-temporal stores (stream_store16)
 };
 
 // Each lane holds the 2S doubles of its observation's two rows; the wave's 64 observations are one
 // contiguous 1024*S-byte run of the output.  Lanes write their rows to the wave's private LDS tile
 // (16 B stores at a 16*S-byte lane stride) and the tile is then streamed out linearly, 16 B per lane
 // per store -> every global store instruction writes 1 KiB of consecutive bytes.
+// The 16-byte store of the output stream, plain or with the non-temporal hint (`global_store_dwordx4 ... nt`), chosen per LAUNCH by
+// the host (EmitArgs::nt_stores, a wave-uniform branch).  A launch whose output fits the 256 MiB Infinity Cache keeps plain
+// stores: the consumer (second-pass Gram, a copy engine, the next evaluation overwriting the same rows) finds the lines there.
+// A launch that streams past the cache sets the hint: a line kept behind the write only displaces the next lines of the same
+// stream (same box, alternating builds, profiles/r05c_emit_sweep_ab.txt: EUCM 12.5 k images = 250 MB 57 -> 45 us, 25 k 105 -> 83,
+// 50 k = 1 GB 201 -> 159 us, 0.67 -> 0.84 of the HBM peak; inside the cache the hint costs: 10 k images 36 -> 41 us).
+__device__ __forceinline__ void stream_store16(HIP_vector_type<double, 2> *dst, const HIP_vector_type<double, 2> &v, bool nt)
+{
+    if (nt) {
+        __builtin_nontemporal_store(v.x, &dst->x);
+        __builtin_nontemporal_store(v.y, &dst->y);
+    } else {
+        *dst = v;
+    }
+}
+
 template <int S>
 __device__ __forceinline__ void wave_store_rows(double *__restrict__ stage, const double *vals,
-                                                double *__restrict__ out_tile, int n_valid_obs, int lane)
+                                                double *__restrict__ out_tile, int n_valid_obs, int lane, bool nt = false)
 {
     using d2 = HIP_vector_type<double, 2>;
     d2 *st = reinterpret_cast<d2 *>(stage);
@@ -127,7 +169,7 @@ __device__ __forceinline__ void wave_store_rows(double *__restrict__ stage, cons
 #pragma unroll
     for (int k = 0; k < S; k++) {
         const int idx = k * kWave + lane;
-        if (idx < n16) dst[idx] = st[idx];
+        if (idx < n16) stream_store16(dst + idx, st[idx], nt);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -149,7 +191,7 @@ constexpr int emit_stage_doubles_per_wave()
 // 32 * 16 * S contiguous bytes out, h = 0, 1.
 template <int S>
 __device__ __forceinline__ void wave_store_rows_halves(double *__restrict__ stage, const double *vals,
-                                                       double *__restrict__ out_tile, int n_valid_obs, int lane)
+                                                       double *__restrict__ out_tile, int n_valid_obs, int lane, bool nt = false)
 {
     static_assert(S <= 2 * kStageRowDoubles, "half a wave of rows must fit the tile");
     using d2 = HIP_vector_type<double, 2>;
@@ -176,7 +218,7 @@ __device__ __forceinline__ void wave_store_rows_halves(double *__restrict__ stag
 #pragma unroll
         for (int k = 0; k < (kHalf * S + kWave - 1) / kWave; k++) {
             const int idx = k * kWave + lane;
-            if (idx < n16) dst[idx] = st[idx];
+            if (idx < n16) stream_store16(dst + idx, st[idx], nt);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -259,7 +301,7 @@ __device__ __forceinline__ void emit_tile(const EmitArgs &a, const unsigned int 
     d2 r;
     r.x = e.ok ? e.u - ob.x : kDoubleBig;
     r.y = e.ok ? e.v - ob.y : kDoubleBig;
-    if (active) reinterpret_cast<d2 *>(a.res)[o] = r;
+    if (active) stream_store16(reinterpret_cast<d2 *>(a.res) + o, r, a.nt_stores != 0);
 
     if (a.failed) {
         // Failures are rare: the counter is never zeroed (an 8-byte hipMemsetAsync is a whole 5 us fill
@@ -291,8 +333,8 @@ __device__ __forceinline__ void emit_tile(const EmitArgs &a, const unsigned int 
                 rows[i] = e.Ju[i];
                 rows[K + i] = e.Jv[i];
             }
-            if (K > kStageRowDoubles) wave_store_rows_halves<K>(stage, rows, a.jac_intr + (size_t)ow * (2 * K), n_valid, lane);
-            else wave_store_rows<(K > kStageRowDoubles ? 1 : K)>(stage, rows, a.jac_intr + (size_t)ow * (2 * K), n_valid, lane);
+            if (K > kStageRowDoubles) wave_store_rows_halves<K>(stage, rows, a.jac_intr + (size_t)ow * (2 * K), n_valid, lane, a.nt_stores != 0);
+            else wave_store_rows<(K > kStageRowDoubles ? 1 : K)>(stage, rows, a.jac_intr + (size_t)ow * (2 * K), n_valid, lane, a.nt_stores != 0);
         }
         // pose blocks, u-row at +12i, v-row at +12i+6       calib_cost_functions.cpp:93-101
         for (int l = 0; l < a.L; l++) {
@@ -300,7 +342,7 @@ __device__ __forceinline__ void emit_tile(const EmitArgs &a, const unsigned int 
             if (!Jm) continue;
             double rows[12];
             pose_rows(e.P, X0, X1, X2, fr + 12 + 21 * l, rows);
-            wave_store_rows<6>(stage, rows, Jm + (size_t)ow * 12, n_valid, lane);
+            wave_store_rows<6>(stage, rows, Jm + (size_t)ow * 12, n_valid, lane, a.nt_stores != 0);
         }
     }
 }
