@@ -273,6 +273,37 @@ def main():
         elif dist is not None:
             all_reduce_(t)
 
+    def allreduce_latency_us(sizes, calls=1000):
+        """Isolated latency of the path's collective: an in-place sum of `size` doubles on a device buffer through the route the
+        solver uses (vg_comm_allreduce_sum = ncclAllReduce when the native communicator exists, torch.distributed otherwise),
+        every call bracketed by a stream synchronisation; median / p10 / p90 over `calls` calls per size, in microseconds.
+        One rank without a communicator has no collective: None."""
+        if comm is None and dist is None:
+            return None
+        res_ = {}
+        for size in sizes:
+            buf = torch.zeros(int(size), dtype=torch.float64, device="cuda")
+            for _ in range(20):
+                sum_over_ranks_(buf)
+            torch.cuda.synchronize()
+            ts = np.empty(calls)
+            for i in range(calls):
+                t0 = time.perf_counter()
+                sum_over_ranks_(buf)
+                torch.cuda.synchronize()
+                ts[i] = time.perf_counter() - t0
+            tt = torch.tensor([float(np.median(ts)), float(np.percentile(ts, 10)), float(np.percentile(ts, 90))], dtype=torch.float64, device="cuda")
+            if dist is not None:
+                all_reduce_(tt, op=dist.ReduceOp.MAX)
+            m = tt.cpu().numpy() * 1e6
+            res_[str(int(size))] = {"doubles": int(size), "bytes": int(size) * 8, "median_us": float(m[0]), "p10_us": float(m[1]), "p90_us": float(m[2])}
+        return res_
+
+    def solver_message_sizes(widths, G):
+        """doubles in the two in-place all-reduces of one LM iteration (vg_solver_impl.hpp): the summed Gram blocks of all datasets
+        (n_ds x Wmax^2) + 5 step scalars per evaluation; the Schur complement (G + 1)^2 + the count of bad pose blocks per linear solve"""
+        return len(widths) * max(widths) ** 2 + 5, (G + 1) ** 2 + 1
+
     cfg_index = 1  # the metric's configuration: EUCM mono, 10 k images x 96 corners
     d = synthetic.make_mono(a.model, a.images, cfg_index, first_image=rank * a.images)
     n_img, N = d["corners"].shape[0], d["board"].shape[0]
@@ -434,22 +465,56 @@ def main():
     # pinned buffers.  Reported for DESIGN.md; it is never `value`.
     pcie = None
     try:
+        from visgeom_amd import capi as _capi
+        import ctypes as _ct
+
+        host_bytes = (16 + 16 * (K + 6)) * n_obs
+        reps = 24
+
+        def to_host_times(h_res, h_ji, h_jm):
+            p.prepare()
+            p.evaluate_dataset_to_host(ds, h_res, h_ji, h_jm)     # first call: staging blocks allocated and touched
+            ts = []
+            for _ in range(reps):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                p.prepare()
+                p.evaluate_dataset_to_host(ds, h_res, h_ji, h_jm)
+                ts.append(time.perf_counter() - t0)
+            return np.array(ts)
+
+        def stats(ts):
+            return {"min_ms": float(ts.min() * 1e3), "median_ms": float(np.median(ts) * 1e3), "max_ms": float(ts.max() * 1e3),
+                    "median_host_GBps": host_bytes / float(np.median(ts)) / 1e9, "evals_per_s_median": n_obs / float(np.median(ts))}
+
+        # (a) the bus on this box: plain blocking hipMemcpy of the same byte count into hipHostMalloc memory
+        sec = np.zeros(reps)
+        _capi.check(_capi.load().vg_calib_d2h_copies(local_rank, host_bytes, reps, sec.ctypes.data_as(_ct.POINTER(_ct.c_double))))
+        ceiling = {"bytes": host_bytes, "min_ms": float(sec.min() * 1e3), "median_ms": float(np.median(sec) * 1e3), "max_ms": float(sec.max() * 1e3),
+                   "median_GBps": host_bytes / float(np.median(sec)) / 1e9}
+        # (b) pinned destinations (torch.pin_memory = hipHostMalloc): chunks straight from the copy engine
         h_res = torch.empty(res.shape, dtype=torch.float64).pin_memory()
         h_ji = torch.empty(ji.shape, dtype=torch.float64).pin_memory()
         h_jm = [torch.empty(t.shape, dtype=torch.float64).pin_memory() for t in jm]
-        reps = max(3, a.steps // 20)
-        p.prepare()
-        p.evaluate_dataset_to_host(ds, h_res, h_ji, h_jm)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            p.prepare()
-            p.evaluate_dataset_to_host(ds, h_res, h_ji, h_jm)
-        el = time.perf_counter() - t0
-        assert torch.equal(h_res, res.cpu())
-        pcie = {"evals_per_s": n_obs * reps / el, "ms_per_step": el / reps * 1e3,
-                "host_GBps": (16 + 16 * (K + 6)) * n_obs * reps / el / 1e9}
+        t_pinned = to_host_times(h_res, h_ji, h_jm)
+        assert torch.equal(h_res, res.cpu()) and torch.equal(h_jm[0], jm[0].cpu())
         del h_res, h_ji, h_jm
+        # (c) ordinary (pageable) destinations, what Ceres allocates: library-owned pinned staging + the host's threads
+        n_res, n_ji = np.empty(tuple(res.shape)), np.empty(tuple(ji.shape))
+        n_jm = [np.empty(tuple(t.shape)) for t in jm]
+        n_res[:] = 0
+        n_ji[:] = 0
+        for t in n_jm:
+            t[:] = 0
+        t_pageable = to_host_times(n_res, n_ji, n_jm)
+        assert np.array_equal(n_res, res.cpu().numpy()) and np.array_equal(n_ji, ji.cpu().numpy()) and np.array_equal(n_jm[0], jm[0].cpu().numpy())
+        del n_res, n_ji, n_jm
+        pcie = {"host_bytes_per_step": host_bytes, "repetitions": reps, "d2h_ceiling_same_box": ceiling,
+                "pinned_destination": stats(t_pinned), "pageable_destination": stats(t_pageable),
+                "pinned_over_ceiling": float(np.median(t_pinned) / np.median(sec)), "pageable_over_ceiling": float(np.median(t_pageable) / np.median(sec)),
+                # kept from earlier rounds' lines: the pinned route's median
+                "ms_per_step": float(np.median(t_pinned) * 1e3), "evals_per_s": n_obs / float(np.median(t_pinned)),
+                "host_GBps": host_bytes / float(np.median(t_pinned)) / 1e9}
     except Exception as e:
         pcie = {"error": repr(e)}
     out["pcie_inclusive"] = pcie
@@ -528,6 +593,7 @@ def main():
 
     W = p.gram_width(ds)
     jtj = {"unit": "ms/iter", "gram_width": W, "images_per_gpu": n_img, "allreduce": dist is not None,
+           "rccl_world_size": comm.n_ranks if comm is not None else None,
            "collective": None if dist is None else ("vg_comm_allreduce_sum (RCCL, in place on the device block)" if comm is not None
                                                     else "torch.distributed " + backend),
            # secondary legs: best of three timed runs (a single run picked up a host hiccup once: 0.12 vs 0.05 ms);
@@ -587,7 +653,13 @@ def main():
             pm.gram_fused_sum(dsm, gm, pack)
             sum_over_ranks_(pack)
 
+        def it_sharded_compute_only():
+            pm.prepare()
+            pm.gram_fused_sum(dsm, gm, pack)
+
         ms = min(wall_ms(it_sharded, a.steps) for _ in range(3))
+        ms_compute = min(wall_ms(it_sharded_compute_only, a.steps) for _ in range(3))
+        lat = allreduce_latency_us([Wm * Wm])
         sharded = {"workload": "Mei mono, %d images x %d corners in total, images sharded over %d rank(s)" % (n_total, N, world),
                    "scaling": "strong", "images_total": n_total, "images_this_rank": hi - lo, "n_ranks": world,
                    "rccl_world_size": comm.n_ranks if comm is not None else None,
@@ -595,6 +667,10 @@ def main():
                                  ("one vg_comm_allreduce_sum per iteration, %d doubles, in place on the device buffer" % pack.numel()
                                   if comm is not None else "torch.distributed " + backend),
                    "ms_per_iter": ms, "evals_per_s": n_total * N / (ms * 1e-3), "gram_width": Wm,
+                   # where an iteration goes: the same loop without the collective (max over ranks), the rest, and the isolated latency of
+                   # an all-reduce of exactly this message
+                   "per_iteration": {"compute_ms": ms_compute, "collective_ms": max(ms - ms_compute, 0.0), "message_doubles": Wm * Wm},
+                   "allreduce_us": lat,
                    "fused_gram_flops_per_obs": 2 * Wm * (Wm + 1) + EVAL_FLOPS["mei"],
                    "fused_gram_TFLOPs_incl_sum_and_collective": (2 * Wm * (Wm + 1) + EVAL_FLOPS["mei"]) * n_total * N / (ms * 1e-3) / 1e12,
                    "cost": float(pack[Wm * Wm - 1].item()) * 0.5,
@@ -628,7 +704,11 @@ def main():
             fence()
             runs.append(summ["total_seconds"] * 1e3)
         xs = ps.get_parameters()
-        solve = {"iterations": summ["num_iterations"], "successful_steps": summ["num_successful_steps"],
+        n_eval_w, n_schur_w = solver_message_sizes([K + 7], K)
+        lat_w = allreduce_latency_us([n_eval_w, n_schur_w], calls=500)
+        solve = {"rccl_world_size": comm.n_ranks if comm is not None else None, "allreduce_us": lat_w,
+                 "messages_doubles": {"evaluation": n_eval_w, "schur": n_schur_w},
+                 "iterations": summ["num_iterations"], "successful_steps": summ["num_successful_steps"],
                  "termination": summ["termination"], "initial_cost": summ["initial_cost"], "final_cost": summ["final_cost"],
                  "total_ms": summ["total_seconds"] * 1e3, "first_solve_of_the_process_ms": runs[0], "runs_ms": runs,
                  "ms_per_iteration": summ["total_seconds"] * 1e3 / max(1, summ["num_iterations"]),
@@ -692,7 +772,8 @@ def main():
     try:
         from visgeom_amd import distributed as vdist
 
-        for key, model_s, n_total, cfg_s in (("mei_10k", "mei", a.sharded_images, 4), ("eucm_100k", "eucm", a.sharded_solve_images, 1)):
+        for key, model_s, n_total, cfg_s in (("mei_10k", "mei", a.sharded_images, 4), ("eucm_100k", "eucm", a.sharded_solve_images, 1),
+                                             ("mei_100k", "mei", a.sharded_solve_images, 4)):
             if n_total <= 0:
                 continue
             lo, hi = vdist.shard_range(n_total, rank, world)
@@ -724,12 +805,21 @@ def main():
                     try:
                         from visgeom_amd import benchlib as _bl
 
-                        emit_sweep = _bl.emit_sweep(dsh, model_s, [s_ for s_ in (2500, 5000, 10000, 12500, 15000, 20000, 25000, 50000, 100000)
-                                                                    if s_ <= hi - lo], device=local_rank)
+                        emit_sweep = _bl.emit_sweep(dsh, model_s, sorted(set([s_ for s_ in (2500, 5000, 10000, 12500, 15000, 20000, 25000, 50000, 100000)
+                                                                                if s_ <= hi - lo] + [hi - lo])), device=local_rank)
                     except Exception as e:
                         emit_sweep = {"error": repr(e)}
             Ksh = dsh["init_intrinsics"].size
+            n_eval, n_schur = solver_message_sizes([Ksh + 7], Ksh)
+            lat_s = allreduce_latency_us([n_eval, n_schur], calls=500)
+            ms_it = runs[-1] / max(1, summ["num_iterations"])
+            coll_ms = None if lat_s is None else (lat_s[str(n_eval)]["median_us"] + lat_s[str(n_schur)]["median_us"]) * 1e-3
             sharded_solve[key] = {
+                "rccl_world_size": comm.n_ranks if comm is not None else None,
+                # two collectives per iteration on the critical path: their isolated latencies at the exact message sizes, and what is
+                # left of the measured iteration once they are taken out (an estimate: the solver queues them between its kernels)
+                "allreduce_us": lat_s, "messages_doubles": {"evaluation": n_eval, "schur": n_schur},
+                "per_iteration": {"total_ms": ms_it, "collective_ms": coll_ms, "compute_ms": None if coll_ms is None else max(ms_it - coll_ms, 0.0)},
                 "workload": "%s mono, %d images x %d corners in total over %d rank(s), full LM solve" % (model_s.upper(), n_total, N, world),
                 "scaling": "strong", "images_total": n_total, "images_this_rank": hi - lo, "n_ranks": world,
                 "collectives_per_iteration": 0 if world == 1 else 2,
@@ -789,6 +879,10 @@ def main():
                 out["pose_init"] = pi
             except Exception as e:
                 out["pose_init"] = {"error": repr(e)}
+    for key in ("config3_stereo", "config5_rig", "eucm_100k", "calib_e2e", "pose_init"):   # replicas per rank: no collective inside them
+        if isinstance(out.get(key), dict):
+            out[key]["rccl_world_size"] = comm.n_ranks if comm is not None else None
+            out[key]["collective"] = "none (every rank measures its own replica; rank 0 reports)"
     # key order of the line as before: headline fields, then the sections
     out = {k: out[k] for k in list(out)[:13] + ["roofline", "jtj", "sharded_mei", "sharded_solve", "solve", "pcie_inclusive"] +
            [k for k in ("config3_stereo", "config5_rig", "eucm_100k", "emit_sweep", "calib_e2e", "pose_init") if k in out]}

@@ -539,6 +539,9 @@ int vg_debug_set(const char *name, long long value);
  * and to measure the achievable HBM rate on the box. */
 int vg_calib_stream_write(void *hip_stream, double *dst, int64_t n_doubles, double value);
 int vg_calib_stream_copy(void *hip_stream, double *dst, const double *src, int64_t n_doubles);
+/* the bus ceiling of the host-memory route on this box: `reps` blocking hipMemcpy device -> hipHostMalloc memory of `bytes`
+ * bytes each (buffers allocated and touched first); seconds_out[reps] receives the duration of every copy. */
+int vg_calib_d2h_copies(int device, int64_t bytes, int reps, double *seconds_out);
 
 #ifdef __cplusplus
 }

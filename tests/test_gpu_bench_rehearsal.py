@@ -22,7 +22,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SMALL = ["--images", "500", "--steps", "3", "--warmup", "1", "--cpu-seconds", "0.2", "--sharded-images", "600",
          "--sharded-solve-images", "1500"]
-SECTIONS = ("roofline", "jtj", "sharded_mei", "sharded_solve", "solve", "pcie_inclusive", "config3_stereo", "config5_rig", "eucm_100k")
+SECTIONS = ("roofline", "jtj", "sharded_mei", "sharded_solve", "solve", "pcie_inclusive", "config3_stereo", "config5_rig", "eucm_100k",
+            "emit_sweep", "calib_e2e", "pose_init")
 
 
 def run(cmd, env_extra):
@@ -40,6 +41,13 @@ def check_sections(line):
     for k in SECTIONS:
         assert k in line, "section %s missing" % k
         assert "error" not in line[k], (k, line[k])
+    # round 5: the product entry point end to end, the pose-initialisation kernel, the host-memory route with its bus ceiling
+    assert set(line["calib_e2e"]["phases"]) >= {"parse_json_s", "refine_total_s", "solve_s", "residual_format_s"} and line["calib_e2e"]["cli_wall_s"] > 0
+    assert line["pose_init"]["kernel_ms"] > 0 and line["pose_init"]["converged"] > 0 and line["pose_init"]["roofline"]["frac"] > 0
+    pc = line["pcie_inclusive"]
+    assert pc["repetitions"] >= 20 and pc["d2h_ceiling_same_box"]["median_GBps"] > 0
+    assert pc["pinned_destination"]["median_ms"] > 0 and pc["pageable_destination"]["median_ms"] > 0
+    assert len(line["emit_sweep"]) >= 1 and all(r["frac"] > 0 for r in line["emit_sweep"])
     assert "secondary_sections" not in line, line.get("secondary_sections")
     for k in ("config3_stereo", "config5_rig"):
         for part in ("emit", "jtj"):
@@ -67,9 +75,18 @@ def test_ranks_over_gloo_on_one_gpu_run_every_section_and_reach_the_one_rank_opt
     check_sections(line)
     assert line["jtj"]["allreduce"] is True and "gloo" in line["jtj"]["collective"]
     assert line["sharded_mei"]["n_ranks"] == n_ranks and line["sharded_mei"]["images_this_rank"] == 600 // n_ranks
-    for key in ("mei_10k", "eucm_100k"):
+    # the multi-rank sections explain themselves: isolated all-reduce latency at the exact message sizes and
+    # the compute / collective split of an iteration
+    sm = line["sharded_mei"]
+    assert sm["per_iteration"]["compute_ms"] > 0 and sm["per_iteration"]["message_doubles"] == 17 * 17
+    assert sm["allreduce_us"]["289"]["median_us"] > 0
+    assert line["solve"]["allreduce_us"] and set(line["solve"]["messages_doubles"]) == {"evaluation", "schur"}
+    for key in ("mei_10k", "eucm_100k", "mei_100k"):
         two, one = line["sharded_solve"][key], one_rank["sharded_solve"][key]
         assert two["n_ranks"] == n_ranks and two["collectives_per_iteration"] == 2
+        msg = two["messages_doubles"]
+        assert two["allreduce_us"][str(msg["evaluation"])]["median_us"] > 0 and two["allreduce_us"][str(msg["schur"])]["median_us"] > 0
+        assert two["per_iteration"]["collective_ms"] > 0 and two["per_iteration"]["compute_ms"] >= 0
         # the same problem split over two ranks ends at the same optimum (summation order differs: 1e-9 on the cost)
         assert abs(two["final_cost"] - one["final_cost"]) <= 1e-9 * abs(one["final_cost"]), (key, two["final_cost"], one["final_cost"])
         assert abs(two["max_rel_intrinsics_error_vs_generating"] - one["max_rel_intrinsics_error_vs_generating"]) <= 1e-6
@@ -90,6 +107,10 @@ def test_one_rank_through_rccl_takes_the_native_communicator_path(one_rank):
     assert "native RCCL communicator: world size 1" in err, err[-2000:]
     assert line["jtj"]["allreduce"] is True and "vg_comm_allreduce_sum" in line["jtj"]["collective"]
     assert line["sharded_mei"]["rccl_world_size"] == 1
-    for key in ("mei_10k", "eucm_100k"):
+    for key in ("jtj", "solve", "config3_stereo", "config5_rig", "eucm_100k", "calib_e2e", "pose_init"):
+        assert line[key]["rccl_world_size"] == 1, key
+    assert line["sharded_mei"]["allreduce_us"]["289"]["median_us"] > 0      # ncclAllReduce of the 17 x 17 block, isolated
+    for key in ("mei_10k", "eucm_100k", "mei_100k"):
+        assert line["sharded_solve"][key]["rccl_world_size"] == 1
         a, b = line["sharded_solve"][key], one_rank["sharded_solve"][key]
         assert abs(a["final_cost"] - b["final_cost"]) <= 1e-9 * abs(b["final_cost"])

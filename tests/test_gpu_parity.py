@@ -379,6 +379,54 @@ def test_evaluate_to_host_delivers_the_same_rows(vg, S):
     p.close()
 
 
+@pytest.mark.parametrize("pinned", [True, False])
+def test_evaluate_to_host_in_many_chunks(vg, S, pinned):
+    """the host route cuts the dataset into chunks of whole images (one emit launch + one trip over the bus each, the next chunk
+    evaluated while the last one travels): with the chunk size forced down to a few images -- a ragged last chunk, pinned
+    destinations (straight from the copy engine) and pageable ones (library staging + host threads) -- every row equals the
+    device evaluation, also residual-only, with NULL blocks, and again after the parameters moved (the staging is reused)"""
+    import torch
+
+    from visgeom_amd import capi
+
+    d = S.make_mono("mei", 53, 4)
+    p = vg.CalibrationProblem(0)
+    cam = p.add_camera("mei", d["init_intrinsics"])
+    glob = p.add_transform(True, [0.01, 0.02, -0.01, 0.01, -0.02, 0.03])
+    seq = p.add_transform(False, d["init_poses"])
+    ds = p.add_dataset(cam, [(glob, 1), (seq, 0)], d["board"], d["corners"])
+    p.finalize()
+    res, ji, jm = p.alloc_outputs(ds)
+
+    def host(t):
+        return torch.empty(t.shape, dtype=torch.float64).pin_memory() if pinned else np.full(tuple(t.shape), np.nan)
+
+    def same(h, t):
+        return np.array_equal(h.numpy() if hasattr(h, "numpy") else h, t.cpu().numpy())
+
+    capi.debug_set("host_chunk_bytes", 7 * 96 * 16 * (1 + 10 + 12))     # 7 images per chunk: 8 chunks, the last of 4 images
+    try:
+        for trial in range(2):
+            p.prepare()
+            p.evaluate_dataset(ds, res, ji, jm)
+            p.synchronize()
+            h_res, h_ji, h_jm = host(res), host(ji), [host(jm[0]), host(jm[1])]
+            p.evaluate_dataset_to_host(ds, h_res, h_ji, h_jm)
+            assert same(h_res, res) and same(h_ji, ji) and same(h_jm[0], jm[0]) and same(h_jm[1], jm[1])
+            h_res2, h_jm1 = host(res), host(jm[1])
+            p.evaluate_dataset_to_host(ds, h_res2, None, [None, h_jm1])           # NULL blocks: a narrower chunk layout
+            assert same(h_res2, res) and same(h_jm1, jm[1])
+            h_res3 = host(res)
+            p.evaluate_dataset_to_host(ds, h_res3, None, None)                    # cost-only
+            assert same(h_res3, res)
+            x = p.get_parameters()
+            x[10:] += 1e-3
+            p.set_parameters(x)
+    finally:
+        capi.debug_set("host_chunk_bytes", 0)
+    p.close()
+
+
 def test_chunked_launches_for_huge_datasets(vg, S, monkeypatch):
     """datasets beyond 2^30 observations are evaluated in several launches of whole images; the chunking is
     exercised here by lowering the per-launch limit (vg_debug_set("max_obs_per_launch")) instead of allocating 240 GB"""

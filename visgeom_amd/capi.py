@@ -176,6 +176,7 @@ SIGNATURES = {
     "vg_debug_set": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_longlong]),
     "vg_calib_stream_write": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_double]),
     "vg_calib_stream_copy": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64]),
+    "vg_calib_d2h_copies": (ctypes.c_int, [ctypes.c_int, ctypes.c_int64, ctypes.c_int, _dp]),
 }
 
 

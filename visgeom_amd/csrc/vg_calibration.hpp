@@ -1128,8 +1128,17 @@ int vg_calibration_write_residuals(vg_calibration *c, int dataset, const char *p
         if ((rc = vg_problem_add_camera(p, c->cameraModelMap[data.cameraName], c->intrinsicMap[data.cameraName].data(), 1, &cam)) == VG_OK &&
             (rc = vg_problem_add_transform(p, 0, 1, (int64_t)n, xi.data(), &seq)) == VG_OK &&
             (rc = vg_problem_add_dataset(p, cam, 1, &seq, st, N, board.data(), (int64_t)n, nullptr, zeros.data(), &ds)) == VG_OK &&
-            (rc = vg_problem_finalize(p)) == VG_OK)
-            rc = vg_dataset_evaluate_to_host(p, ds, proj.data(), nullptr, nullptr);  // projecting = the residual against zero observations
+            (rc = vg_problem_finalize(p)) == VG_OK) {
+            // projecting = the residual against zero observations.  One launch into a device block of this call, one copy back
+            // (vg_dataset_evaluate_to_host would set up its pinned staging for a problem that lives for one evaluation)
+            double *d_res = nullptr;
+            if (hipMalloc(&d_res, sizeof(double) * proj.size()) != hipSuccess) rc = vgi::fail(VG_ERR_ALLOC, "out of device memory");
+            if (rc == VG_OK) rc = vg_dataset_evaluate(p, ds, d_res, nullptr, nullptr);
+            if (rc == VG_OK) rc = vg_problem_synchronize(p);
+            if (rc == VG_OK && hipMemcpy(proj.data(), d_res, sizeof(double) * proj.size(), hipMemcpyDeviceToHost) != hipSuccess)
+                rc = vgi::fail(VG_ERR_HIP, "copying the projections back failed");
+            if (d_res) (void)hipFree(d_res);
+        }
         vg_problem_destroy(p);
         if (rc != VG_OK) return rc;
     }

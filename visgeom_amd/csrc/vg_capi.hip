@@ -1,6 +1,7 @@
 // vg_capi.hip -- implementation of include/visgeom_amd.h (host side + kernel launches).
 // Built with hipcc for gfx950 only.  No CPU fallback: every compute entry needs a HIP device.
 #define VG_TU_CORE  // the non-template kernels this translation unit owns (the headers guard them by owner)
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -55,13 +56,16 @@ void free_dataset(Dataset &d)
     if (d.d_partials) (void)hipFree(d.d_partials);
     if (d.d_wg_partials) (void)hipFree(d.d_wg_partials);
     d.d_partials = d.d_wg_partials = nullptr;
-    if (d.d_out_res) (void)hipFree(d.d_out_res);
-    if (d.d_out_ji) (void)hipFree(d.d_out_ji);
-    d.d_out_res = d.d_out_ji = nullptr;
-    for (int l = 0; l < vg::kMaxChain; l++) {
-        if (d.d_out_jm[l]) (void)hipFree(d.d_out_jm[l]);
-        d.d_out_jm[l] = nullptr;
-    }
+    if (d.d_host_stage) (void)hipFree(d.d_host_stage);
+    if (d.h_host_stage) (void)hipHostFree(d.h_host_stage);
+    d.d_host_stage = d.h_host_stage = nullptr;
+    d.d_host_stage_doubles = d.h_host_stage_doubles = 0;
+    for (hipEvent_t e : d.host_chunk_ready) (void)hipEventDestroy(e);
+    for (hipEvent_t e : d.host_chunk_copied) (void)hipEventDestroy(e);
+    d.host_chunk_ready.clear();
+    d.host_chunk_copied.clear();
+    if (d.host_copy_stream) (void)hipStreamDestroy(d.host_copy_stream);
+    d.host_copy_stream = nullptr;
     d.d_board = d.d_obs = d.d_frames = nullptr;
     d.d_seq = nullptr;
     d.d_failed = nullptr;
@@ -152,18 +156,18 @@ bool single_launch_dataset(const vg_problem *p, const Dataset &d)
     return !p->force_prepared_frames && dataset_can_inline_chain(p, d);
 }
 
-void fill_emit_args(const vg_problem *p, const Dataset &d, vg::EmitArgs &a, int64_t b0, int64_t nb, double *residuals,
-                    double *jac_intr, double *const *jac_member)
+// blocks [b0, b0 + nb) of a dataset; the output pointers are those of block b0 (chunk-local)
+void fill_emit_args_at(const vg_problem *p, const Dataset &d, vg::EmitArgs &a, int64_t b0, int64_t nb, double *res_b0, double *ji_b0,
+                       double *const *jm_b0)
 {
     const Camera &cam = p->cams[d.camera];
     a.frames = d.d_frames + (size_t)b0 * d.frame_stride;
     a.board = d.d_board;
     a.obs = d.d_obs + (size_t)b0 * 2 * d.N;
     a.intr = p->d_params + cam.offset;
-    a.res = residuals + (size_t)b0 * 2 * d.N;
-    a.jac_intr = jac_intr ? jac_intr + (size_t)b0 * 2 * d.N * cam.K : nullptr;
-    for (int l = 0; l < vg::kMaxChain; l++)
-        a.jac_member[l] = (l < d.L && jac_member && jac_member[l]) ? jac_member[l] + (size_t)b0 * 2 * d.N * 6 : nullptr;
+    a.res = res_b0;
+    a.jac_intr = ji_b0;
+    for (int l = 0; l < vg::kMaxChain; l++) a.jac_member[l] = (l < d.L && jm_b0) ? jm_b0[l] : nullptr;
     a.failed = d.d_failed;
     a.epoch = d.epoch;
     a.n_obs = (unsigned int)(nb * d.N);
@@ -177,6 +181,17 @@ void fill_emit_args(const vg_problem *p, const Dataset &d, vg::EmitArgs &a, int6
     a.nt_stores = emit_output_bytes(a, cam.K) >= emit_nt_min_bytes() ? 1 : 0;  // a merged launch decides for all its datasets together
 }
 
+// the same with whole-dataset arrays: block b0's rows lie b0 blocks into each of them
+void fill_emit_args(const vg_problem *p, const Dataset &d, vg::EmitArgs &a, int64_t b0, int64_t nb, double *residuals,
+                    double *jac_intr, double *const *jac_member)
+{
+    const int K = p->cams[d.camera].K;
+    double *jm[vg::kMaxChain] = {nullptr};
+    for (int l = 0; l < d.L; l++)
+        if (jac_member && jac_member[l]) jm[l] = jac_member[l] + (size_t)b0 * 2 * d.N * 6;
+    fill_emit_args_at(p, d, a, b0, nb, residuals + (size_t)b0 * 2 * d.N, jac_intr ? jac_intr + (size_t)b0 * 2 * d.N * K : nullptr, jm);
+}
+
 }  // namespace
 
 
@@ -184,7 +199,7 @@ void fill_emit_args(const vg_problem *p, const Dataset &d, vg::EmitArgs &a, int6
 namespace {
 long long g_debug_hooks[vgi::kHookCount] = {0};
 const char *const kDebugHookNames[vgi::kHookCount] = {"inline_chain_max_bytes", "gram_force_mfma", "gram_ch1", "gram_no_merge", "max_obs_per_launch",
-                                                      "solver_timing", "solver_host_loop", "solver_device_loop", "solver_no_speculation", "emit_equal_tiles", "schur_private_gather", "solver_event_wait", "solver_no_fold_frames", "solver_one_wave_fold", "solver_fold_max_groups", "emit_nt_min_bytes", "gram_stamps"};
+                                                      "solver_timing", "solver_host_loop", "solver_device_loop", "solver_no_speculation", "emit_equal_tiles", "schur_private_gather", "solver_event_wait", "solver_no_fold_frames", "solver_one_wave_fold", "solver_fold_max_groups", "emit_nt_min_bytes", "host_chunk_bytes", "gram_stamps"};
 }  // namespace
 long long vgi::debug_hook(vgi::DebugHook h) { return g_debug_hooks[h]; }
 #endif
@@ -675,33 +690,11 @@ int vg_dataset_evaluate(vg_problem *p, int dataset_id, double *residuals, double
     return VG_OK;
 }
 
-int vg_dataset_evaluate_to_host(vg_problem *p, int dataset_id, double *residuals, double *jac_intr, double *const *jac_member)
-{
-    int rc = valid_dataset(p, dataset_id);
-    if (rc != VG_OK) return rc;
-    if (!p->finalized) return fail(VG_ERR_STATE, "problem not finalized");
-    Dataset &d = p->dss[dataset_id];
-    if (!d.n_blocks) return VG_OK;
-    if (!residuals) return fail(VG_ERR_INVALID_ARGUMENT, "residuals is NULL");
-    VG_HIP(hipSetDevice(p->device));
-    const size_t rows = (size_t)d.n_blocks * 2 * d.N;
-    const int K = p->cams[d.camera].K;
-    if (!d.d_out_res) VG_HIP(hipMalloc(&d.d_out_res, sizeof(double) * rows));
-    if (jac_intr && !d.d_out_ji) VG_HIP(hipMalloc(&d.d_out_ji, sizeof(double) * rows * K));
-    double *jm[vg::kMaxChain] = {nullptr};
-    for (int l = 0; l < d.L; l++)
-        if (jac_member && jac_member[l]) {
-            if (!d.d_out_jm[l]) VG_HIP(hipMalloc(&d.d_out_jm[l], sizeof(double) * rows * 6));
-            jm[l] = d.d_out_jm[l];
-        }
-    if ((rc = vg_dataset_evaluate(p, dataset_id, d.d_out_res, jac_intr ? d.d_out_ji : nullptr, jm)) != VG_OK) return rc;
-    VG_HIP(hipMemcpyAsync(residuals, d.d_out_res, sizeof(double) * rows, hipMemcpyDeviceToHost, p->stream));
-    if (jac_intr) VG_HIP(hipMemcpyAsync(jac_intr, d.d_out_ji, sizeof(double) * rows * K, hipMemcpyDeviceToHost, p->stream));
-    for (int l = 0; l < d.L; l++)
-        if (jm[l]) VG_HIP(hipMemcpyAsync(jac_member[l], jm[l], sizeof(double) * rows * 6, hipMemcpyDeviceToHost, p->stream));
-    VG_HIP(hipStreamSynchronize(p->stream));
-    return VG_OK;
-}
+}  // extern "C"
+
+#include "vg_host_route.hpp"
+
+extern "C" {
 
 int vg_problem_evaluate(vg_problem *p, const vg_dataset_outputs *outs)
 {
@@ -1150,6 +1143,30 @@ int vg_calib_stream_write(void *hip_stream, double *dst, int64_t n_doubles, doub
                        dst, n2, value);
     VG_HIP(hipGetLastError());
     return VG_OK;
+}
+
+int vg_calib_d2h_copies(int device, int64_t bytes, int reps, double *seconds_out)
+{
+    if (bytes <= 0 || reps <= 0 || !seconds_out) return fail(VG_ERR_INVALID_ARGUMENT, "bad arguments");
+    VG_HIP(hipSetDevice(device));
+    void *dev = nullptr, *host = nullptr;
+    VG_HIP(hipMalloc(&dev, (size_t)bytes));
+    if (hipHostMalloc(&host, (size_t)bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipFree(dev);
+        return fail(VG_ERR_ALLOC, "hipHostMalloc failed");
+    }
+    int rc = VG_OK;
+    if (hipMemset(dev, 1, (size_t)bytes) != hipSuccess) rc = fail(VG_ERR_HIP, "hipMemset failed");
+    std::memset(host, 0, (size_t)bytes);
+    if (rc == VG_OK && hipMemcpy(host, dev, (size_t)bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(VG_ERR_HIP, "hipMemcpy failed");  // warm
+    for (int r = 0; r < reps && rc == VG_OK; r++) {
+        const auto t0 = std::chrono::steady_clock::now();
+        if (hipMemcpy(host, dev, (size_t)bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(VG_ERR_HIP, "hipMemcpy failed");
+        seconds_out[r] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    (void)hipHostFree(host);
+    (void)hipFree(dev);
+    return rc;
 }
 
 int vg_calib_stream_copy(void *hip_stream, double *dst, const double *src, int64_t n_doubles)

@@ -37,6 +37,7 @@ enum DebugHook {
     kHookSolverOneWaveFold,        // vg_backsub_solve_kernel: the reduced system by the first wave alone, a row per lane (the route before the entry-parallel L D L^T; A/B)
     kHookSolverFoldMaxGroups,      // largest number of back-substitution workgroups whose launch also solves the reduced system (each workgroup redundantly); beyond: a one-workgroup solve launch in front (0 = the default, kFoldMaxGroups)
     kHookEmitNtMinBytes,           // smallest launch output (bytes) written with non-temporal stores (0 = the default; 1 = always; a huge value = never)
+    kHookHostChunkBytes,           // chunk size of vg_dataset_evaluate_to_host in bytes (0 = the default, 32 MiB): tests force many small chunks
     kHookGramStamps,               // measurement build (-DVG_GRAM_STAMPS) only: device address of the per-wave clock stamps of the Gram kernel
     kHookCount
 };
@@ -89,8 +90,13 @@ struct Dataset {
     double *d_board = nullptr, *d_obs = nullptr, *d_frames = nullptr;
     int32_t *d_seq = nullptr;
     unsigned long long *d_failed = nullptr;
-    double *d_out_res = nullptr, *d_out_ji = nullptr;  // device staging of vg_dataset_evaluate_to_host
-    double *d_out_jm[vg::kMaxChain] = {nullptr};
+    // vg_dataset_evaluate_to_host (vg_host_route.hpp): the rows travel chunk by chunk -- device staging laid out chunk-major
+    // [res | jac_intr | jac_member ...] per chunk, a copy stream of its own, one event pair per chunk, and (for destinations
+    // that are not pinned) a pinned staging block of the same layout that the host's threads scatter into the caller's arrays
+    double *d_host_stage = nullptr, *h_host_stage = nullptr;
+    size_t d_host_stage_doubles = 0, h_host_stage_doubles = 0;
+    hipStream_t host_copy_stream = nullptr;
+    std::vector<hipEvent_t> host_chunk_ready, host_chunk_copied;
     double *d_partials = nullptr;  // [ceil(n_blocks / kSlab)][W*W] workspace of vg_dataset_gram_sum
     double *d_wg_partials = nullptr;  // [W(W+1)/2][n_workgroups] per-workgroup sums of the vector-pipe Gram kernel
     unsigned long long epoch = 0;  // evaluation counter, tags d_failed
