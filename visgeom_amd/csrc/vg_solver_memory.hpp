@@ -63,10 +63,9 @@ struct ArenaCache {
     int device = -1;
     void drop()
     {
-        if (dev) {
-            (void)hipSetDevice(device);
-            (void)hipFree(dev);
-        }
+        // (hipFree takes the pointer's own device: the calling thread's current device is not touched -- a torch caller relies
+        //  on its own)
+        if (dev) (void)hipFree(dev);
         if (pin) (void)hipHostFree(pin);
         dev = pin = nullptr;
         dev_cap = pin_cap = 0;
@@ -78,6 +77,7 @@ thread_local SolveArena *t_arena = nullptr;
 // takes the cached blocks when they are large enough, allocates otherwise; the destructor hands the blocks back
 struct ArenaScope {
     SolveArena a;
+    bool discard = false;  // set when the solve's stream could not be drained: the blocks are freed, never cached
     ArenaScope(int device, size_t dev_need, size_t pin_need, size_t up_cap)
     {
         {
@@ -93,7 +93,7 @@ struct ArenaScope {
         }
         if (!a.dev) {
             if (hipMalloc(reinterpret_cast<void **>(&a.dev), dev_need) != hipSuccess) a.dev = nullptr;
-            if (a.dev && hipHostMalloc(reinterpret_cast<void **>(&a.pin), pin_need, hipHostMallocDefault) != hipSuccess) {
+            if (a.dev && hipHostMalloc(reinterpret_cast<void **>(&a.pin), pin_need, hipHostMallocCoherent) != hipSuccess) {
                 (void)hipFree(a.dev);
                 a.dev = a.pin = nullptr;
             }
@@ -111,7 +111,9 @@ struct ArenaScope {
         t_arena = nullptr;
         if (!a.dev) return;
         std::lock_guard<std::mutex> lk(g_arena_cache.m);
-        if (a.dev_cap >= g_arena_cache.dev_cap) {  // keep the larger one
+        // keep the pair that serves more solves: a hit needs BOTH capacities, so a pair replaces the cached one only when it
+        // is at least as large in both (or nothing is cached)
+        if (!discard && a.dev_cap >= g_arena_cache.dev_cap && a.pin_cap >= g_arena_cache.pin_cap) {
             g_arena_cache.drop();
             g_arena_cache.dev = a.dev;
             g_arena_cache.pin = a.pin;
@@ -167,7 +169,7 @@ struct PinnedBuf {
         n = count;
         const size_t bytes = sizeof(double) * (count ? count : 1);
         if (t_arena && (p = static_cast<double *>(t_arena->pin_alloc(bytes))) != nullptr) return VG_OK;
-        VG_HIP(hipHostMalloc(reinterpret_cast<void **>(&p), bytes, hipHostMallocDefault));
+        VG_HIP(hipHostMalloc(reinterpret_cast<void **>(&p), bytes, hipHostMallocCoherent));   // the host spins on words kernels store here
         owned = true;
         return VG_OK;
     }
