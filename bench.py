@@ -862,17 +862,6 @@ def main():
             try:
                 pi = benchlib.pose_init(a.model, small or n_img, reps=5, device=local_rank, keep_inputs=True)
                 inputs = pi.pop("_inputs")
-                kernel_s = out["calib_e2e"].get("refine_kernel_s") if isinstance(out.get("calib_e2e"), dict) else None
-                if kernel_s:
-                    # the launch alone, HIP events inside the library (the front-end run above refines the same images from the
-                    # same 4-corner poses); rocprofv3: vg_pose_lm_kernel in profiles/r05*_calib_kernel_stats.csv
-                    pi["kernel"] = "vg_pose_lm_kernel<%s>" % a.model
-                    pi["kernel_ms"] = kernel_s * 1e3
-                    pi["roofline"] = {"bound": "fp64", "achieved": pi["algorithmic_flops"] / kernel_s / 1e12, "peak": 78.6, "unit": "TFLOP/s",
-                                      "frac": pi["algorithmic_flops"] / kernel_s / 78.6e12,
-                                      "note": "latency bound: every half-wave runs its image's whole LM (mean %.1f, max %d iterations of a dependent "
-                                              "evaluate -> 32-lane sum -> 6x6 Cholesky chain); 0.2 %% of the calibration's wall clock" % (
-                                                  pi["iterations_mean"], pi["iterations_max"])}
                 if not a.no_cpu_baseline:
                     pi["cpu_baseline"] = pose_init_cpu_baseline(inputs)
                     pi["images_per_s"] = (small or n_img) / (pi["refine_call_ms"] * 1e-3)

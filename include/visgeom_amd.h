@@ -401,6 +401,12 @@ int vg_refine_poses(int device, void *hip_stream, int model, const double *intri
                     int64_t n_images, const double *corners, double *poses, const vg_solve_options *options,
                     int32_t *iterations, double *final_cost, int32_t *termination);
 
+/* the same call with a clock on the launch itself: *kernel_seconds = duration of vg_pose_lm_kernel alone (HIP events on the
+ * launch stream), without the uploads and the read-back around it (bench.py section pose_init, tools/bench_calib.py) */
+int vg_refine_poses_timed(int device, void *hip_stream, int model, const double *intrinsics, int n_points, const double *board,
+                          int64_t n_images, const double *corners, double *poses, const vg_solve_options *options,
+                          int32_t *iterations, double *final_cost, int32_t *termination, double *kernel_seconds);
+
 /* Host-only helper of the solver, exported so the host logic can be tested without a GPU:
  * solves the symmetric positive definite n x n system A x = b (row-major A, untouched) by Cholesky.
  * Returns VG_ERR_NUMERIC when A is not positive definite. */

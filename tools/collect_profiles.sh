@@ -13,6 +13,9 @@ cp gpurun_out/box_$T.txt profiles/${T}_box.txt
 grep -E "passed|failed|Gram blocks" gpurun_out/pytest_gpu_$T.log | tail -3 > profiles/${T}_pytest_gpu_tail.txt
 cp gpurun_out/gram_kernel_by_context_$T.txt profiles/${T}_gram_kernel_by_context.txt
 cp gpurun_out/pmc_sq_$T.csv profiles/${T}_pmc_sq_raw.csv
+for f in calib_kernel_stats_$T.csv calib_e2e_$T.json calib_e2e_$T.md; do
+  [ -f gpurun_out/$f ] && cp gpurun_out/$f profiles/${T}_${f/_$T/}
+done
 if [ -f gpurun_out/bench_local_$T.txt ]; then
   { echo "# tools/bench_local.py, round tag \`$T\` (one MI355X, HIP-event timings)"; echo; echo '```'; grep -v amdgpu.ids gpurun_out/bench_local_$T.txt; echo '```'; } > profiles/${T}_local.md
 fi

@@ -22,6 +22,7 @@ for PASS in A B; do
   run config3 $PASS "$C" python "$R/tools/bench_configs.py" 20 --config 3
   run config5 $PASS "$C" python "$R/tools/bench_configs.py" 20 --config 5
   run local $PASS "$C" python "$R/tools/bench_local.py" 20
+  run calib $PASS "$C" python "$R/tools/bench_calib.py" --only mono_eucm_10k --no-cli --runs 1   # vg_pose_lm_kernel (f2) inside the front end
 done
 python "$R/tools/pmc_aggregate.py" "$O" "$R/gpurun_out/pmc_sq_$TAG.csv"
 echo "aggregate rc=$?"

@@ -333,14 +333,21 @@ def pose_init(model="eucm", images=10000, reps=5, device=0, keep_inputs=False):
         capi.check(L.vg_initial_grid_pose(capi.MODELS[model], intr.ctypes.data_as(dp), b4.ctypes.data_as(dp), c4.ctypes.data_as(dp),
                                           start[i].ctypes.data_as(dp)))
     t_geo_py = time.perf_counter() - t0   # through ctypes, one call per image: an upper bound of the host loop in the library
-    best, it = None, None
+    best, it, kernel_s = None, None, None
     for _ in range(max(1, reps)):
+        ks = []
         t0 = time.perf_counter()
-        poses, it, cost, term = refine_poses(model, intr, board, corners, start, device=device)
+        poses, it, cost, term = refine_poses(model, intr, board, corners, start, device=device, kernel_seconds=ks)
         dt = time.perf_counter() - t0
         best = dt if best is None or dt < best else best
+        kernel_s = ks[0] if kernel_s is None or ks[0] < kernel_s else kernel_s
     flops = float(np.sum((it.astype(np.float64) + 1) * N * (EVAL_FLOPS[model] + 2 * 7 * 8)))
     out = {"workload": "%s, %d images x %d corners, start = 4-corner pose at the initial intrinsics" % (model, images, N),
+           "kernel": "vg_pose_lm_kernel<%s>" % model, "kernel_ms": kernel_s * 1e3,
+           "roofline": {"bound": "fp64", "achieved": flops / kernel_s / 1e12, "peak": FP64_PEAK / 1e12, "unit": "TFLOP/s",
+                        "frac": flops / kernel_s / FP64_PEAK,
+                        "note": "latency bound: every half-wave runs its image's whole LM (a dependent evaluate -> 32-lane sum -> 6 x 6 "
+                                "Cholesky chain per iteration), a wave lives as long as its slower image"},
            "refine_call_ms": best * 1e3, "iterations_mean": float(it.mean()), "iterations_p99": float(np.percentile(it, 99)),
            "iterations_max": int(it.max()), "converged": int(np.sum(term <= 2)), "algorithmic_flops": flops,
            "max_pose_error_vs_generating": float(np.max(np.abs(poses - d["gt_poses"]))),

@@ -115,11 +115,12 @@ def transform_from_values(values):
     return out
 
 
-def refine_poses(model, intrinsics, board, corners, poses, device=0, **options):
+def refine_poses(model, intrinsics, board, corners, poses, device=0, kernel_seconds=None, **options):
     """estimateInitialGrid's per-image refinement (unified_calibration.cpp:1137-1155) for all images at once: n
     INDEPENDENT 6-DOF problems, one kernel launch (vg_refine_poses).  corners [n, N, 2], poses [n, 6] (start).
     options: fields of vg_solve_options; none = the reference's setting (Ceres defaults, 500 iterations,
-    SoftLOneLoss(25)).  Returns (poses [n, 6], iterations [n], final_cost [n], termination [n])."""
+    SoftLOneLoss(25)).  kernel_seconds: a list that receives the launch's own duration (HIP events).
+    Returns (poses [n, 6], iterations [n], final_cost [n], termination [n])."""
     L = capi.load()
     m = capi.MODELS[model] if isinstance(model, str) else int(model)
     intr = np.ascontiguousarray(intrinsics, dtype=np.float64)
@@ -143,7 +144,10 @@ def refine_poses(model, intrinsics, board, corners, poses, device=0, **options):
             setattr(opt, k, v)
     dp = ctypes.POINTER(ctypes.c_double)
     ip = ctypes.POINTER(ctypes.c_int32)
-    capi.check(L.vg_refine_poses(device, None, m, intr.ctypes.data_as(dp), N, board.ctypes.data_as(dp), n,
-                                 corners.ctypes.data_as(dp), out.ctypes.data_as(dp), ctypes.byref(opt) if opt is not None else None,
-                                 it.ctypes.data_as(ip), cost.ctypes.data_as(dp), term.ctypes.data_as(ip)))
+    ks = ctypes.c_double(0.0)
+    capi.check(L.vg_refine_poses_timed(device, None, m, intr.ctypes.data_as(dp), N, board.ctypes.data_as(dp), n,
+                                       corners.ctypes.data_as(dp), out.ctypes.data_as(dp), ctypes.byref(opt) if opt is not None else None,
+                                       it.ctypes.data_as(ip), cost.ctypes.data_as(dp), term.ctypes.data_as(ip), ctypes.byref(ks)))
+    if kernel_seconds is not None:   # a one-element list: receives the duration of vg_pose_lm_kernel alone
+        kernel_seconds[:] = [ks.value]
     return out, it, cost, term

@@ -142,6 +142,8 @@ SIGNATURES = {
     "vg_problem_solve": (ctypes.c_int, [_vp, ctypes.POINTER(SolveOptions), ctypes.POINTER(SolveSummary)]),
     "vg_refine_poses": (ctypes.c_int, [ctypes.c_int, _vp, ctypes.c_int, _dp, ctypes.c_int, _dp, ctypes.c_int64, _dp, _dp,
                                        ctypes.POINTER(SolveOptions), _i32p, _dp, _i32p]),
+    "vg_refine_poses_timed": (ctypes.c_int, [ctypes.c_int, _vp, ctypes.c_int, _dp, ctypes.c_int, _dp, ctypes.c_int64, _dp, _dp,
+                                             ctypes.POINTER(SolveOptions), _i32p, _dp, _i32p, _dp]),
     "vg_host_cholesky_solve": (ctypes.c_int, [ctypes.c_int, _dp, _dp, _dp]),
     "vg_calibration_create": (ctypes.c_int, [_vpp, ctypes.c_int]),
     "vg_calibration_destroy": (None, [_vp]),

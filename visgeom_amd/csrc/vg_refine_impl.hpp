@@ -116,3 +116,11 @@ extern "C" int vg_refine_poses(int device, void *hip_stream, int model, const do
     return vgi::refine_poses(device, hip_stream, model, intrinsics, n_points, board, n_images, corners, poses, options, iterations,
                              final_cost, termination, nullptr);
 }
+
+extern "C" int vg_refine_poses_timed(int device, void *hip_stream, int model, const double *intrinsics, int n_points, const double *board,
+                                     int64_t n_images, const double *corners, double *poses, const vg_solve_options *options,
+                                     int32_t *iterations, double *final_cost, int32_t *termination, double *kernel_seconds)
+{
+    return vgi::refine_poses(device, hip_stream, model, intrinsics, n_points, board, n_images, corners, poses, options, iterations,
+                             final_cost, termination, kernel_seconds);
+}
