@@ -491,6 +491,8 @@ __host__ __device__ constexpr int valu_min_waves()
 {
 #ifdef VG_GRAM_CH2
     return (CameraTraits<MODEL>::K + 6 * L + 1 <= 13 && CH <= 2) ? 3 : 2;
+#elif defined(VG_GRAM_WAVES3)   // tools/exp A/B build: three waves per SIMD by register limit (168) with THREE corners per lane -- the rows alone are 156
+    return (CameraTraits<MODEL>::K + 6 * L + 1 <= 13) ? 3 : 2;
 #else
     return 2;
 #endif
