@@ -51,6 +51,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary-configs", action="store_true",
                     help="skip the per-config sections (BASELINE configs 3 and 5, the beyond-L3 stream)")
+    ap.add_argument("--headline-kernels-only", action="store_true",
+                    help="profiling passes (tools/gpu_check.sh): skip the sections that launch the headline's emit kernel at OTHER sizes "
+                         "(emit_sweep, the chunked host route of pcie_inclusive) and the calib / pose-init sections, so that the "
+                         "kernel's average in a rocprofv3 trace of this command is the headline launch's")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU-baseline budget per leg")
     return ap.parse_args()
 
@@ -465,6 +469,8 @@ def main():
     # pinned buffers.  Reported for DESIGN.md; it is never `value`.
     pcie = None
     try:
+        if a.headline_kernels_only:
+            raise RuntimeError("skipped (--headline-kernels-only)")
         from visgeom_amd import capi as _capi
         import ctypes as _ct
 
@@ -801,7 +807,7 @@ def main():
                 psh.close()
             if key == "eucm_100k" and not a.no_secondary_configs:
                 stream_100k = beyond_l3_stream(dsh, model_s, hi - lo)
-                if rank == 0:   # the Infinity-Cache knee between the headline size and this one, on slices of the same set
+                if rank == 0 and not a.headline_kernels_only:   # the Infinity-Cache knee between the headline size and this one, on slices of the same set
                     try:
                         from visgeom_amd import benchlib as _bl
 
@@ -853,7 +859,7 @@ def main():
         # unified_calibration.cpp:1066-1158: 4-corner construction + one independent LM per image), global solve, report and
         # image_error files out -- with the library's per-phase clock; and the pose-initialisation kernel (f2) on its own.
         # Host-heavy: rank 0 only.
-        if rank == 0:
+        if rank == 0 and not a.headline_kernels_only:
             try:
                 e2e_images = small or n_img
                 out["calib_e2e"] = benchlib.calib_e2e("mono_%s" % a.model, e2e_images, runs=2, cli=True, device=local_rank)

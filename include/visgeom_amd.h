@@ -150,7 +150,8 @@ int vg_problem_add_transform(vg_problem *p, int is_global, int constant, int cou
  *   board: 3*n_points host doubles (initGrid :279-309 / initGridIR :234-250);
  *   image_index[n_images]: index into the sequence transform(s) for each block; images whose
  *     corner list was empty are simply not listed (:520);
- *   corners: [n_images][2*n_points] host doubles, [u0,v0,u1,v1,...] per image. */
+ *   corners: [n_images][2*n_points] host doubles, [u0,v0,u1,v1,...] per image; NULL = all zeros (nothing is uploaded): the
+ *     residuals of such a dataset are the projections themselves, which is how writeImageResidual (:1186-1292) projects. */
 int vg_problem_add_dataset(vg_problem *p, int camera_id, int chain_len, const int *transform_ids,
                            const int *status, int n_points, const double *board, int64_t n_images,
                            const int32_t *image_index, const double *corners, int *dataset_id);

@@ -7,6 +7,8 @@ import subprocess
 import numpy as np
 import pytest
 
+from oracle import vgo
+
 pytestmark = pytest.mark.gpu
 
 
@@ -374,3 +376,74 @@ def test_odometry_intrinsic_on_a_sequence_initialised_from_the_images(gpu, tmp_p
     with pytest.raises(Exception, match="fewer elements than the odometry intervals need"):
         cc.addResiduals(str(tmp_path / "c.json"))
     cc.close()
+
+
+def test_residual_file_is_written_like_the_reference_writes_it(gpu, tmp_path):
+    """writeImageResidual (unified_calibration.cpp:1186-1292) line by line: `err.x err.y   proj.x proj.y   tx ty tz rx ry rz`, every
+    vector in Eigen's default row format (6 significant digits, coefficients right-aligned to the widest).  The projections come
+    out of ONE launch for all images and the text is produced by several host threads (300 images: every thread gets a range);
+    each line must equal the line formatted here from the oracle's projection of that image at the solved parameters."""
+    from visgeom_amd import synthetic as S
+    from visgeom_amd.calibration import GenericCameraCalibration
+
+    n = 300
+    d = S.make_mono("ucm", n, 0, sigma=0.1)
+    path = S.write_calibration_json(str(tmp_path), d, "ucm", prior=True, skip=(0, 17, 299))
+    c = GenericCameraCalibration()
+    c.addResiduals(path)
+    c.compute(max_num_iterations=5)
+    out = tmp_path / "image_error_0.txt"
+    sigma, outliers = c.writeImageResidual(0, out, n_images=n)
+    lines = open(out).read().splitlines()
+    assert len(lines) == (n - 3) * 96
+    intr, poses = c.intrinsics("cam"), c.transform("xiCamBoard")
+
+    def row(v):
+        t = ["%g" % x for x in v]
+        w = max(len(x) for x in t)
+        return " ".join(x.rjust(w) for x in t)
+
+    k = 0
+    for i in range(n):
+        if i in (0, 17, 299):
+            assert sigma[i] == 0
+            continue
+        # chain {DIRECT} from identity: the reference composes through the quaternion round trip; the oracle's block does the same
+        res, _ = vgo.eval_block(vgo.MODEL_UCM, [0], d["board"], np.zeros((96, 2)), [intr, poses[i]], want_jac=False)
+        proj = res.reshape(96, 2)
+        err = d["corners"][i] - proj
+        assert abs(sigma[i] - np.sqrt(np.sum(err ** 2) / 94)) < 1e-9
+        for j in (0, 47, 95):      # three lines of every image, character by character
+            want = row(err[j]) + "   " + row(proj[j]) + "   " + row(poses[i][:3]) + " " + row(poses[i][3:])
+            got = lines[k + j]
+            if got != want:        # a projection that differs in its 11th digit may print differently in the 6th: compare numbers then
+                assert np.allclose(np.array(got.split(), dtype=float), np.array(want.split(), dtype=float), rtol=2e-6, atol=1e-9), (i, j, got, want)
+        k += 96
+    c.close()
+
+
+def test_front_end_phase_clock_and_stereo_file_with_a_global_transform_from_the_data(gpu, tmp_path):
+    """`vg_calibration_get_timings` after a full run of a stereo calibration file whose global xiCam12 has no prior: its value comes
+    from the data (the 4-corner pose of the first frame, then initGlobalTransform over all frames, unified_calibration.cpp:358-429);
+    every phase that ran has a clock reading, the refinement counted its images and iterations, and the solve ends at the
+    generating parameters (noise-free)."""
+    from visgeom_amd import synthetic as S
+    from visgeom_amd.calibration import GenericCameraCalibration
+
+    st = S.make_stereo(60, sigma=0.0)
+    path = S.write_stereo_json(str(tmp_path), st)
+    c = GenericCameraCalibration()
+    c.addResiduals(path)
+    c.compute(max_num_iterations=200)
+    for i in range(2):
+        c.writeImageResidual(i, tmp_path / ("image_error_%d.txt" % i))
+    t = c.timings()
+    for k in ("read_files_s", "parse_json_s", "geometric_init_s", "refine_total_s", "refine_kernel_s", "global_init_s", "assemble_s", "solve_s",
+              "readback_s", "residual_eval_s", "residual_format_s"):
+        assert t[k] > 0, k
+    assert t["refine_kernel_s"] < t["refine_total_s"]
+    assert t["refine_images"] == 60 + 1 and t["refine_iterations"] >= t["refine_images"] and t["refine_max_iterations"] >= 2
+    assert t["residual_lines"] == 2 * 60 * 96 and t["json_bytes"] > 2 * 60 * 96 * 20
+    assert rel(c.intrinsics("camera1"), st["gt_intrinsics1"]) < 1e-6 and rel(c.intrinsics("camera2"), st["gt_intrinsics2"]) < 1e-6
+    assert np.max(np.abs(c.transform("xiCam12")[0] - st["gt_xi12"])) < 1e-6
+    c.close()

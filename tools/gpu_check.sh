@@ -20,7 +20,7 @@ timeout 600 python bench.py --images 100000 --steps 50 --warmup 5 --no-cpu-basel
 echo "bench100k rc=$?"; cat gpurun_out/bench_100k_$TAG.json
 cd /tmp && export TMPDIR=/tmp
 P="$R/gpurun_out/prof_$TAG"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$P/trace" -o t -- python "$R/bench.py" --steps 100 --warmup 10 --no-cpu-baseline > "$P.trace.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$P/trace" -o t -- python "$R/bench.py" --steps 100 --warmup 10 --no-cpu-baseline --headline-kernels-only > "$P.trace.log" 2>&1
 echo "rocprof trace rc=$?"
 # the product entry point under the kernel trace: `calib` on the headline-size JSON -- vg_pose_lm_kernel, the solve's
 # kernels and the projection launch of the residual report in one table
@@ -31,7 +31,7 @@ find "$P/trace_calib" -name '*kernel_trace.csv' -delete
 timeout 900 python "$R/tools/bench_calib.py" --out "$R/gpurun_out/calib_e2e_$TAG.json" --md "$R/gpurun_out/calib_e2e_$TAG.md" --tag $TAG > "$R/gpurun_out/calib_e2e_$TAG.log" 2>&1
 echo "bench_calib rc=$?"
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$P/pmc_$C" -o t -- python "$R/bench.py" --steps 20 --warmup 2 --no-cpu-baseline > "$P.pmc_$C.log" 2>&1
+  timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$P/pmc_$C" -o t -- python "$R/bench.py" --steps 20 --warmup 2 --no-cpu-baseline --headline-kernels-only > "$P.pmc_$C.log" 2>&1
   echo "rocprof pmc $C rc=$?"
 done
 # SQ counters: tools/pmc_sq.sh (own passes, aggregated on the box -- the per-dispatch CSV of an 8-counter pass is larger

@@ -18,7 +18,7 @@ run() {  # name, pass letter, counters, command...
 }
 for PASS in A B; do
   C=$PASS_A; [ $PASS = B ] && C=$PASS_B
-  run headline $PASS "$C" python "$R/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-secondary-configs
+  run headline $PASS "$C" python "$R/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-secondary-configs --headline-kernels-only
   run config3 $PASS "$C" python "$R/tools/bench_configs.py" 20 --config 3
   run config5 $PASS "$C" python "$R/tools/bench_configs.py" 20 --config 5
   run local $PASS "$C" python "$R/tools/bench_local.py" 20

@@ -60,6 +60,7 @@ f_cal = CAL_BYTES / (cal_f["vg::vg_stream_copy_kernel"] * 1024) if "vg::vg_strea
 w_cal = CAL_BYTES / (cal_w["vg::vg_stream_write_kernel"] * 1024) if "vg::vg_stream_write_kernel" in cal_w else float("nan")
 
 all_rows, fields = [], None
+traffic_json = {}
 md = ["# rocprofv3 per config, round tag `%s`" % tag, "",
       "Source: `tools/prof_configs.sh %s` on one MI355X: per config and kind of pass one `--kernel-trace --stats` run of" % tag,
       "`tools/bench_configs.py --config N --only emit|jtj|solve`, and separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs.",
@@ -96,6 +97,9 @@ for cfg in sorted(DATASETS):
             if "vg_emit" in k:
                 b = emit_bytes(cfg)
                 work, frac = "%.4g B" % b, "%.3f of 8 TB/s (traffic / algorithmic = %.3f)" % (b / (ns * 1e-9) / HBM_PEAK, traffic / b if b else 0)
+                if traffic > 0:   # what bench.py's per-config sections report as roofline.traffic (visgeom_amd/benchlib.py)
+                    traffic_json["config%d_emit" % cfg] = {"hbm_bytes_per_launch": traffic, "kernel": k, "tag": tag, "trace_avg_ns": ns,
+                                                            "fetch_factor": f_cal, "write_factor": w_cal, "algorithmic_bytes": b}
             elif "vg_gram_valu" in k or "vg_gram_fused" in k:
                 fl = gram_flops(cfg)
                 work, frac = "%.4g flop" % fl, "%.3f of 78.6 TFLOP/s" % (fl / (ns * 1e-9) / FP64_PEAK)
@@ -108,6 +112,13 @@ if all_rows:
         for r in all_rows:
             w.writerow(r)
 open(os.path.join(OUT, tag + "_configs_pmc.md"), "w").write("\n".join(md) + "\n")
+if traffic_json:
+    import json
+
+    tj = os.path.join(OUT, "pmc_traffic.json")
+    cur = json.load(open(tj)) if os.path.exists(tj) else {}
+    cur.update(traffic_json)
+    json.dump(cur, open(tj, "w"), indent=1, sort_keys=True)
 src = os.path.join(ROOT, "gpurun_out", "bench_configs_%s.txt" % tag)
 if os.path.exists(src):
     text = open(src).read()

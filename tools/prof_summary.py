@@ -76,7 +76,10 @@ lines += ["", "SQ counters (issue / stall split per kernel): `profiles/%s_pmc_sq
 open(os.path.join(OUT, tag + "_pmc.md"), "w").write("\n".join(lines) + "\n")
 # the headline launch: the emit kernel that walks the chain itself (<model, jac, frames in LDS, INLINE = true>); the bench also
 # runs the prepared-frames variant on its 100 k-image stream section, which must not be taken for it
-emit = sorted((k for k in traffic if "vg_emit_kernel" in k), key=lambda k: (not k.rstrip().endswith("true>"), k))
+# (template arguments <model, WANT_JAC, FRAMES_LDS, INLINE_CHAIN>: the Jacobian-emitting instantiations only -- the residual-only
+#  one also runs, in the report projection of the calib section)
+emit = sorted((k for k in traffic if "vg_emit_kernel" in k and ", true, true, " in k.split("<", 1)[1][:20]),
+              key=lambda k: (not k.rstrip().endswith("true>"), k))
 tj = os.path.join(OUT, "pmc_traffic.json")
 cur = json.load(open(tj)) if os.path.exists(tj) else {}
 if emit:
@@ -84,7 +87,7 @@ if emit:
                          "fetch_factor": f_cal, "write_factor": w_cal,
                          "trace_avg_ns": float(stats[emit[0]]["AverageNs"]) if emit[0] in stats else None}
 # the prepared-frames emit kernel runs in bench.py's default line only on the 100 k-image stream section (eucm_100k)
-prep = [k for k in traffic if "vg_emit_kernel" in k and not k.rstrip().endswith("true>")]
+prep = [k for k in traffic if "vg_emit_kernel" in k and ", true, true, " in k.split("<", 1)[1][:20] and not k.rstrip().endswith("true>")]
 if prep and workload_key == "eucm_10000":
     cur["eucm_100000_stream"] = {"hbm_bytes_per_launch": traffic[prep[0]], "kernel": prep[0], "tag": tag, "fetch_factor": f_cal, "write_factor": w_cal,
                                  "trace_avg_ns": float(stats[prep[0]]["AverageNs"]) if prep[0] in stats else None}

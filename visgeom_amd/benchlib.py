@@ -185,6 +185,20 @@ def section(cfg, reps=200, device=0, images=None, solve_runs=2, comm=None, allre
     from . import capi
 
     one_launch = (not multi) and capi.load().vg_dataset_single_launch(p._h, dss[0][0]) == 1
+    # HBM bytes per emit launch from the committed PMC passes of this configuration (tools/prof_configs.sh + prof_configs_summary.py);
+    # only at the configuration's own size
+    traffic, traffic_source = None, None
+    if images is None:
+        try:
+            import json
+            import os
+
+            ent = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json"))).get("config%d_emit" % cfg)
+            if ent:
+                traffic = ent["hbm_bytes_per_launch"]
+                traffic_source = "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/prof_configs.sh, tag %s" % ent.get("tag")
+        except Exception:
+            traffic = None
     row = {
         "workload": name, "observations": n_obs,
         "emit": {"step_ms": t_emit * 1e3, "evals_per_s": n_obs / t_emit,
@@ -193,7 +207,7 @@ def section(cfg, reps=200, device=0, images=None, solve_runs=2, comm=None, allre
                  "roofline": {"bound": "hbm", "kernel": "vg_emit_multi_kernel" if multi else "vg_emit_kernel", "achieved": bytes_emit / t_emit_only / 1e9,
                               "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": bytes_emit / t_emit_only / HBM_PEAK,
                               "frac_whole_step": bytes_emit / t_emit / HBM_PEAK, "algorithmic_bytes_per_launch": bytes_emit,
-                              "avg_launch_ms": t_emit_only * 1e3, "traffic": None}},
+                              "avg_launch_ms": t_emit_only * 1e3, "traffic": traffic, "traffic_source": traffic_source}},
         "jtj": {"ms_per_iter": t_jtj * 1e3,
                 "launches": "chain prep + merged Gram launch + one partial-sum launch" if multi else "fused Gram launch + partial-sum launch",
                 "roofline": {"bound": "fp64", "kernel": "vg_gram_valu_multi_kernel" if multi else "vg_gram_valu_kernel", "achieved": flops_jtj / t_gram / 1e12,

@@ -1119,7 +1119,6 @@ int vg_calibration_write_residuals(vg_calibration *c, int dataset, const char *p
         }
         std::vector<double> board;
         for (auto &pt : data.board) board.insert(board.end(), pt.begin(), pt.end());
-        const std::vector<double> zeros(2 * (size_t)N * n, 0.);
         vg_problem *p = nullptr;
         int rc = vg_problem_create(&p, c->device, nullptr);
         if (rc != VG_OK) return rc;
@@ -1127,7 +1126,7 @@ int vg_calibration_write_residuals(vg_calibration *c, int dataset, const char *p
         const int st[1] = {VG_TRANSFORM_DIRECT};
         if ((rc = vg_problem_add_camera(p, c->cameraModelMap[data.cameraName], c->intrinsicMap[data.cameraName].data(), 1, &cam)) == VG_OK &&
             (rc = vg_problem_add_transform(p, 0, 1, (int64_t)n, xi.data(), &seq)) == VG_OK &&
-            (rc = vg_problem_add_dataset(p, cam, 1, &seq, st, N, board.data(), (int64_t)n, nullptr, zeros.data(), &ds)) == VG_OK &&
+            (rc = vg_problem_add_dataset(p, cam, 1, &seq, st, N, board.data(), (int64_t)n, nullptr, nullptr, &ds)) == VG_OK &&   // no corners: zero observations
             (rc = vg_problem_finalize(p)) == VG_OK) {
             // projecting = the residual against zero observations.  One launch into a device block of this call, one copy back
             // (vg_dataset_evaluate_to_host would set up its pinned staging for a problem that lives for one evaluation)

@@ -326,7 +326,7 @@ int vg_problem_add_dataset(vg_problem *p, int camera_id, int chain_len, const in
         return fail(VG_ERR_INVALID_ARGUMENT, "chain length must be in [0, 5]");  // :566-567 throws above 5
     if (chain_len > 0 && (!transform_ids || !status)) return fail(VG_ERR_INVALID_ARGUMENT, "chain arrays are NULL");
     if (n_points <= 0 || !board) return fail(VG_ERR_INVALID_ARGUMENT, "empty board");
-    if (n_images < 0 || (n_images > 0 && !corners)) return fail(VG_ERR_INVALID_ARGUMENT, "corners are NULL");
+    if (n_images < 0) return fail(VG_ERR_INVALID_ARGUMENT, "negative image count");   // corners NULL: zero observations (see the header)
     Dataset d;
     d.camera = camera_id;
     d.L = chain_len;
@@ -350,7 +350,8 @@ int vg_problem_add_dataset(vg_problem *p, int camera_id, int chain_len, const in
         d.h_seq[(size_t)i] = (int32_t)idx;
     }
     d.h_board.assign(board, board + 3 * (size_t)n_points);
-    d.h_obs.assign(corners, corners + (size_t)n_images * 2 * n_points);
+    d.zero_obs = corners == nullptr;
+    if (corners) d.h_obs.assign(corners, corners + (size_t)n_images * 2 * n_points);
     p->dss.push_back(std::move(d));
     if (dataset_id) *dataset_id = (int)p->dss.size() - 1;
     return VG_OK;
@@ -505,7 +506,8 @@ int vg_problem_finalize(vg_problem *p)
         VG_HIP(hipMalloc(&d.d_failed, sizeof(unsigned long long)));
         VG_HIP(hipMemset(d.d_failed, 0, sizeof(unsigned long long)));
         if (nb) {
-            VG_HIP(hipMemcpy(d.d_obs, d.h_obs.data(), sizeof(double) * nb * 2 * d.N, hipMemcpyHostToDevice));
+            if (d.zero_obs) VG_HIP(hipMemset(d.d_obs, 0, sizeof(double) * nb * 2 * d.N));   // a projection dataset: r = proj - 0
+            else VG_HIP(hipMemcpy(d.d_obs, d.h_obs.data(), sizeof(double) * nb * 2 * d.N, hipMemcpyHostToDevice));
             VG_HIP(hipMemcpy(d.d_seq, d.h_seq.data(), sizeof(int32_t) * nb, hipMemcpyHostToDevice));
         }
         // host copies are no longer needed; everything stays resident in HBM

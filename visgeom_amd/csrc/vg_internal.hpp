@@ -87,6 +87,7 @@ struct Dataset {
     std::vector<double> h_board, h_obs;
     std::vector<int32_t> h_seq;
     bool seq_identity = true;  // image b uses element b of its sequence: no index array needed on the device
+    bool zero_obs = false;     // added without corners: the observations are zeros (cleared on the device, nothing uploaded)
     double *d_board = nullptr, *d_obs = nullptr, *d_frames = nullptr;
     int32_t *d_seq = nullptr;
     unsigned long long *d_failed = nullptr;
