@@ -36,9 +36,10 @@ int vgi::refine_poses(int device, void *hip_stream, int model, const double *int
     struct Bufs {
         double *board = nullptr, *obs = nullptr, *intr = nullptr, *poses = nullptr, *cost = nullptr;
         int *it = nullptr, *term = nullptr;
+        unsigned int *next = nullptr;
         ~Bufs()
         {
-            for (void *q : {(void *)board, (void *)obs, (void *)intr, (void *)poses, (void *)cost, (void *)it, (void *)term})
+            for (void *q : {(void *)board, (void *)obs, (void *)intr, (void *)poses, (void *)cost, (void *)it, (void *)term, (void *)next})
                 if (q) (void)hipFree(q);
         }
     } d;
@@ -50,6 +51,8 @@ int vgi::refine_poses(int device, void *hip_stream, int model, const double *int
     VG_HIP(hipMalloc(&d.cost, sizeof(double) * n));
     VG_HIP(hipMalloc(&d.it, sizeof(int) * n));
     VG_HIP(hipMalloc(&d.term, sizeof(int) * n));
+    VG_HIP(hipMalloc(&d.next, sizeof(unsigned int)));
+    VG_HIP(hipMemsetAsync(d.next, 0, sizeof(unsigned int), st));
     VG_HIP(hipMemcpyAsync(d.board, board, sizeof(double) * 3 * N, hipMemcpyHostToDevice, st));
     VG_HIP(hipMemcpyAsync(d.obs, corners, sizeof(double) * 2 * N * n, hipMemcpyHostToDevice, st));
     VG_HIP(hipMemcpyAsync(d.intr, intrinsics, sizeof(double) * K, hipMemcpyHostToDevice, st));
@@ -62,6 +65,7 @@ int vgi::refine_poses(int device, void *hip_stream, int model, const double *int
     a.iterations = d.it;
     a.final_cost = d.cost;
     a.termination = d.term;
+    a.next = d.next;
     a.n_images = (unsigned int)n_images;
     a.N = (unsigned int)n_points;
     a.max_iter = o.max_num_iterations;
@@ -75,7 +79,26 @@ int vgi::refine_poses(int device, void *hip_stream, int model, const double *int
     a.min_rel_decrease = o.min_relative_decrease;
     a.dmin = o.min_lm_diagonal;
     a.dmax = o.max_lm_diagonal;
-    const dim3 grid((unsigned int)((n_images + vg::kValuImagesPerBlock - 1) / vg::kValuImagesPerBlock)), blk(vg::kValuThreads);
+    // a persistent grid: as many workgroups as are resident at once (two per CU at two waves per SIMD), never more than the images
+    // need; every half-wave starts on the image of its position and takes further ones from the counter
+    static int cu_count[64] = {0};   // per device, asked once (hipGetDeviceProperties is a millisecond)
+    if (device < 64 && !cu_count[device]) {
+        int cus = 0;
+        VG_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+        cu_count[device] = cus > 0 ? cus : 1;
+    }
+    const int n_cus = device < 64 ? cu_count[device] : 256;
+    int per_cu = 0;
+    const void *fn = model == VG_MODEL_EUCM ? reinterpret_cast<const void *>(vg::vg_pose_lm_kernel<vg::kEUCM>)
+                     : model == VG_MODEL_UCM ? reinterpret_cast<const void *>(vg::vg_pose_lm_kernel<vg::kUCM>)
+                                             : reinterpret_cast<const void *>(vg::vg_pose_lm_kernel<vg::kMEI>);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, vg::kValuThreads, 0) != hipSuccess || per_cu < 1) {
+        (void)hipGetLastError();
+        per_cu = 1;
+    }
+    const int64_t wgs_needed = (n_images + vg::kValuImagesPerBlock - 1) / vg::kValuImagesPerBlock;
+    const int64_t wgs_resident = (int64_t)per_cu * n_cus;
+    const dim3 grid((unsigned int)(wgs_needed < wgs_resident ? wgs_needed : wgs_resident)), blk(vg::kValuThreads);
     struct Events {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         ~Events()
