@@ -268,10 +268,85 @@ VG_HD constexpr int frame_stride(int L) { return (frame_doubles(L) + 1) & ~1; }
 // The chain walk, one member at a time.  Mirrors calib_cost_functions.cpp:32-46 (accumulation) and :76-92 (xi13 / xi23
 // pick); the reference walks the chain twice with identical arithmetic, one walk is enough.
 struct ChainState {
-    Transf acc;         // xiAcc
+    Transf acc;         // xiAcc (acc.r is maintained only while !fast)
     double Racc[9];     // R(xiAcc.rot) when racc_valid
     bool racc_valid;
+    Quat qacc;          // fast: xiAcc's rotation as the unit quaternion with w >= 0, i.e. Quaternion(xiAcc.rot)
+    bool fast;
 };
+
+// The device walk keeps the accumulated rotation as a quaternion wherever that is the reference's arithmetic up to rounding.
+// The reference turns every product q1 * q2 back into a rotation vector (atan2), and the next consumer turns that vector into
+// a quaternion (sincos of theta/2) or a matrix (sincos of theta) again: Quaternion(toRotationVector(q)) is q / |q| with
+// w >= 0, and rotationMatrix(toRotationVector(q)) is the matrix of that unit quaternion, both to 1e-16 -- EXCEPT inside the
+// first-order branches (|q.xyz| < 1e-5 in toRotationVector, theta < 1e-5 / 1e-6 in rotationMatrix / Quaternion), whose
+// results are up to 5e-11 away from the exact ones.  So the quaternion is carried only while |q.xyz| >= 1e-4 |q| (theta >=
+// 2e-4: twenty times the widest threshold); below, the reference-order routines run unchanged.  A [global INVERSE, pose
+// DIRECT] chain drops from seven sincos, two atan2 and their square roots / divisions in one dependent chain to two sincos.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(VG_WALK_REFERENCE_ORDER)
+#define VG_WALK_FAST 1
+#else
+#define VG_WALK_FAST 0
+#endif
+
+// rotation matrix of a unit quaternion, row-major
+VG_HD void quat_matrix(const Quat &q, double *R)
+{
+    const double xx = q.x * q.x, yy = q.y * q.y, zz = q.z * q.z;
+    const double xy = q.x * q.y, xz = q.x * q.z, yz = q.y * q.z;
+    const double wx = q.w * q.x, wy = q.w * q.y, wz = q.w * q.z;
+    R[0] = 1. - 2. * (yy + zz); R[1] = 2. * (xy - wz);      R[2] = 2. * (xz + wy);
+    R[3] = 2. * (xy + wz);      R[4] = 1. - 2. * (xx + zz); R[5] = 2. * (yz - wx);
+    R[6] = 2. * (xz - wy);      R[7] = 2. * (yz + wx);      R[8] = 1. - 2. * (xx + yy);
+}
+
+#if VG_WALK_FAST
+// qres = q1 * q2 of a compose / composeInverse: true when its rotation is carried as s.qacc from here on
+__device__ __forceinline__ bool chain_carry_quat(ChainState &s, const Quat &qres)
+{
+    const double v2 = qres.x * qres.x + qres.y * qres.y + qres.z * qres.z;
+    const double n2 = v2 + qres.w * qres.w;
+    s.fast = v2 >= 1e-8 * n2;
+    if (!s.fast) return false;
+    double nrm, inv;
+    sqrt_rsqrt_nr(n2, nrm, inv);
+    if (qres.w < 0.) inv = -inv;   // toRotationVector wraps theta > pi to theta - 2 pi: the quaternion of that vector is -q
+    s.qacc = {qres.x * inv, qres.y * inv, qres.z * inv, qres.w * inv};
+    return true;
+}
+#endif
+
+// R(xiAcc.rot) into s.Racc
+VG_HD void chain_acc_matrix(ChainState &s)
+{
+#if VG_WALK_FAST
+    if (s.fast) {
+        quat_matrix(s.qacc, s.Racc);
+        return;
+    }
+#endif
+    const RotTrig go = rot_trig(s.acc.r, true, false);
+    rotation_matrix(s.acc.r, 1., go, s.Racc);
+}
+
+// trig of a chain member's own rotation vector.  Device: ONE sincos (half angle; sin th = 2 sh ch, cos th = 1 - 2 sh^2, so the
+// 1 - cos th of rotationMatrix is 2 sh^2 to an ulp), in exactly the branches rot_trig takes.
+VG_HD RotTrig rot_trig_member(const double *v)
+{
+#if VG_WALK_FAST
+    RotTrig q;
+    q.th = norm3(v);
+    q.s = 0.; q.c = 1.; q.sh = 0.; q.ch = 1.;
+    if (!(fabs(q.th) < 1e-6)) sincos_(q.th / 2., &q.sh, &q.ch);
+    if (!(q.th < 1e-5)) {
+        q.s = 2. * q.sh * q.ch;
+        q.c = 1. - 2. * q.sh * q.sh;
+    }
+    return q;
+#else
+    return rot_trig(v, true, true);
+#endif
+}
 
 VG_HD void chain_state_init(ChainState &s)
 {
@@ -280,11 +355,16 @@ VG_HD void chain_state_init(ChainState &s)
 #pragma unroll
     for (int i = 0; i < 9; i++) s.Racc[i] = I0[i];
     s.racc_valid = true;
+    s.qacc = {0., 0., 0., 1.};
+    s.fast = false;   // the identity is inside the first-order branches: reference order
 }
 
 // Quaternion(xiAcc.rot): what every member's compose / composeInverse starts with (transformation.h:83,105)
 VG_HD Quat chain_acc_quat(const ChainState &s)
 {
+#if VG_WALK_FAST
+    if (s.fast) return s.qacc;
+#endif
     const RotTrig gacc = rot_trig(s.acc.r, false, true);
     return quat_from_rotvec(s.acc.r, gacc);
 }
@@ -295,7 +375,7 @@ VG_HD void chain_walk_member(ChainState &s, const Quat &q1, const double *xi23, 
     Transf &acc = s.acc;
     const double t23[3] = {xi23[0], xi23[1], xi23[2]};
     const double r23[3] = {xi23[3], xi23[4], xi23[5]};
-    const RotTrig g23 = rot_trig(r23, true, true);
+    const RotTrig g23 = rot_trig_member(r23);
     const Quat q2 = quat_from_rotvec(r23, g23);
 
     double R13[9], t13[3];
@@ -307,19 +387,18 @@ VG_HD void chain_walk_member(ChainState &s, const Quat &q1, const double *xi23, 
         acc.t[0] = rt[0] + acc.t[0];
         acc.t[1] = rt[1] + acc.t[1];
         acc.t[2] = rt[2] + acc.t[2];
-        quat_to_rotvec(qres, acc.r);
-        const RotTrig gn = rot_trig(acc.r, true, false);
-        rotation_matrix(acc.r, 1., gn, s.Racc);
+#if VG_WALK_FAST
+        if (!chain_carry_quat(s, qres))
+#endif
+            quat_to_rotvec(qres, acc.r);
+        chain_acc_matrix(s);
         s.racc_valid = true;
 #pragma unroll
         for (int i = 0; i < 9; i++) R13[i] = s.Racc[i];
         t13[0] = acc.t[0]; t13[1] = acc.t[1]; t13[2] = acc.t[2];
     } else {
         // xi13 = xiAcc; xiAcc = xiAcc.composeInverse(xi23)   transformation.h:101-110
-        if (!s.racc_valid) {
-            const RotTrig go = rot_trig(acc.r, true, false);
-            rotation_matrix(acc.r, 1., go, s.Racc);
-        }
+        if (!s.racc_valid) chain_acc_matrix(s);
 #pragma unroll
         for (int i = 0; i < 9; i++) R13[i] = s.Racc[i];
         t13[0] = acc.t[0]; t13[1] = acc.t[1]; t13[2] = acc.t[2];
@@ -330,7 +409,10 @@ VG_HD void chain_walk_member(ChainState &s, const Quat &q1, const double *xi23, 
         acc.t[0] = acc.t[0] - rt[0];
         acc.t[1] = acc.t[1] - rt[1];
         acc.t[2] = acc.t[2] - rt[2];
-        quat_to_rotvec(qres, acc.r);
+#if VG_WALK_FAST
+        if (!chain_carry_quat(s, qres))
+#endif
+            quat_to_rotvec(qres, acc.r);
         s.racc_valid = false;
     }
 
@@ -350,10 +432,7 @@ VG_HD void chain_walk_member(ChainState &s, const Quat &q1, const double *xi23, 
 // frame[0..11] = R(xiAcc.rot), xiAcc.trans of the finished chain
 VG_HD void chain_finish(ChainState &s, double *frame)
 {
-    if (!s.racc_valid) {
-        const RotTrig go = rot_trig(s.acc.r, true, false);
-        rotation_matrix(s.acc.r, 1., go, s.Racc);
-    }
+    if (!s.racc_valid) chain_acc_matrix(s);
 #pragma unroll
     for (int i = 0; i < 9; i++) frame[i] = s.Racc[i];
     frame[9] = s.acc.t[0]; frame[10] = s.acc.t[1]; frame[11] = s.acc.t[2];
