@@ -273,6 +273,21 @@ def test_text_to_double_conversion_equals_strtod(tmp_path):
     assert b"bad 0" in r.stdout
 
 
+def test_report_numbers_print_as_percent_g(tmp_path):
+    """the residual report's numbers (writeImageResidual unified_calibration.cpp:1210-1213 through operator<<: "%g") come from
+    vgtext::fmt_g6, one multiplication by an exact power of ten with the exact conversion behind every near-tie: a compiled host
+    check holds its text to snprintf("%g") on 21 M values incl. exact ties of the sixth digit, decade boundaries and specials"""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "format_g6_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", os.path.join(root, "tests", "host", "format_g6_check.cpp"), "-o", exe])
+    r = subprocess.run([exe], stdout=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stdout.decode()
+    assert b" bad 0" in r.stdout
+
+
 def test_corner_file_is_read_exactly_and_frames_keep_their_order(tmp_path):
     """readCorners (unified_calibration.cpp:252-277) through the streaming reader: every corner equals the value written
     (repr round trip), frames without an entry for the camera are empty, entries of other cameras and unknown keys are skipped,

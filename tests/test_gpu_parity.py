@@ -163,6 +163,55 @@ def test_small_angle_and_wraparound_branches(vg, name, status):
     blk.close()
 
 
+ACC_CASES = {
+    # what the chain has accumulated after its first two members, in front of the board pose
+    "cancels_to_identity": ([0.3, -0.2, 0.25], 0.0),
+    "below_quaternion_1e-6": ([0.3, -0.2, 0.25], 1.4e-6),
+    "just_below_rotvec_1e-5": ([0.3, -0.2, 0.25], 1.99e-5),    # |q.xyz| = theta / 2 against 1e-5 (quaternion.h:88)
+    "just_above_rotvec_1e-5": ([0.3, -0.2, 0.25], 2.01e-5),
+    "matrix_1e-5": ([0.3, -0.2, 0.25], 1.0001e-5),             # rotationMatrix's own threshold (geometry_core.h:45)
+    "below_device_switch": ([0.3, -0.2, 0.25], 1.99e-4),       # the device walk carries the quaternion from |q.xyz| = 1e-4
+    "above_device_switch": ([0.3, -0.2, 0.25], 2.01e-4),
+    "wraps_past_pi": ([0.0, 2.5, 0.0], None),                  # 2.5 + 2.4 rad about one axis: toRotationVector renormalises
+    "exactly_pi": ([0.0, np.pi / 2, 0.0], "pi"),
+}
+
+
+@pytest.mark.parametrize("name", sorted(ACC_CASES))
+@pytest.mark.parametrize("status", [[0, 1, 0], [0, 0, 0], [1, 0, 0], [0, 1, 1, 0]], ids=["DID", "DDD", "IDD", "DIID"])
+def test_accumulated_rotation_of_a_long_chain_in_every_zone(vg, name, status):
+    """The accumulated transformation xiAcc BETWEEN members: inside the first-order branches of toRotationVector / Quaternion /
+    rotationMatrix (where the reference's results are 5e-11 away from the exact ones and must be reproduced), either side of the
+    magnitude from which the device walk carries a quaternion instead of the rotation vector (vg_geometry.hpp VG_WALK_FAST), and
+    past pi, where compose() renormalises the angle (transformation.h:80-88, quaternion.h:84-98)."""
+    from scipy.spatial.transform import Rotation as Rot
+    from visgeom_amd import synthetic
+
+    board = synthetic.board_points()
+    r1, residue = ACC_CASES[name]
+    r1 = np.array(r1)
+    R1 = Rot.from_rotvec(r1)
+    if residue is None:
+        R2 = Rot.from_rotvec([0.0, 2.4, 0.0])
+    elif residue == "pi":
+        R2 = Rot.from_rotvec([0.0, np.pi / 2, 0.0])
+    else:
+        R2 = R1.inv() * Rot.from_rotvec(residue * np.array([0.6, -0.64, 0.48]))   # R1 R2 = a rotation of `residue` rad
+    # member k contributes R_k or its inverse: pick the vectors so that the accumulated ROTATION is R1, then R1 R2, whatever the status
+    def member(R, st, t):
+        return np.concatenate([t, (R.inv() if st else R).as_rotvec()])
+    first = [member(R1, status[0], [0.02, -0.01, 0.03]), member(R2, status[1], [-0.01, 0.02, 0.01])]
+    extra = [member(Rot.from_rotvec([1e-3, 2e-3, -1e-3]), st, [0.0, 0.01, 0.0]) for st in status[2:-1]]
+    pose = np.array([-0.55, -0.35, 0.9, 0.3, -0.4, 0.1])
+    params = [synthetic.GT_EUCM_CAM1] + first + extra + [pose]
+    obs = np.full((96, 2), 600.0)
+    blk = vg.GenericProjectionJac(obs, board, "eucm", status)
+    res, J = blk.Evaluate(params)
+    rr, JJ = vgo.eval_block(vgo.MODEL_EUCM, status, board, obs, params)
+    assert_block_parity(res, J, rr, JJ, obs, name)
+    blk.close()
+
+
 @pytest.mark.parametrize("model", MODELS)
 def test_failed_and_behind_camera_points(vg, S, model):
     """EUCM reports failure in-band (1e15 / zero rows); UCM and Mei never do and return

@@ -34,6 +34,7 @@
 #include "vg_host_parallel.hpp"
 #include "vg_internal.hpp"
 #include "vg_json.hpp"
+#include "vg_text_format.hpp"
 #include "vg_transf_host.hpp"
 
 namespace vgcal {
@@ -118,32 +119,10 @@ struct ImageData {  // unified_calibration.h:46-87 (the fields the grid residual
 };
 
 // Eigen's default stream format of a row vector: the stream's default notation with 6 significant digits (what printf's
-// "%g" prints; std::to_chars in general notation with precision 6 is specified as exactly that conversion and is three
-// times faster than snprintf -- 75 against 250 ns per number, identical text on 4 M test values, profiles/NOTES.md round 5),
-// coefficients right-aligned to the widest one, separated by one space
-inline int fmt_g6(double v, char *buf, size_t size)
-{
-    const std::to_chars_result r = std::to_chars(buf, buf + size, v, std::chars_format::general, 6);
-    if (r.ec != std::errc()) return std::snprintf(buf, size, "%g", v);
-    return (int)(r.ptr - buf);
-}
+// "%g" prints: vgtext::fmt_g6, vg_text_format.hpp), coefficients right-aligned to the widest one, separated by one space
+inline int fmt_g6(double v, char *buf, size_t size) { return vgtext::fmt_g6(v, buf, size); }   // vg_text_format.hpp
 
-inline void fmt_vec_append(std::string &out, const double *v, int n)
-{
-    char buf[8][32];
-    int len[8];
-    if (n > 8) n = 8;  // the front end prints 2- and 3-vectors
-    int w = 0;
-    for (int i = 0; i < n; i++) {
-        len[i] = fmt_g6(v[i], buf[i], sizeof(buf[i]));
-        w = len[i] > w ? len[i] : w;
-    }
-    for (int i = 0; i < n; i++) {
-        if (i) out += ' ';
-        out.append((size_t)(w - len[i]), ' ');
-        out.append(buf[i], (size_t)len[i]);
-    }
-}
+inline void fmt_vec_append(std::string &out, const double *v, int n) { vgtext::fmt_vec_append(out, v, n); }
 
 inline std::string fmt_vec(const double *v, int n)
 {
@@ -633,14 +612,14 @@ inline void read_frame_corners(vgjson::Cursor &cur, const std::string &cameraID,
 
 inline void read_corners(vg_calibration *c, ImageData &data, const std::string &file, const std::string &cameraID)
 {
-    std::string text;
+    vgjson::TextFile text;
     {
         PhaseClock clk(c->timings.read_files_s);
-        text = vgjson::read_text_file(file);
+        text.read(file);   // ranges of the file side by side, one per host thread
     }
     c->timings.json_bytes += (int64_t)text.size();
     PhaseClock clk(c->timings.parse_json_s);
-    const std::vector<std::pair<size_t, size_t>> frames = vgjson::element_spans(text);
+    const std::vector<std::pair<size_t, size_t>> frames = vgjson::element_spans(text.c_str(), text.size());
     const size_t first = data.detectedCornersVec.size(), n_board = data.board.size();
     data.detectedCornersVec.resize(first + frames.size());
     vgpar::parallel_ranges(frames.size(), 64, [&](size_t b, size_t e, int) {
@@ -1142,22 +1121,38 @@ int vg_calibration_write_residuals(vg_calibration *c, int dataset, const char *p
         if (rc != VG_OK) return rc;
     }
     vgcal::PhaseClock clk(c->timings.residual_format_s);
-    std::vector<std::string> text((size_t)vgpar::host_threads());
-    std::vector<int64_t> outliers(text.size(), 0);
-    const int parts = vgpar::parallel_ranges(n, 64, [&](size_t b, size_t e, int part) {
-        std::string &out = text[(size_t)part];
-        out.reserve((e - b) * (size_t)N * 100);
+    // every thread formats its image range into a block of its own (a line is at most 14 numbers of <= 13 characters, blanks and the
+    // newline: kMaxLine bytes; pages a range does not reach are never touched), then the blocks are written in order
+    constexpr size_t kMaxLine = 14 * 14 + 16;
+    struct Part {
+        std::unique_ptr<char[]> buf;
+        size_t len = 0;
+        int64_t outliers = 0;
+    };
+    std::vector<Part> part((size_t)vgpar::host_threads());
+    const int parts = vgpar::parallel_ranges(n, 64, [&](size_t b, size_t e, int pi) {
+        Part &P = part[(size_t)pi];
+        P.buf.reset(new char[(e - b) * (size_t)N * kMaxLine]);
+        char *o = P.buf.get();
         for (size_t k = b; k < e; k++) {
             const std::vector<double> &det = data.detectedCornersVec[images[k]];
             const double *pr = &proj[2 * (size_t)N * k];
-            const std::string pose = "   " + vgcal::fmt_vec(&xi[6 * k], 3) + " " + vgcal::fmt_vec(&xi[6 * k + 3], 3) + "\n";
+            char pose[8 * 14 + 8];
+            char *pe = pose;
+            *pe++ = ' '; *pe++ = ' '; *pe++ = ' ';
+            pe = vgtext::fmt_vec_at(pe, &xi[6 * k], 3);
+            *pe++ = ' ';
+            pe = vgtext::fmt_vec_at(pe, &xi[6 * k + 3], 3);
+            *pe++ = '\n';
+            const size_t pose_len = (size_t)(pe - pose);
             double stdAcc = 0;
             for (int i = 0; i < N; i++) {
                 const double err[2] = {det[2 * (size_t)i] - pr[2 * i], det[2 * (size_t)i + 1] - pr[2 * i + 1]};
-                vgcal::fmt_vec_append(out, err, 2);
-                out += "   ";
-                vgcal::fmt_vec_append(out, pr + 2 * i, 2);
-                out += pose;
+                o = vgtext::fmt_vec_at(o, err, 2);
+                *o++ = ' '; *o++ = ' '; *o++ = ' ';
+                o = vgtext::fmt_vec_at(o, pr + 2 * i, 2);
+                std::memcpy(o, pose, pose_len);
+                o += pose_len;
                 stdAcc += err[0] * err[0] + err[1] * err[1];
             }
             const double sigma = std::sqrt(stdAcc / (N - 2));
@@ -1165,15 +1160,16 @@ int vg_calibration_write_residuals(vg_calibration *c, int dataset, const char *p
             for (int i = 0; i < N; i++) {
                 const double ex = det[2 * (size_t)i] - pr[2 * i], ey = det[2 * (size_t)i + 1] - pr[2 * i + 1];
                 const double en = std::sqrt(ex * ex + ey * ey);
-                if (!(en < 3.6 * sigma && en < 1.)) outliers[(size_t)part]++;  // :1222
+                if (!(en < 3.6 * sigma && en < 1.)) P.outliers++;  // :1222
             }
         }
+        P.len = (size_t)(o - P.buf.get());
     });
     int64_t total = 0;
     for (int k = 0; k < parts; k++) {
-        if (!text[(size_t)k].empty() && std::fwrite(text[(size_t)k].data(), 1, text[(size_t)k].size(), f) != text[(size_t)k].size())
+        if (part[(size_t)k].len && std::fwrite(part[(size_t)k].buf.get(), 1, part[(size_t)k].len, f) != part[(size_t)k].len)
             return vgi::fail(VG_ERR_INVALID_ARGUMENT, std::string("cannot write ") + path);
-        total += outliers[(size_t)k];
+        total += part[(size_t)k].outliers;
     }
     closer.f = nullptr;
     if (std::fclose(f) != 0) return vgi::fail(VG_ERR_INVALID_ARGUMENT, std::string("cannot write ") + path);
