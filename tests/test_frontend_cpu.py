@@ -273,6 +273,21 @@ def test_text_to_double_conversion_equals_strtod(tmp_path):
     assert b"bad 0" in r.stdout
 
 
+def test_parallel_cut_of_a_corner_file_equals_the_serial_one(tmp_path):
+    """element_spans_parallel (three sweeps over ranges of the text side by side: string state, depth, top-level separators) against
+    element_spans_serial on random arrays whose strings carry brackets, commas, quotes and backslash runs, with range boundaries
+    inside strings and escapes, and on damaged copies: equal, or declined whenever the serial cut throws"""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "json_spans_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", os.path.join(root, "tests", "host", "json_spans_check.cpp"), "-o", exe])
+    r = subprocess.run([exe], stdout=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stdout.decode()[-2000:]
+    assert b" bad 0" in r.stdout
+
+
 def test_report_numbers_print_as_percent_g(tmp_path):
     """the residual report's numbers (writeImageResidual unified_calibration.cpp:1210-1213 through operator<<: "%g") come from
     vgtext::fmt_g6, one multiplication by an exact power of ten with the exact conversion behind every near-tie: a compiled host
@@ -288,16 +303,19 @@ def test_report_numbers_print_as_percent_g(tmp_path):
     assert b" bad 0" in r.stdout
 
 
-def test_corner_file_is_read_exactly_and_frames_keep_their_order(tmp_path):
+@pytest.mark.parametrize("n_frames", [300, 600])
+def test_corner_file_is_read_exactly_and_frames_keep_their_order(tmp_path, n_frames):
     """readCorners (unified_calibration.cpp:252-277) through the streaming reader: every corner equals the value written
     (repr round trip), frames without an entry for the camera are empty, entries of other cameras and unknown keys are skipped,
-    the FIRST matching entry of a frame counts; 300 frames so that several host threads share the file"""
+    the FIRST matching entry of a frame counts; 300 frames so that several host threads share the file, 600 (6 MB) so that the
+    file is also CUT into frames by several threads (element_spans_parallel, from 4 MB)"""
     import json
+    import os
 
-    d = S.make_mono("eucm", 300, 1)
-    skip = {3, 17, 299}
+    d = S.make_mono("eucm", n_frames, 1)
+    skip = {3, 17, n_frames - 1}
     frames = []
-    for i in range(300):
+    for i in range(n_frames):
         fr = [{"camera": "other", "points": [[1.0, 2.0]], "extra": {"a": [1, {"b": "]"}], "s": 'x"y\\'}}]
         if i not in skip:
             fr.append({"points": d["corners"][i].tolist(), "note": "first", "camera": "cam"})   # keys in another order
@@ -305,11 +323,12 @@ def test_corner_file_is_read_exactly_and_frames_keep_their_order(tmp_path):
         frames.append(fr)
     path = S.write_calibration_json(str(tmp_path), d, "eucm", prior=True)
     json.dump(frames, open(tmp_path / "calib_corners.json", "w"), indent=1)
+    assert (os.path.getsize(tmp_path / "calib_corners.json") >= 4 << 20) == (n_frames == 600)
     c = GenericCameraCalibration()
     c.addResiduals(path)
     got = c.corners(0)
-    assert len(got) == 300
-    for i in range(300):
+    assert len(got) == n_frames
+    for i in range(n_frames):
         if i in skip:
             assert got[i] is None
         else:
