@@ -118,6 +118,19 @@ struct ImageData {  // unified_calibration.h:46-87 (the fields the grid residual
     }
 };
 
+// the corners of `images` (indices into detectedCornersVec, every one non-empty with 2 N doubles) as one block [image][N][2], copied
+// by the host's threads into memory nobody cleared first (10 000 images: 15 MB; growing a vector by insert() cost 4 ms per use)
+inline std::unique_ptr<double[]> gather_corners(const ImageData &data, const std::vector<int> &images, int N)
+{
+    std::unique_ptr<double[]> out(new double[images.size() * 2 * (size_t)N + 1]);
+    double *dst = out.get();
+    vgpar::parallel_ranges(images.size(), 256, [&](size_t b, size_t e, int) {
+        for (size_t k = b; k < e; k++)
+            std::memcpy(dst + k * 2 * (size_t)N, data.detectedCornersVec[(size_t)images[k]].data(), sizeof(double) * 2 * (size_t)N);
+    });
+    return out;
+}
+
 // Eigen's default stream format of a row vector: the stream's default notation with 6 significant digits (what printf's
 // "%g" prints: vgtext::fmt_g6, vg_text_format.hpp), coefficients right-aligned to the widest one, separated by one space
 inline int fmt_g6(double v, char *buf, size_t size) { return vgtext::fmt_g6(v, buf, size); }   // vg_text_format.hpp
@@ -369,16 +382,15 @@ inline std::vector<Array6d> estimate_initial_grids(vg_calibration *c, const Imag
     if (!data.doNotSolve && !images.empty()) {
         PhaseClock clk(c->timings.refine_total_s);
         const int N = (int)data.board.size();
-        std::vector<double> board, corners, poses;
+        std::vector<double> board, poses;
         for (auto &pt : data.board) board.insert(board.end(), pt.begin(), pt.end());
-        for (int img : images) {
-            corners.insert(corners.end(), data.detectedCornersVec[(size_t)img].begin(), data.detectedCornersVec[(size_t)img].end());
-            poses.insert(poses.end(), cam_pose[(size_t)img].begin(), cam_pose[(size_t)img].end());
-        }
+        poses.reserve(6 * images.size());
+        for (int img : images) poses.insert(poses.end(), cam_pose[(size_t)img].begin(), cam_pose[(size_t)img].end());
+        const std::unique_ptr<double[]> corners = gather_corners(data, images, N);   // (a non-empty list has 2 N entries: read_corners)
         std::vector<int32_t> iters(images.size(), 0);
         double kernel_s = 0.;
         const int rc = vgi::refine_poses(c->device, nullptr, c->cameraModelMap[data.cameraName], c->intrinsicMap[data.cameraName].data(), N,
-                                         board.data(), (int64_t)images.size(), corners.data(), poses.data(), nullptr, iters.data(), nullptr,
+                                         board.data(), (int64_t)images.size(), corners.get(), poses.data(), nullptr, iters.data(), nullptr,
                                          nullptr, &kernel_s);
         if (rc != VG_OK) throw Error{rc, vg_last_error()};
         c->timings.refine_kernel_s += kernel_s;
@@ -906,19 +918,17 @@ int vg_calibration_compute(vg_calibration *c, const vg_solve_options *options, v
     for (auto &data : c->dataVec) {  // addGridResidualBlocks :514-630
         std::vector<int> tids;
         for (auto &n : data.transNameVec) tids.push_back(tfId[n]);
-        std::vector<double> board, corners;
+        std::vector<double> board;
         std::vector<int32_t> idx;
         for (auto &pt : data.board) board.insert(board.end(), pt.begin(), pt.end());
         // "do_not_solve_global" (:516): the dataset adds no residual blocks to the global problem -- it is registered
         // without images so that dataset ids keep matching dataVec (its residual file is still written afterwards)
         for (size_t i = 0; i < data.detectedCornersVec.size() && !data.doNotSolveGlobal; i++)
-            if (!data.detectedCornersVec[i].empty()) {  // :520
-                idx.push_back((int32_t)i);
-                corners.insert(corners.end(), data.detectedCornersVec[i].begin(), data.detectedCornersVec[i].end());
-            }
+            if (!data.detectedCornersVec[i].empty()) idx.push_back((int32_t)i);  // :520
+        const std::unique_ptr<double[]> corners = vgcal::gather_corners(data, std::vector<int>(idx.begin(), idx.end()), (int)data.board.size());
         if ((rc = vg_problem_add_dataset(p, camId[data.cameraName], (int)tids.size(), tids.data(), data.transStatusVec.data(),
                                          (int)data.board.size(), board.data(), (int64_t)idx.size(), idx.data(),
-                                         corners.data(), nullptr)) != VG_OK)
+                                         corners.get(), nullptr)) != VG_OK)
             return bail(rc);
     }
     for (auto &od : c->odometry) {  // one OdometryPrior per consecutive pair (:790-801), optional anchor (:803-806)
