@@ -7,6 +7,9 @@
 #include <sched.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <cstdio>
 #include <exception>
 #include <system_error>
@@ -79,6 +82,71 @@ inline int parallel_ranges(size_t n, size_t min_per_part, F &&fn)
     for (auto &e : err)
         if (e) std::rethrow_exception(e);
     return (int)parts;
+}
+
+// produce(k) for k in [0, n_items) on the host's threads, in whatever order they get to them; consume(k) on the CALLING thread in
+// increasing k, each as soon as produce(k) has returned (the residual report: image ranges are formatted side by side while the
+// finished ones are already being written).  An exception of produce / consume stops the pipeline and is rethrown after all threads
+// have joined.
+template <class Produce, class Consume>
+inline void ordered_pipeline(size_t n_items, Produce &&produce, Consume &&consume)
+{
+    if (n_items == 0) return;
+    std::vector<unsigned char> done(n_items, 0);
+    std::mutex m;
+    std::condition_variable cv;
+    std::atomic<size_t> next(0);
+    std::atomic<bool> stop(false);
+    std::exception_ptr error;
+    auto work = [&] {
+        for (;;) {
+            const size_t k = next.fetch_add(1);
+            if (k >= n_items || stop.load()) return;
+            std::exception_ptr e;
+            try {
+                produce(k);
+            } catch (...) {
+                e = std::current_exception();
+            }
+            std::lock_guard<std::mutex> lk(m);
+            if (e) {
+                if (!error) error = e;
+                stop.store(true);
+            }
+            done[k] = 1;
+            cv.notify_all();
+        }
+    };
+    std::vector<std::thread> team;
+    const size_t want = std::min<size_t>((size_t)host_threads(), n_items);
+    if (want >= 2) {
+        team.reserve(want);
+        for (size_t t = 0; t < want; t++) {
+            try {
+                team.emplace_back(work);
+            } catch (const std::system_error &) {
+                break;
+            }
+        }
+    }
+    try {
+        for (size_t k = 0; k < n_items; k++) {
+            if (team.empty()) {   // no helper could be started (or one CPU): produce here
+                produce(k);
+            } else {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return done[k] != 0 || (bool)error; });
+                if (error) break;
+            }
+            consume(k);
+        }
+    } catch (...) {
+        std::lock_guard<std::mutex> lk(m);
+        if (!error) error = std::current_exception();
+    }
+    stop.store(true);
+    for (auto &t : team) t.join();
+    if (error) std::rethrow_exception(error);
 }
 
 }  // namespace vgpar
