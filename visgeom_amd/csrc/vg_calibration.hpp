@@ -29,6 +29,7 @@
 #include <memory>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "vg_host_parallel.hpp"
@@ -179,6 +180,11 @@ struct vg_calibration {
     std::vector<OdometryIntrinsic> odometryIntrinsic;
     std::string log;  // what the reference prints to stdout while parsing / solving
     vg_calibration_timings timings = {};  // where the wall-clock time of this handle went (vg_calibration_get_timings)
+    std::thread runtime_warmup;           // brings the HIP runtime up beside the reading of the files (vg_calibration_create)
+    ~vg_calibration()
+    {
+        if (runtime_warmup.joinable()) runtime_warmup.join();
+    }
 
     vgcal::Array6d &getTransformData(const std::string &name, int idx)  // unified_calibration.h:161-165
     {
@@ -862,6 +868,18 @@ int vg_calibration_create(vg_calibration **out, int device)
     *out = new (std::nothrow) vg_calibration();
     if (!*out) return vgi::fail(VG_ERR_ALLOC, "out of host memory");
     (*out)->device = device;
+    // A fresh process spends ~0.11 s in the first HIP call (runtime + device initialisation: half the wall clock of `calib a.json`
+    // on 10 000 images, tools/exp/cli_phases_probe.py) and the front end has ~20 ms of host work -- reading and parsing the
+    // files, the four-corner poses -- before it needs the device: the runtime comes up on a helper thread meanwhile (the first
+    // HIP call of the calling thread waits for it inside the runtime).  With the runtime already up this is one thread start.
+    // (Asking for a kernel's attributes per translation unit on the same thread, to have the code objects loaded early as
+    // well, changed nothing: the first launches of a fresh process are not slow because of them.)
+    try {
+        (*out)->runtime_warmup = std::thread([device] {
+            if (hipSetDevice(device) == hipSuccess) (void)hipFree(nullptr);
+        });
+    } catch (...) {   // no thread: the first HIP call initialises, as before
+    }
     return VG_OK;
 }
 
