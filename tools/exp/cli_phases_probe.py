@@ -21,4 +21,6 @@ for i in range(runs):
     r = subprocess.run([exe, path], cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=env, timeout=600)
     t1 = time.clock_gettime(time.CLOCK_MONOTONIC)
     st = [l.split() for l in r.stderr.decode().splitlines() if l.startswith("calib clock:")]
+    for l in r.stderr.decode().splitlines():
+        if l.startswith("calib phases:"): print("   ", l)
     print("run %d rc=%d  " % (i, r.returncode) + "  ".join("%s %.3f" % (x[2], float(x[3])) for x in st) + "  parent_wait %.3f" % (t1 - t0))

@@ -64,6 +64,14 @@ int main(int argc, char **argv)
         if (vg_calibration_write_residuals(calib, i, name.c_str(), nullptr, nullptr) != VG_OK) return die(name.c_str());
     }
     stage("write_residuals");
+    if (std::getenv("VG_CALIB_CLOCK_T0")) {  // the library's own per-phase clock of this (cold) process beside the stages
+        vg_calibration_timings t;
+        if (vg_calibration_get_timings(calib, &t) == VG_OK)
+            std::fprintf(stderr, "calib phases: read %.4f parse %.4f geometric %.4f refine %.4f (kernel %.4f) global_init %.4f assemble %.4f "
+                         "solve %.4f readback %.4f residual_eval %.4f residual_format %.4f\n", t.read_files_s, t.parse_json_s,
+                         t.geometric_init_s, t.refine_total_s, t.refine_kernel_s, t.global_init_s, t.assemble_s, t.solve_s, t.readback_s,
+                         t.residual_eval_s, t.residual_format_s);
+    }
     vg_calibration_destroy(calib);
     stage("destroy");
     // everything this program produces is written and closed: leave without the HIP runtime's tear-down (35-100 ms of the
