@@ -199,7 +199,7 @@ void fill_emit_args(const vg_problem *p, const Dataset &d, vg::EmitArgs &a, int6
 namespace {
 long long g_debug_hooks[vgi::kHookCount] = {0};
 const char *const kDebugHookNames[vgi::kHookCount] = {"inline_chain_max_bytes", "gram_force_mfma", "gram_ch1", "gram_no_merge", "max_obs_per_launch",
-                                                      "solver_timing", "solver_host_loop", "solver_device_loop", "solver_no_speculation", "emit_equal_tiles", "schur_private_gather", "solver_event_wait", "solver_no_fold_frames", "solver_one_wave_fold", "solver_fold_max_groups", "emit_nt_min_bytes", "host_chunk_bytes", "gram_stamps"};
+                                                      "solver_timing", "solver_host_loop", "solver_device_loop", "solver_no_speculation", "emit_equal_tiles", "schur_private_gather", "solver_event_wait", "solver_no_fold_frames", "solver_one_wave_fold", "solver_fold_max_groups", "emit_nt_min_bytes", "host_chunk_bytes", "gram_stamps", "gram_persistent"};
 }  // namespace
 long long vgi::debug_hook(vgi::DebugHook h) { return g_debug_hooks[h]; }
 #endif

@@ -83,6 +83,51 @@ bool gram_inline_chain(const vg_problem *p, const Dataset &d)
     return !p->force_prepared_frames && gram_uses_valu(p, d) && d.L == 1 && d.status[0] == VG_TRANSFORM_DIRECT;
 }
 
+// The persistent form (vg_gram_valu_pers_kernel): a single DIRECT member walked in the kernel, blocks up to 13 wide, a board of
+// exactly 32 CH points (8 x 12), at least one full round of the one-shot kernel's workgroups.  n_wg_out = the workgroups it runs with
+// (= the number of partials it leaves), 0 = does not apply.
+template <int MODEL, int CH>
+unsigned int gram_pers_workgroups(const vg::GramValuArgs &a)
+{
+    constexpr int W = vg::CameraTraits<MODEL>::K + 7;
+    static unsigned int resident = 0;   // per instantiation; the device's properties do not change
+    if (!resident) {
+        int per_cu = 0, dev = 0;
+        hipDeviceProp_t prop;
+        constexpr size_t lds = vg::gram_valu_pers_lds_bytes<W, CH>();
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(vg::vg_gram_valu_pers_kernel<MODEL, CH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, vg::vg_gram_valu_pers_kernel<MODEL, CH>, vg::kValuThreads, lds) != hipSuccess ||
+            hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || per_cu < 1)
+            return 0;
+        resident = (unsigned int)per_cu * (unsigned int)prop.multiProcessorCount;
+    }
+    const long long hook = vgi::debug_hook(vgi::kHookGramPersistent);
+    if (hook == 1 || a.g.N != (unsigned)(vg::kValuLanesPerImage * CH)) return 0;   // one full chunk per image: the 8 x 12 board
+    const unsigned int n_pairs = (a.g.n_blocks + 1) / 2;
+    // by size: from four rounds of the one-shot kernel's octets on (16 384 images on 256 CUs), where it measures 3-7 % faster
+    // (20 k images 34.0 -> 32.9 us, 100 k 155 -> 149.5 us, with the partial sums 167 -> 156 us); at 10 k images the two tie, at
+    // 5 k the one-shot kernel wins by 20 % (profiles/r05z_gram_pers_probe2.txt)
+    if (hook != 2 && a.g.n_blocks < 32u * resident) return 0;
+    return n_pairs < resident ? n_pairs : resident;
+}
+
+template <int MODEL, int CH>
+int launch_gram_valu_pers(hipStream_t stream, const vg::GramValuArgs &a, unsigned int n_wg)
+{
+    constexpr int W = vg::CameraTraits<MODEL>::K + 7;
+    vg::GramValuArgs ap = a;
+    ap.n_wg = n_wg;
+    constexpr size_t lds = vg::gram_valu_pers_lds_bytes<W, CH>();
+    static bool raised = false;   // 67 KB of dynamic LDS: above the default limit
+    if (!raised) {
+        VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(vg::vg_gram_valu_pers_kernel<MODEL, CH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        raised = true;
+    }
+    hipLaunchKernelGGL((vg::vg_gram_valu_pers_kernel<MODEL, CH>), dim3(n_wg), dim3(vg::kValuThreads), lds, stream, ap, (a.g.n_blocks + 1) / 2);
+    VG_HIP(hipGetLastError());
+    return VG_OK;
+}
+
 template <int MODEL, int L, int CH>
 int launch_gram_valu_lch(hipStream_t stream, const vg::GramValuArgs &a, bool inline_chain)
 {
@@ -177,10 +222,26 @@ int vgi::gram_fused_at(vg_problem *p, int dataset_id, const double *d_params, do
             if (!d.d_wg_partials) VG_HIP(hipMalloc(&d.d_wg_partials, sizeof(double) * (size_t)E * a.n_wg));
             a.partials = d.d_wg_partials;
         }
-        switch (cam.model) {
-        case VG_MODEL_EUCM: rc = launch_gram_valu<vg::kEUCM>(p->stream, a, d.L, inl); break;
-        case VG_MODEL_UCM: rc = launch_gram_valu<vg::kUCM>(p->stream, a, d.L, inl); break;
-        default: rc = launch_gram_valu<vg::kMEI>(p->stream, a, d.L, inl); break;
+        unsigned int pers = 0;
+        if (inl && d.L == 1) {
+            switch (cam.model) {
+            case VG_MODEL_EUCM: pers = gram_pers_workgroups<vg::kEUCM, 3>(a); break;
+            case VG_MODEL_UCM: pers = gram_pers_workgroups<vg::kUCM, 3>(a); break;
+            default: break;   // Mei's 17-wide block: five entries per lane, no packed output table -- the one-shot kernel
+            }
+        }
+        if (pers) {
+            switch (cam.model) {
+            case VG_MODEL_EUCM: rc = launch_gram_valu_pers<vg::kEUCM, 3>(p->stream, a, pers); break;
+            default: rc = launch_gram_valu_pers<vg::kUCM, 3>(p->stream, a, pers); break;
+            }
+            a.n_wg = pers;
+        } else {
+            switch (cam.model) {
+            case VG_MODEL_EUCM: rc = launch_gram_valu<vg::kEUCM>(p->stream, a, d.L, inl); break;
+            case VG_MODEL_UCM: rc = launch_gram_valu<vg::kUCM>(p->stream, a, d.L, inl); break;
+            default: rc = launch_gram_valu<vg::kMEI>(p->stream, a, d.L, inl); break;
+            }
         }
         if (rc != VG_OK || !sum) return rc;
         hipLaunchKernelGGL(vg::vg_gram_partials_sum_kernel, dim3(E), dim3(256), 0, p->stream,

@@ -506,6 +506,191 @@ __global__ __launch_bounds__(kValuThreads, (valu_min_waves<MODEL, L, CH>())) voi
 }
 
 // ------------------------------------------------------------------------------------------
+// PERSISTENT form of the direct kernel for a single DIRECT member walked in the kernel and a board of exactly 32 CH points
+// (one full chunk per image: the 8 x 12 board of every BASELINE configuration): as many workgroups as are resident, each
+// owning a contiguous range of image PAIRS.  What it changes against one workgroup per octet:
+//   * the chain walk -- ~250 instructions that two lanes of every wave execute in the one-shot kernel, a sixth of the wave --
+//     runs ONCE per workgroup and chunk for up to 64 images, one image per lane of one wave, into LDS;
+//   * a wave takes its next pair from a counter in LDS as soon as it is done with one, so the waves of a SIMD drift apart
+//     instead of meeting at every round's start, and the head of a wave's life (parameter load -> walk) is paid once;
+//   * the observations of the NEXT pair travel from HBM straight into a wave-private LDS block (global_load_lds_dwordx4: no
+//     registers, the pair loop has none to spare) while the current pair is computed; the board is read from LDS;
+//   * the per-pair totals go to LDS BY PAIR INDEX and are added in pair order after the chunk, so the workgroup's partial does
+//     not depend on which wave took which pair (the order of every sum stays fixed).
+// ------------------------------------------------------------------------------------------
+constexpr int kPersChunkPairs = 32;   // pairs per chunk: 64 frames + 32 pair totals in LDS
+constexpr int kPersMaxCH = 3;
+
+// LDS: frames [64][FS] | pair totals [32][E] | board [32 CH][3] | staging [4 waves][2][CH][64 lanes] x 16 bytes | counter
+template <int W, int CH>
+__host__ __device__ constexpr size_t gram_valu_pers_lds_bytes()
+{
+    return sizeof(double) * (size_t)(2 * kPersChunkPairs * frame_stride(1) + kPersChunkPairs * (W * (W + 1) / 2) + 3 * 32 * CH +
+                                     (kValuThreads / kWave) * 2 * CH * kWave * 2) + 16;
+}
+
+// 16 bytes per lane from HBM into LDS at lds_addr + 16 * lane, without a register in between.  The compiler does not know this
+// load: the kernel waits for it itself (pers_wait_loads) before the data is read.
+__device__ __forceinline__ void pers_load_to_lds(const void *g, unsigned int lds_addr)
+{
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_addr) : "memory", "m0");
+}
+
+// the walk of one chunk: thread t of the walker wave derives the frame of image img0 + t.  NOT inlined: inside the kernel its
+// 64-bit constants and addresses were hoisted across the pair loop and spilled there (31 dwords); a call per chunk costs nothing.
+__device__ __attribute__((noinline)) void gram_pers_walk(const double *chain_params, const int *seq_index, long long chain_stride,
+                                                         unsigned int img0, unsigned int chunk_images, int walker, double *fr_lds)
+{
+    const int tid = threadIdx.x;
+    if ((tid >> 6) != walker) return;
+    const unsigned int t = (unsigned)(tid & 63);
+    if (t >= chunk_images) return;
+    const unsigned int b = img0 + t;
+    const long long si = seq_index ? (long long)seq_index[b] : (long long)b;
+    const double *xp = chain_params + chain_stride * si;
+    double xi_reg[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) xi_reg[k] = xp[k];
+    build_frame_single_direct_fast(xi_reg, fr_lds + t * frame_stride(1));
+}
+
+template <int MODEL, int CH>
+__global__ __launch_bounds__(kValuThreads, 2) void vg_gram_valu_pers_kernel(GramValuArgs a, unsigned int n_pairs)
+{
+    extern __shared__ __attribute__((aligned(16))) double valu_lds[];
+    using Rows = ValuRows<MODEL, 1, CH>;
+    using d2 = HIP_vector_type<double, 2>;
+    constexpr int K = Rows::K, W = Rows::W, E = Rows::E, FS = frame_stride(1);
+    constexpr int kOut = halved(E, 5);
+    static_assert(kOut <= 3 && W * W < 512, "packed output table");
+    static_assert(E <= kValuThreads, "one entry of the partial per thread");
+    static_assert(CH <= kPersMaxCH, "staging block");
+    double *fr_lds = valu_lds, *tot_lds = fr_lds + 2 * kPersChunkPairs * FS, *board_lds = tot_lds + kPersChunkPairs * E;
+    double *stage_lds = board_lds + 3 * 32 * CH;
+    int *counter = reinterpret_cast<int *>(stage_lds + (kValuThreads / kWave) * 2 * CH * kWave * 2);
+    if (gate_closed(a.g.gate, a.g.gate_expect)) return;
+
+    const unsigned int block = blockIdx.x, n_wg = gridDim.x;
+    // pairs [p_first, p_end) of this workgroup
+    const unsigned int p_first = (unsigned int)(((unsigned long long)block * n_pairs) / n_wg);
+    const unsigned int p_end = (unsigned int)(((unsigned long long)(block + 1) * n_pairs) / n_wg);
+    // the camera's intrinsics once, in front of every store of the kernel (re-read behind a store they would be per-lane
+    // vector loads in the pair loop)
+    double intr_r[K];
+#pragma unroll
+    for (int i = 0; i < K; i++) {   // into scalar registers: as vector registers they would be 2 K of the 256 the pair loop has
+        const double v = a.g.intr[i];
+        intr_r[i] = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+    }
+    for (int i = threadIdx.x; i < 3 * 32 * CH; i += kValuThreads) board_lds[i] = a.g.board[i];   // visible behind the first barrier
+
+    double wg_sum = 0.;   // thread e < E: entry e of the workgroup's partial, chunks added in order
+    // chunks of about equal size, a multiple of the four waves that share them (98 pairs: 28 + 28 + 28 + 14, not 32 + 32 + 32 + 2,
+    // and not 25 + 25 + 24 + 24 -- every chunk ends at a barrier, and 25 pairs are 7 + 6 + 6 + 6)
+    const unsigned int n_chunks = (p_end - p_first + kPersChunkPairs - 1) / kPersChunkPairs;
+    const unsigned int chunk_step = n_chunks ? (((p_end - p_first + n_chunks - 1) / n_chunks + 3u) & ~3u) : 4u;
+    unsigned int chunk_no = 0;
+    for (unsigned int pc = p_first; pc < p_end; pc += chunk_step, chunk_no++) {
+        const unsigned int chunk_pairs = p_end - pc < chunk_step ? p_end - pc : chunk_step;
+        const unsigned int img0 = 2 * pc;
+        const unsigned int chunk_images = a.g.n_blocks - img0 < 2 * chunk_pairs ? a.g.n_blocks - img0 : 2 * chunk_pairs;
+        // ---- the walk: one image per lane of ONE wave (a different one per workgroup and chunk, so that no SIMD of the CU
+        // carries all of them)
+        gram_pers_walk(a.chain_params, a.seq_index, a.chain_stride, img0, chunk_images, (int)((block + chunk_no) & 3u), fr_lds);
+        if (threadIdx.x == 0) *counter = 0;
+        __syncthreads();
+        // ---- pairs of the chunk, taken from the counter; the observations of a wave's NEXT pair are on their way while it
+        // computes the current one
+        {
+            int tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));   // nothing derived from the thread index is kept across the walk
+            const int lane = tid & (kWave - 1), wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+            const int sl = lane & (kValuLanesPerImage - 1), h = lane >> 5;
+            double *stage = stage_lds + (size_t)wave * (2 * CH * kWave * 2);
+            const unsigned int stage_addr = (unsigned int)(size_t)(__attribute__((address_space(3))) void *)stage;
+            const d2 *obs = reinterpret_cast<const d2 *>(a.g.obs);
+            auto claim = [&]() {
+                int u = 0;
+                if (lane == 0) u = atomicAdd(counter, 1);
+                return __builtin_amdgcn_readfirstlane(u);
+            };
+            auto request = [&](int u, int parity) {   // the CH observations of this lane's corners of pair u -> stage[parity]
+                const unsigned int li = 2u * (unsigned)u + (unsigned)h;
+                const unsigned int bb = li < chunk_images ? img0 + li : img0;
+#pragma unroll
+                for (int j = 0; j < CH; j++)
+                    pers_load_to_lds(obs + ((size_t)bb * a.g.N + (unsigned)(sl + kValuLanesPerImage * j)),
+                                     (unsigned int)__builtin_amdgcn_readfirstlane((int)(stage_addr + (unsigned)((parity * CH + j) * kWave * 16))));
+            };
+            int u = claim(), parity = 0;
+            if ((unsigned)u < chunk_pairs) {
+                request(u, 0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            while ((unsigned)u < chunk_pairs) {
+                const unsigned int li = 2u * (unsigned)u + (unsigned)h;
+                const unsigned int b = img0 + li;
+                const bool bvalid = li < chunk_images;
+                const unsigned long long lane_out = kLaneOutTable<W>.v[sl];
+                ValuChunkIn<CH> in;
+#pragma unroll
+                for (int j = 0; j < CH; j++) {
+                    in.ob[j] = reinterpret_cast<const d2 *>(stage)[(parity * CH + j) * kWave + lane];
+                    const int c = sl + kValuLanesPerImage * j;
+                    in.gb[j][0] = board_lds[3 * c];
+                    in.gb[j][1] = board_lds[3 * c + 1];
+                    in.gb[j][2] = board_lds[3 * c + 2];
+                    in.ragged[j] = !bvalid;
+                }
+                const int u_next = claim();
+                if ((unsigned)u_next < chunk_pairs) request(u_next, parity ^ 1);
+                const double *fr = fr_lds + (bvalid ? li : 0u) * FS;
+                double out[kOut];
+#pragma unroll
+                for (int k = 0; k < kOut; k++) out[k] = 0.;
+                valu_chunk<MODEL, 1, CH, kOut>(intr_r, fr, in, sl, out);
+                // the next pair's observations have had the whole pair to arrive: waiting HERE, in front of this pair's
+                // stores, is free -- at the head of the next pair the same wait would also wait for those stores
+                if constexpr (kOut == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(out[0]), "+v"(out[1]), "+v"(out[2])::"memory");
+                else if constexpr (kOut == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(out[0]), "+v"(out[1])::"memory");
+                else asm volatile("s_waitcnt vmcnt(0)" : "+v"(out[0])::"memory");
+                const int base = (int)((lane_out >> 54) & 0xff), real = (int)(lane_out >> 62);
+                double *G = a.g.gram + (size_t)(bvalid ? b : 0) * (W * W);
+#pragma unroll
+                for (int k = 0; k < kOut; k++) {
+                    const bool have = k < real;
+                    const unsigned int o_rc = (unsigned)(lane_out >> (18 * k)) & 0x1ff, o_cr = (unsigned)(lane_out >> (18 * k + 9)) & 0x1ff;
+                    if (have && bvalid) {
+                        G[o_rc] = out[k];
+                        G[o_cr] = out[k];
+                    }
+                    if (a.partials) {
+                        const double tot = out[k] + __shfl_xor(out[k], 32, kWave);
+                        if (have && lane < kValuLanesPerImage) tot_lds[u * E + base + k] = tot;
+                    }
+                }
+                u = u_next;
+                parity ^= 1;
+            }
+        }
+        __syncthreads();
+        if (a.partials) {
+            const int tid = threadIdx.x;
+            if (tid < E) {
+                double sc = tot_lds[tid];
+                for (unsigned int q = 1; q < chunk_pairs; q++) sc += tot_lds[q * E + tid];   // pair order
+                wg_sum = chunk_no == 0 ? sc : wg_sum + sc;
+            }
+        }
+        if (pc + chunk_step < p_end) __syncthreads();   // the next chunk's walk overwrites the frames and the totals
+    }
+    if (a.partials) {
+        const int tid = threadIdx.x;
+        if (tid < E) a.partials[(size_t)tid * n_wg + block] = (p_first < p_end) ? wg_sum : 0.;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Chains of TWO OR MORE members: the factored form.  InterJacobian::dpdxi (jacobian.h:155-171) gives for member l and a
 // corner with projection Jacobian row p and camera-frame point X
 //     J_l = [ p R12_l | ((-p) hat(X - t13_l)) M12_l ] = [ p | p hat(X) ] F_l ,   F_l = [ R12_l   hat(t13_l) M12_l ]   (6 x 6)
