@@ -208,9 +208,9 @@ def test_matrix_core_kernels_for_narrow_blocks(vg):
 
 # The persistent form of the direct kernel (vg_gram_valu_pers_kernel: resident workgroups, the chain walk once per workgroup
 # and chunk, pairs taken from a counter, per-pair totals added in pair order) against the one-shot kernel, through the hook
-# `gram_persistent` (1 = never, 2 = whenever it applies): the per-image blocks are the SAME arithmetic -- bit-identical --,
-# the sums differ by the order of additions only, and two runs of the persistent form give the same bits (which wave took
-# which pair must not show).
+# `gram_persistent` (1 = never, 2 / 3 = its four-wave / eight-wave shape whenever it applies): the per-image blocks are the SAME
+# arithmetic -- bit-identical --, the sums differ by the order of additions only, and two runs of a persistent shape give the
+# same bits (which wave took which pair must not show).
 @pytest.mark.parametrize("model,n_images,n_points", [("eucm", 41, None),      # 21 pairs, the last one half empty
                                                      ("ucm", 64, None),
                                                      ("eucm", 9, 100),        # ragged board: one full chunk + a 4-corner remainder
@@ -223,7 +223,7 @@ def test_persistent_direct_kernel_equals_the_one_shot_kernel(vg, model, n_images
     W = K + 7
     out = {}
     try:
-        for name, hook in (("one-shot", 1), ("persistent", 2), ("persistent again", 2)):
+        for name, hook in (("one-shot", 1), ("persistent", 2), ("persistent again", 2), ("eight waves", 3), ("eight waves again", 3)):
             capi.debug_set("gram_persistent", hook)
             gram, gsum = p.alloc_gram(ds)
             gram.fill_(float("nan"))
@@ -237,11 +237,15 @@ def test_persistent_direct_kernel_equals_the_one_shot_kernel(vg, model, n_images
     g0, s0 = out["one-shot"]
     g1, s1 = out["persistent"]
     g2, s2 = out["persistent again"]
+    g3, s3 = out["eight waves"]
+    g4, s4 = out["eight waves again"]
     assert g0.shape[0] == n_images and np.isfinite(g1).all() and np.isfinite(s1).all()
     assert np.array_equal(g0, g1), "per-image blocks must be bit-identical"
     assert np.array_equal(g1, g2) and np.array_equal(s1, s2), "the persistent form must not depend on which wave took which pair"
+    assert np.array_equal(g0, g3) and np.array_equal(g3, g4) and np.array_equal(s3, s4)
     scale = np.sqrt(np.abs(np.outer(np.diag(s0.reshape(W, W)), np.diag(s0.reshape(W, W)))))
     assert np.max(np.abs(s1.reshape(W, W) - s0.reshape(W, W)) / np.maximum(scale, 1e-300)) <= 1e-12
+    assert np.max(np.abs(s3.reshape(W, W) - s0.reshape(W, W)) / np.maximum(scale, 1e-300)) <= 1e-12
     if n_images <= 100:   # and both equal the long-double Gram of the oracle's rows
         pv = p.get_parameters()
         Gref = oracle_grams(model, status, board, corners, pv, 0, bases, strides, np.arange(n_images))

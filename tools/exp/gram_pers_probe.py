@@ -1,5 +1,5 @@
 """Persistent form of the direct Gram kernel against the one-shot kernel, same process, alternating through the hook
-`gram_persistent` (1 = never, 2 = whenever it applies).  usage: python tools/exp/gram_pers_probe.py [model] [images ...]"""
+`gram_persistent` (1 = never, 2 / 3 = the four- / eight-wave shape whenever it applies, 0 = the library's choice by size).  usage: python tools/exp/gram_pers_probe.py [model] [images ...]"""
 import os, sys, torch
 root = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 sys.path.insert(0, root)
@@ -32,7 +32,7 @@ for n in sizes:
         p.prepare(); p.gram_fused_sum(ds, gram, gsum)
     res = {}
     for rep in range(3):
-        for name, hook in (("one-shot", 1), ("persistent", 2)):
+        for name, hook in (("one-shot", 1), ("four waves", 2), ("eight waves", 3), ("by size", 0)):
             _capi.debug_set("gram_persistent", hook)
             res.setdefault(name, []).append((t(it_fused), t(it_sum)))
     _capi.debug_set("gram_persistent", 1); p.prepare(); p.gram_fused_sum(ds, gram, gsum)

@@ -84,48 +84,63 @@ bool gram_inline_chain(const vg_problem *p, const Dataset &d)
 }
 
 // The persistent form (vg_gram_valu_pers_kernel): a single DIRECT member walked in the kernel, blocks up to 13 wide, a board of
-// exactly 32 CH points (8 x 12), at least one full round of the one-shot kernel's workgroups.  n_wg_out = the workgroups it runs with
-// (= the number of partials it leaves), 0 = does not apply.
-template <int MODEL, int CH>
-unsigned int gram_pers_workgroups(const vg::GramValuArgs &a)
+// exactly 32 CH points (8 x 12), at least one full round of the one-shot kernel's workgroups.  Returns the workgroups it runs
+// with (= the number of partials it leaves; 0 = does not apply) and the shape (threads per workgroup).
+template <int MODEL, int CH, int THREADS>
+unsigned int gram_pers_resident()
 {
     constexpr int W = vg::CameraTraits<MODEL>::K + 7;
     static unsigned int resident = 0;   // per instantiation; the device's properties do not change
     if (!resident) {
         int per_cu = 0, dev = 0;
         hipDeviceProp_t prop;
-        constexpr size_t lds = vg::gram_valu_pers_lds_bytes<W, CH>();
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(vg::vg_gram_valu_pers_kernel<MODEL, CH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, vg::vg_gram_valu_pers_kernel<MODEL, CH>, vg::kValuThreads, lds) != hipSuccess ||
+        constexpr size_t lds = vg::gram_valu_pers_lds_bytes<W, CH, THREADS>();
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(vg::vg_gram_valu_pers_kernel<MODEL, CH, THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, vg::vg_gram_valu_pers_kernel<MODEL, CH, THREADS>, THREADS, lds) != hipSuccess ||
             hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || per_cu < 1)
             return 0;
         resident = (unsigned int)per_cu * (unsigned int)prop.multiProcessorCount;
     }
+    return resident;
+}
+
+// which shape, by size: none below 4 096 images (less than a round of the one-shot kernel's octets), the eight-wave shape up to
+// 16 384, the four-wave shape beyond (profiles/r05z_gram_pers_probe5.txt; NOTES).  hook gram_persistent: 1 = never,
+// 2 = the four-wave shape whenever it applies, 3 = the eight-wave shape whenever it applies
+template <int CH>
+int gram_pers_shape(const vg::GramValuArgs &a, bool with_sum)
+{
     const long long hook = vgi::debug_hook(vgi::kHookGramPersistent);
-    if (hook == 1 || a.g.N != (unsigned)(vg::kValuLanesPerImage * CH)) return 0;   // one full chunk per image: the 8 x 12 board
-    const unsigned int n_pairs = (a.g.n_blocks + 1) / 2;
-    // by size: from four rounds of the one-shot kernel's octets on (16 384 images on 256 CUs), where it measures 3-7 % faster
-    // (20 k images 34.0 -> 32.9 us, 100 k 155 -> 149.5 us, with the partial sums 167 -> 156 us); at 10 k images the two tie, at
-    // 5 k the one-shot kernel wins by 20 % (profiles/r05z_gram_pers_probe2.txt)
-    if (hook != 2 && a.g.n_blocks < 32u * resident) return 0;
-    return n_pairs < resident ? n_pairs : resident;
+    if (hook == 1 || a.g.N != (unsigned)(vg::kValuLanesPerImage * CH) || a.g.n_blocks < 2) return 0;   // one full chunk per image: the 8 x 12 board
+    if (hook == 2) return vg::kPersThreadsLong;
+    if (hook == 3) return vg::kPersThreadsShort;
+    if (a.g.n_blocks >= 16384u) return vg::kPersThreadsLong;
+    // below: the eight-wave shape ties with the one-shot kernel as a launch (10 k images: 19.2 / 19.0 us) and wins through the 256
+    // partials it leaves for the sum (22.7 -> 21.75 us): only when the sum is asked for
+    return (with_sum && a.g.n_blocks >= 4096u) ? vg::kPersThreadsShort : 0;
+}
+
+template <int MODEL, int CH, int THREADS>
+int launch_gram_valu_pers(hipStream_t stream, const vg::GramValuArgs &a, unsigned int *n_wg_out)
+{
+    constexpr int W = vg::CameraTraits<MODEL>::K + 7;
+    const unsigned int resident = gram_pers_resident<MODEL, CH, THREADS>();
+    if (!resident) return fail(VG_ERR_HIP, "occupancy query of the persistent Gram kernel failed");
+    const unsigned int n_pairs = (a.g.n_blocks + 1) / 2, n_wg = n_pairs < resident ? n_pairs : resident;
+    vg::GramValuArgs ap = a;
+    ap.n_wg = n_wg;
+    constexpr size_t lds = vg::gram_valu_pers_lds_bytes<W, CH, THREADS>();
+    hipLaunchKernelGGL((vg::vg_gram_valu_pers_kernel<MODEL, CH, THREADS>), dim3(n_wg), dim3(THREADS), lds, stream, ap, n_pairs);
+    VG_HIP(hipGetLastError());
+    *n_wg_out = n_wg;
+    return VG_OK;
 }
 
 template <int MODEL, int CH>
-int launch_gram_valu_pers(hipStream_t stream, const vg::GramValuArgs &a, unsigned int n_wg)
+int launch_gram_valu_pers_shape(hipStream_t stream, const vg::GramValuArgs &a, int shape, unsigned int *n_wg_out)
 {
-    constexpr int W = vg::CameraTraits<MODEL>::K + 7;
-    vg::GramValuArgs ap = a;
-    ap.n_wg = n_wg;
-    constexpr size_t lds = vg::gram_valu_pers_lds_bytes<W, CH>();
-    static bool raised = false;   // 67 KB of dynamic LDS: above the default limit
-    if (!raised) {
-        VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(vg::vg_gram_valu_pers_kernel<MODEL, CH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        raised = true;
-    }
-    hipLaunchKernelGGL((vg::vg_gram_valu_pers_kernel<MODEL, CH>), dim3(n_wg), dim3(vg::kValuThreads), lds, stream, ap, (a.g.n_blocks + 1) / 2);
-    VG_HIP(hipGetLastError());
-    return VG_OK;
+    return shape == vg::kPersThreadsShort ? launch_gram_valu_pers<MODEL, CH, vg::kPersThreadsShort>(stream, a, n_wg_out)
+                                          : launch_gram_valu_pers<MODEL, CH, vg::kPersThreadsLong>(stream, a, n_wg_out);
 }
 
 template <int MODEL, int L, int CH>
@@ -219,23 +234,18 @@ int vgi::gram_fused_at(vg_problem *p, int dataset_id, const double *d_params, do
         a.partials = nullptr;
         const int E = W * (W + 1) / 2;
         if (sum) {
-            if (!d.d_wg_partials) VG_HIP(hipMalloc(&d.d_wg_partials, sizeof(double) * (size_t)E * a.n_wg));
+            // room for either kernel's partials: one per octet (one-shot), one per resident workgroup (persistent: at most one per
+            // image pair and never more than 1 024)
+            const size_t n_pairs = ((size_t)d.n_blocks + 1) / 2, n_part = std::max<size_t>(a.n_wg, std::min<size_t>(n_pairs, 1024));
+            if (!d.d_wg_partials) VG_HIP(hipMalloc(&d.d_wg_partials, sizeof(double) * (size_t)E * n_part));
             a.partials = d.d_wg_partials;
         }
-        unsigned int pers = 0;
-        if (inl && d.L == 1) {
-            switch (cam.model) {
-            case VG_MODEL_EUCM: pers = gram_pers_workgroups<vg::kEUCM, 3>(a); break;
-            case VG_MODEL_UCM: pers = gram_pers_workgroups<vg::kUCM, 3>(a); break;
-            default: break;   // Mei's 17-wide block: five entries per lane, no packed output table -- the one-shot kernel
-            }
-        }
+        const int pers = (inl && d.L == 1 && cam.model != VG_MODEL_MEI) ? gram_pers_shape<3>(a, sum != nullptr) : 0;   // Mei's 17-wide block: five entries per lane, no packed output table
         if (pers) {
-            switch (cam.model) {
-            case VG_MODEL_EUCM: rc = launch_gram_valu_pers<vg::kEUCM, 3>(p->stream, a, pers); break;
-            default: rc = launch_gram_valu_pers<vg::kUCM, 3>(p->stream, a, pers); break;
-            }
-            a.n_wg = pers;
+            unsigned int n_wg = 0;
+            rc = cam.model == VG_MODEL_EUCM ? launch_gram_valu_pers_shape<vg::kEUCM, 3>(p->stream, a, pers, &n_wg)
+                                            : launch_gram_valu_pers_shape<vg::kUCM, 3>(p->stream, a, pers, &n_wg);
+            a.n_wg = n_wg;
         } else {
             switch (cam.model) {
             case VG_MODEL_EUCM: rc = launch_gram_valu<vg::kEUCM>(p->stream, a, d.L, inl); break;
@@ -371,7 +381,8 @@ int vg_problem_gram_fused_sum(vg_problem *p, double *const *grams, double *const
         if (!d.n_blocks || d.n_blocks > 0x7fffffff) continue;
         const int W = p->cams[d.camera].K + 6 * d.L + 1, E = W * (W + 1) / 2;
         const size_t n_wg = (size_t)((d.n_blocks + vg::kValuImagesPerBlock - 1) / vg::kValuImagesPerBlock);
-        if (!d.d_wg_partials) VG_HIP(hipMalloc(&d.d_wg_partials, sizeof(double) * (size_t)E * n_wg));
+        const size_t n_pairs = ((size_t)d.n_blocks + 1) / 2, n_part = std::max<size_t>(n_wg, std::min<size_t>(n_pairs, 1024));   // as in gram_fused_at: the buffer is shared
+        if (!d.d_wg_partials) VG_HIP(hipMalloc(&d.d_wg_partials, sizeof(double) * (size_t)E * n_part));
         parts[(size_t)i] = d.d_wg_partials;
     }
     std::vector<char> taken;

@@ -511,8 +511,8 @@ __global__ __launch_bounds__(kValuThreads, (valu_min_waves<MODEL, L, CH>())) voi
 // owning a contiguous range of image PAIRS.  What it changes against one workgroup per octet:
 //   * the chain walk -- ~250 instructions that two lanes of every wave execute in the one-shot kernel, a sixth of the wave --
 //     runs ONCE per workgroup and chunk for up to 64 images, one image per lane of one wave, into LDS;
-//   * a wave takes its next pair from a counter in LDS as soon as it is done with one, so the waves of a SIMD drift apart
-//     instead of meeting at every round's start, and the head of a wave's life (parameter load -> walk) is paid once;
+//   * a wave takes its next pair from a counter in LDS as soon as it is done with one (one counter per SIMD of the CU, see
+//     kPersThreads), and the head of a wave's life (parameter load -> walk) is paid once;
 //   * the observations of the NEXT pair travel from HBM straight into a wave-private LDS block (global_load_lds_dwordx4: no
 //     registers, the pair loop has none to spare) while the current pair is computed; the board is read from LDS;
 //   * the per-pair totals go to LDS BY PAIR INDEX and are added in pair order after the chunk, so the workgroup's partial does
@@ -520,13 +520,22 @@ __global__ __launch_bounds__(kValuThreads, (valu_min_waves<MODEL, L, CH>())) voi
 // ------------------------------------------------------------------------------------------
 constexpr int kPersChunkPairs = 32;   // pairs per chunk: 64 frames + 32 pair totals in LDS
 constexpr int kPersMaxCH = 3;
+// Two shapes of the same kernel (THREADS):
+//   256  two workgroups of four waves per CU, ONE pair counter per workgroup -- fewer waves at a chunk's barrier: the better
+//        shape for long ranges (from 16 384 images on: 20 k images 34.0 -> 32.9 us, 100 k 155 -> 149.5 us);
+//   512  ONE workgroup of eight waves per CU (two per SIMD, the register budget of the one-shot kernel); the pairs of a chunk are
+//        cut into four ranges, one per SIMD, and the two waves of a SIMD (they read their SIMD from the hardware id) take pairs
+//        from their range's counter first and from the others' only when it is empty -- with a few pairs per wave (5 k - 16 k
+//        images) the workgroup evens out what two blind workgroups per CU cannot, and the launch leaves 256 partials to add
+//        instead of 1 250 (10 k images: kernel 19.0 / 19.1 us, with the sum 22.6 -> 21.6 us; 5 k: 12.4 -> 12.25).
+constexpr int kPersThreadsLong = 256, kPersThreadsShort = 512;
 
-// LDS: frames [64][FS] | pair totals [32][E] | board [32 CH][3] | staging [4 waves][2][CH][64 lanes] x 16 bytes | counter
-template <int W, int CH>
+// LDS: frames [64][FS] | pair totals [32][E] | board [32 CH][3] | staging [waves][2][CH][64 lanes] x 16 bytes | 4 counters
+template <int W, int CH, int THREADS>
 __host__ __device__ constexpr size_t gram_valu_pers_lds_bytes()
 {
     return sizeof(double) * (size_t)(2 * kPersChunkPairs * frame_stride(1) + kPersChunkPairs * (W * (W + 1) / 2) + 3 * 32 * CH +
-                                     (kValuThreads / kWave) * 2 * CH * kWave * 2) + 16;
+                                     (THREADS / kWave) * 2 * CH * kWave * 2) + 32;
 }
 
 // 16 bytes per lane from HBM into LDS at lds_addr + 16 * lane, without a register in between.  The compiler does not know this
@@ -554,20 +563,21 @@ __device__ __attribute__((noinline)) void gram_pers_walk(const double *chain_par
     build_frame_single_direct_fast(xi_reg, fr_lds + t * frame_stride(1));
 }
 
-template <int MODEL, int CH>
-__global__ __launch_bounds__(kValuThreads, 2) void vg_gram_valu_pers_kernel(GramValuArgs a, unsigned int n_pairs)
+template <int MODEL, int CH, int THREADS>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void vg_gram_valu_pers_kernel(GramValuArgs a, unsigned int n_pairs)
 {
+    constexpr int kPersThreads = THREADS, kPersWaves = THREADS / kWave, kRanges = THREADS == kPersThreadsShort ? 4 : 1;
     extern __shared__ __attribute__((aligned(16))) double valu_lds[];
     using Rows = ValuRows<MODEL, 1, CH>;
     using d2 = HIP_vector_type<double, 2>;
     constexpr int K = Rows::K, W = Rows::W, E = Rows::E, FS = frame_stride(1);
     constexpr int kOut = halved(E, 5);
     static_assert(kOut <= 3 && W * W < 512, "packed output table");
-    static_assert(E <= kValuThreads, "one entry of the partial per thread");
+    static_assert(E <= kPersThreads, "one entry of the partial per thread");
     static_assert(CH <= kPersMaxCH, "staging block");
     double *fr_lds = valu_lds, *tot_lds = fr_lds + 2 * kPersChunkPairs * FS, *board_lds = tot_lds + kPersChunkPairs * E;
     double *stage_lds = board_lds + 3 * 32 * CH;
-    int *counter = reinterpret_cast<int *>(stage_lds + (kValuThreads / kWave) * 2 * CH * kWave * 2);
+    int *counter = reinterpret_cast<int *>(stage_lds + kPersWaves * 2 * CH * kWave * 2);   // [4]: next pair of each SIMD's range
     if (gate_closed(a.g.gate, a.g.gate_expect)) return;
 
     const unsigned int block = blockIdx.x, n_wg = gridDim.x;
@@ -582,13 +592,12 @@ __global__ __launch_bounds__(kValuThreads, 2) void vg_gram_valu_pers_kernel(Gram
         const double v = a.g.intr[i];
         intr_r[i] = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
     }
-    for (int i = threadIdx.x; i < 3 * 32 * CH; i += kValuThreads) board_lds[i] = a.g.board[i];   // visible behind the first barrier
+    for (int i = threadIdx.x; i < 3 * 32 * CH; i += kPersThreads) board_lds[i] = a.g.board[i];   // visible behind the first barrier
 
     double wg_sum = 0.;   // thread e < E: entry e of the workgroup's partial, chunks added in order
-    // chunks of about equal size, a multiple of the four waves that share them (98 pairs: 28 + 28 + 28 + 14, not 32 + 32 + 32 + 2,
-    // and not 25 + 25 + 24 + 24 -- every chunk ends at a barrier, and 25 pairs are 7 + 6 + 6 + 6)
+    // chunks of about equal size, a multiple of the waves that share them (every chunk ends at a barrier)
     const unsigned int n_chunks = (p_end - p_first + kPersChunkPairs - 1) / kPersChunkPairs;
-    const unsigned int chunk_step = n_chunks ? (((p_end - p_first + n_chunks - 1) / n_chunks + 3u) & ~3u) : 4u;
+    const unsigned int chunk_step = n_chunks ? (((p_end - p_first + n_chunks - 1) / n_chunks + (unsigned)kPersWaves - 1u) & ~((unsigned)kPersWaves - 1u)) : (unsigned)kPersWaves;
     unsigned int chunk_no = 0;
     for (unsigned int pc = p_first; pc < p_end; pc += chunk_step, chunk_no++) {
         const unsigned int chunk_pairs = p_end - pc < chunk_step ? p_end - pc : chunk_step;
@@ -596,8 +605,8 @@ __global__ __launch_bounds__(kValuThreads, 2) void vg_gram_valu_pers_kernel(Gram
         const unsigned int chunk_images = a.g.n_blocks - img0 < 2 * chunk_pairs ? a.g.n_blocks - img0 : 2 * chunk_pairs;
         // ---- the walk: one image per lane of ONE wave (a different one per workgroup and chunk, so that no SIMD of the CU
         // carries all of them)
-        gram_pers_walk(a.chain_params, a.seq_index, a.chain_stride, img0, chunk_images, (int)((block + chunk_no) & 3u), fr_lds);
-        if (threadIdx.x == 0) *counter = 0;
+        gram_pers_walk(a.chain_params, a.seq_index, a.chain_stride, img0, chunk_images, (int)((block + chunk_no) & (unsigned)(kPersWaves - 1)), fr_lds);
+        if (threadIdx.x < 4) counter[threadIdx.x] = 0;
         __syncthreads();
         // ---- pairs of the chunk, taken from the counter; the observations of a wave's NEXT pair are on their way while it
         // computes the current one
@@ -609,10 +618,24 @@ __global__ __launch_bounds__(kValuThreads, 2) void vg_gram_valu_pers_kernel(Gram
             double *stage = stage_lds + (size_t)wave * (2 * CH * kWave * 2);
             const unsigned int stage_addr = (unsigned int)(size_t)(__attribute__((address_space(3))) void *)stage;
             const d2 *obs = reinterpret_cast<const d2 *>(a.g.obs);
-            auto claim = [&]() {
-                int u = 0;
-                if (lane == 0) u = atomicAdd(counter, 1);
-                return __builtin_amdgcn_readfirstlane(u);
+            // pairs [range_first(s), range_first(s + 1)) of the chunk belong to SIMD s (one range = the whole chunk: kRanges == 1)
+            const int simd = kRanges == 1 ? 0 : (int)((__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4)) & 3u);   // HW_ID bits 5:4
+            auto range_first = [&](int r) { return (unsigned int)(((unsigned long long)chunk_pairs * (unsigned)r) / (unsigned)kRanges); };
+            auto claim = [&]() {   // next pair of this wave's SIMD, then of the others'; chunk_pairs = none left
+                int u = (int)chunk_pairs;
+#pragma unroll
+                for (int q = 0; q < kRanges; q++) {
+                    const int r = (simd + q) & (kRanges - 1);
+                    const unsigned int first = range_first(r), end = range_first(r + 1);
+                    int t = 0;
+                    if (lane == 0) t = atomicAdd(counter + r, 1);
+                    t = __builtin_amdgcn_readfirstlane(t);
+                    if (first + (unsigned)t < end) {
+                        u = (int)(first + (unsigned)t);
+                        break;
+                    }
+                }
+                return u;
             };
             auto request = [&](int u, int parity) {   // the CH observations of this lane's corners of pair u -> stage[parity]
                 const unsigned int li = 2u * (unsigned)u + (unsigned)h;

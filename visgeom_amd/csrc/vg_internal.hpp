@@ -39,7 +39,7 @@ enum DebugHook {
     kHookEmitNtMinBytes,           // smallest launch output (bytes) written with non-temporal stores (0 = the default; 1 = always; a huge value = never)
     kHookHostChunkBytes,           // chunk size of vg_dataset_evaluate_to_host in bytes (0 = the default, 32 MiB): tests force many small chunks
     kHookGramStamps,               // measurement build (-DVG_GRAM_STAMPS) only: device address of the per-wave clock stamps of the Gram kernel
-    kHookGramPersistent,           // persistent form of the direct Gram kernel (vg_gram_valu_pers_kernel): 1 = never, 2 = whenever it applies, 0 = by size
+    kHookGramPersistent,           // persistent form of the direct Gram kernel (vg_gram_valu_pers_kernel): 1 = never, 2 / 3 = its four- / eight-wave shape whenever it applies, 0 = by size
     kHookCount
 };
 #ifdef VG_DEBUG_HOOKS
