@@ -10,6 +10,9 @@ from visgeom_amd import synthetic as S
 from visgeom_amd import capi as _capi  # noqa: E402
 
 _capi.hooks_from_env()  # legacy VG_* switches -> vg_debug_set
+if os.environ.get("AB_LIB"):   # an A/B library (python -m visgeom_amd._build --variant NAME -DFLAG)
+    from visgeom_amd import _build
+    _build.LIB = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), os.environ["AB_LIB"])
 from visgeom_amd.problem import CalibrationProblem
 
 model = sys.argv[1] if len(sys.argv) > 1 else "eucm"
