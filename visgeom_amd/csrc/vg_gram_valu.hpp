@@ -579,6 +579,20 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
     double *stage_lds = board_lds + 3 * 32 * CH;
     int *counter = reinterpret_cast<int *>(stage_lds + kPersWaves * 2 * CH * kWave * 2);   // [4]: next pair of each SIMD's range
     if (gate_closed(a.g.gate, a.g.gate_expect)) return;
+#ifdef VG_GRAM_STAMPS   // measurement build (tools/exp/gram_pers_stamps_probe.py): 16 wall-clock stamps (100 MHz) per wave -- 0 entry,
+                        // 1 walk + barrier done, 2 first pair's observations in LDS, 3..9 end of every pair (its stores issued); inside a
+                        // wave's FIRST pair: 10 inputs read + next pair requested, 11 rows / products / tree done, 12 the wait passed;
+                        // 13 shader-clock cycles of rows / products / tree (first pair: low word, second: high word); 14 chunk barrier
+                        // passed, 15 end
+    unsigned long long *pstamps = a.g.res ? reinterpret_cast<unsigned long long *>(const_cast<double *>(a.g.res)) + ((size_t)blockIdx.x * (THREADS / kWave) + (threadIdx.x >> 6)) * 16 : nullptr;
+    int pstamp_unit = 3;
+#define VG_PSTAMP(i) do { if (pstamps && (threadIdx.x & 63) == 0) pstamps[i] = wall_clock64(); } while (0)
+    if (pstamps && (threadIdx.x & 63) == 0)   // the per-pair slots of an earlier launch of a train must not survive
+        for (int i = 3; i < 14; i++) pstamps[i] = 0ull;
+#else
+#define VG_PSTAMP(i) do { } while (0)
+#endif
+    VG_PSTAMP(0);
 
     const unsigned int block = blockIdx.x, n_wg = gridDim.x;
     // pairs [p_first, p_end) of this workgroup
@@ -608,6 +622,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
         gram_pers_walk(a.chain_params, a.seq_index, a.chain_stride, img0, chunk_images, (int)((block + chunk_no) & (unsigned)(kPersWaves - 1)), fr_lds);
         if (threadIdx.x < 4) counter[threadIdx.x] = 0;
         __syncthreads();
+        VG_PSTAMP(1);
         // ---- pairs of the chunk, taken from the counter; the observations of a wave's NEXT pair are on their way while it
         // computes the current one
         {
@@ -650,6 +665,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 request(u, 0);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
+            VG_PSTAMP(2);
             while ((unsigned)u < chunk_pairs) {
                 const unsigned int li = 2u * (unsigned)u + (unsigned)h;
                 const unsigned int b = img0 + li;
@@ -671,12 +687,31 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 double out[kOut];
 #pragma unroll
                 for (int k = 0; k < kOut; k++) out[k] = 0.;
+#ifdef VG_GRAM_STAMPS
+                unsigned long long cyc0 = 0;
+                if (pstamp_unit <= 4) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (pstamp_unit == 3) VG_PSTAMP(10);
+                    cyc0 = __builtin_readcyclecounter();
+                }
+#endif
                 valu_chunk<MODEL, 1, CH, kOut>(intr_r, fr, in, sl, out);
+#ifdef VG_GRAM_STAMPS
+                if (pstamp_unit <= 4) {
+                    asm volatile("" : "+v"(out[0]));
+                    const unsigned long long dc = __builtin_readcyclecounter() - cyc0;
+                    if (pstamp_unit == 3) VG_PSTAMP(11);
+                    if (pstamps && (threadIdx.x & 63) == 0) pstamps[13] = pstamp_unit == 3 ? (dc & 0xffffffffull) : (pstamps[13] | (dc << 32));
+                }
+#endif
                 // the next pair's observations have had the whole pair to arrive: waiting HERE, in front of this pair's
                 // stores, is free -- at the head of the next pair the same wait would also wait for those stores
                 if constexpr (kOut == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(out[0]), "+v"(out[1]), "+v"(out[2])::"memory");
                 else if constexpr (kOut == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(out[0]), "+v"(out[1])::"memory");
                 else asm volatile("s_waitcnt vmcnt(0)" : "+v"(out[0])::"memory");
+#ifdef VG_GRAM_STAMPS
+                if (pstamp_unit == 3) VG_PSTAMP(12);
+#endif
                 const int base = (int)((lane_out >> 54) & 0xff), real = (int)(lane_out >> 62);
                 double *G = a.g.gram + (size_t)(bvalid ? b : 0) * (W * W);
 #pragma unroll
@@ -694,9 +729,13 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 }
                 u = u_next;
                 parity ^= 1;
+#ifdef VG_GRAM_STAMPS
+                if (pstamp_unit < 10) { VG_PSTAMP(pstamp_unit); pstamp_unit++; }
+#endif
             }
         }
         __syncthreads();
+        VG_PSTAMP(14);
         if (a.partials) {
             const int tid = threadIdx.x;
             if (tid < E) {
@@ -711,6 +750,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
         const int tid = threadIdx.x;
         if (tid < E) a.partials[(size_t)tid * n_wg + block] = (p_first < p_end) ? wg_sum : 0.;
     }
+    VG_PSTAMP(15);
+#undef VG_PSTAMP
 }
 
 // ------------------------------------------------------------------------------------------
