@@ -631,6 +631,27 @@ def main():
                        "gram_flops_per_obs": 2 * (K + 7) * (K + 8), "eval_flops_per_obs": EVAL_FLOPS[a.model],
                        "avg_launch_ms": gram_ms, "achieved": ach, "peak": FP64_PEAK, "unit": "TFLOP/s",
                        "frac": ach / FP64_PEAK}
+    # what the FP64 pipe delivers on THIS box at the Gram kernels' occupancy (dependent-FMA chains, no memory): the same role as
+    # measured_stream_write_GBps beside the HBM peak -- `frac` stays priced against the guide's 78.6 TFLOP/s
+    try:
+        fl = ctypes.c_int64(0)
+        scratch = torch.zeros(4096, dtype=torch.float64, device="cuda")
+        fma = lambda: capi.check(L.vg_calib_fp64_fma(sp, ctypes.c_void_p(scratch.data_ptr()), 20000, ctypes.byref(fl)))
+        for _ in range(3):
+            fma()
+        torch.cuda.synchronize()
+        f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        f0.record(stream)
+        for _ in range(10):
+            fma()
+        f1.record(stream)
+        torch.cuda.synchronize()
+        fma_tf = fl.value * 10 / (f0.elapsed_time(f1) * 1e-3) / 1e12
+        jtj["roofline"]["measured_fp64_fma_TFLOPs"] = fma_tf
+        jtj["roofline"]["frac_of_measured_fma_rate"] = ach / fma_tf
+    except Exception as e:  # a measurement helper must not take the line down
+        jtj["roofline"]["measured_fp64_fma_TFLOPs"] = None
+        jtj["roofline"]["measured_fp64_fma_error"] = str(e)[:200]
 
     # ---- BASELINE.json config 4, the north-star multi-GPU case: Mei (K = 10), 10 000 images x 96 corners IN TOTAL,
     # images sharded over the ranks (strong scaling).  One LM-style iteration = chain prep + fused evaluate + Gram of

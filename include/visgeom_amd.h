@@ -546,6 +546,10 @@ int vg_debug_set(const char *name, long long value);
  * and to measure the achievable HBM rate on the box. */
 int vg_calib_stream_write(void *hip_stream, double *dst, int64_t n_doubles, double value);
 int vg_calib_stream_copy(void *hip_stream, double *dst, const double *src, int64_t n_doubles);
+/* what the FP64 vector pipe delivers on this box at the occupancy of the fused Gram kernels (two waves per SIMD): one launch of
+ * dependent-FMA chains (eight per lane, `iters` FMAs each) on `hip_stream`; *flops_out = the launch's flop count.  `scratch`:
+ * any device buffer of at least 2 x (number of CUs) doubles (never written in practice).  The caller times the launch. */
+int vg_calib_fp64_fma(void *hip_stream, double *scratch, int iters, int64_t *flops_out);
 /* the bus ceiling of the host-memory route on this box: `reps` blocking hipMemcpy device -> hipHostMalloc memory of `bytes`
  * bytes each (buffers allocated and touched first); seconds_out[reps] receives the duration of every copy. */
 int vg_calib_d2h_copies(int device, int64_t bytes, int reps, double *seconds_out);

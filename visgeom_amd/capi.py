@@ -179,6 +179,7 @@ SIGNATURES = {
     "vg_calib_stream_write": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_double]),
     "vg_calib_stream_copy": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64]),
     "vg_calib_d2h_copies": (ctypes.c_int, [ctypes.c_int, ctypes.c_int64, ctypes.c_int, _dp]),
+    "vg_calib_fp64_fma": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int64)]),
 }
 
 

@@ -1147,6 +1147,26 @@ int vg_calib_stream_write(void *hip_stream, double *dst, int64_t n_doubles, doub
     return VG_OK;
 }
 
+int vg_calib_fp64_fma(void *hip_stream, double *scratch, int iters, int64_t *flops_out)
+{
+    if (!scratch || iters < 1 || !flops_out) return fail(VG_ERR_INVALID_ARGUMENT, "scratch / iters / flops_out");
+    int dev = 0;
+    hipDeviceProp_t prop;
+    VG_HIP(hipGetDevice(&dev));
+    VG_HIP(hipGetDeviceProperties(&prop, dev));
+    const size_t lds = 72 * 1024;   // two workgroups of four waves per CU = two waves per SIMD: the fused Gram kernels' occupancy
+    static bool raised = false;
+    if (!raised) {
+        VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(vg::vg_fp64_fma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        raised = true;
+    }
+    const unsigned int grid = 2u * (unsigned int)prop.multiProcessorCount;
+    hipLaunchKernelGGL(vg::vg_fp64_fma_kernel, dim3(grid), dim3(256), lds, reinterpret_cast<hipStream_t>(hip_stream), scratch, iters, 1.0);
+    VG_HIP(hipGetLastError());
+    *flops_out = (int64_t)grid * 256 * (int64_t)iters * vg::kFmaChains * 2;
+    return VG_OK;
+}
+
 int vg_calib_d2h_copies(int device, int64_t bytes, int reps, double *seconds_out)
 {
     if (bytes <= 0 || reps <= 0 || !seconds_out) return fail(VG_ERR_INVALID_ARGUMENT, "bad arguments");

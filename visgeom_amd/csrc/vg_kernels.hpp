@@ -467,4 +467,31 @@ __global__ __launch_bounds__(256) void vg_stream_copy_kernel(double *__restrict_
 }
 #endif
 
+// What the FP64 vector pipe delivers on this box under the occupancy of the fused Gram kernels (two waves per SIMD: 256-thread
+// workgroups, two per CU by their LDS reservation): every lane runs kFmaChains independent chains of dependent v_fma_f64 -- no
+// memory, a loop of a few hundred bytes.  The guide's 78.6 TFLOP/s assume 2.4 GHz; under this load the part runs lower
+// (profiles/NOTES.md, tools/exp/fp64_ramp.hip), and bench.py prints this next to the Gram kernel's roofline fraction.
+constexpr int kFmaChains = 8;
+#ifdef VG_TU_CORE  // this kernel is launched by one translation unit only; the others see the header without it
+__global__ __launch_bounds__(256) void vg_fp64_fma_kernel(double *__restrict__ out, int iters, double seed)
+{
+    extern __shared__ double fma_pad[];   // reserves the LDS that limits a CU to two workgroups; never touched
+    double x[kFmaChains];
+#pragma unroll
+    for (int i = 0; i < kFmaChains; i++) x[i] = seed + 1e-3 * i + 1e-9 * threadIdx.x;
+    const double a = 1.0000001, b = 1e-9;
+#pragma unroll 4
+    for (int k = 0; k < iters; k++)
+#pragma unroll
+        for (int i = 0; i < kFmaChains; i++) x[i] = __builtin_fma(x[i], a, b);
+    double t = 0.;
+#pragma unroll
+    for (int i = 0; i < kFmaChains; i++) t += x[i];
+    if (t == 12345.678) {   // never: keeps the chains alive
+        fma_pad[threadIdx.x] = t;
+        out[blockIdx.x] = fma_pad[threadIdx.x ^ 1];
+    }
+}
+#endif
+
 }  // namespace vg
