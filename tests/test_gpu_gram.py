@@ -214,7 +214,9 @@ def test_matrix_core_kernels_for_narrow_blocks(vg):
 @pytest.mark.parametrize("model,n_images,n_points", [("eucm", 41, None),      # 21 pairs, the last one half empty
                                                      ("ucm", 64, None),
                                                      ("eucm", 9, 100),        # ragged board: one full chunk + a 4-corner remainder
-                                                     ("eucm", 40001, None)])  # 20 001 pairs on 512 workgroups: two chunks each
+                                                     ("eucm", 40001, None),   # 20 001 pairs on 512 workgroups: two chunks each
+                                                     ("mei", 37, None),       # 17-wide rows: two corners of a lane, then the third
+                                                     ("mei", 30001, None)])   # chunks of 24 pairs: two (four-wave shape) / five (eight-wave shape) per workgroup
 def test_persistent_direct_kernel_equals_the_one_shot_kernel(vg, model, n_images, n_points):
     import torch
     from visgeom_amd import capi

@@ -84,7 +84,7 @@ bool gram_inline_chain(const vg_problem *p, const Dataset &d)
 }
 
 // The persistent form (vg_gram_valu_pers_kernel): a single DIRECT member walked in the kernel, blocks up to 13 wide, a board of
-// exactly 32 CH points (8 x 12), at least one full round of the one-shot kernel's workgroups.  Returns the workgroups it runs
+// exactly 96 points (8 x 12), at least one full round of the one-shot kernel's workgroups.  Returns the workgroups it runs
 // with (= the number of partials it leaves; 0 = does not apply) and the shape (threads per workgroup).
 template <int MODEL, int CH, int THREADS>
 unsigned int gram_pers_resident()
@@ -94,7 +94,7 @@ unsigned int gram_pers_resident()
     if (!resident) {
         int per_cu = 0, dev = 0;
         hipDeviceProp_t prop;
-        constexpr size_t lds = vg::gram_valu_pers_lds_bytes<W, CH, THREADS>();
+        constexpr size_t lds = vg::gram_valu_pers_lds_bytes<W, THREADS>();
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(vg::vg_gram_valu_pers_kernel<MODEL, CH, THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, vg::vg_gram_valu_pers_kernel<MODEL, CH, THREADS>, THREADS, lds) != hipSuccess ||
             hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || per_cu < 1)
@@ -107,11 +107,10 @@ unsigned int gram_pers_resident()
 // which shape, by size: none below 4 096 images (less than a round of the one-shot kernel's octets), the eight-wave shape up to
 // 16 384, the four-wave shape beyond (profiles/r05z_gram_pers_probe5.txt; NOTES).  hook gram_persistent: 1 = never,
 // 2 = the four-wave shape whenever it applies, 3 = the eight-wave shape whenever it applies
-template <int CH>
-int gram_pers_shape(const vg::GramValuArgs &a, bool with_sum)
+inline int gram_pers_shape(const vg::GramValuArgs &a, bool with_sum)
 {
     const long long hook = vgi::debug_hook(vgi::kHookGramPersistent);
-    if (hook == 1 || a.g.N != (unsigned)(vg::kValuLanesPerImage * CH) || a.g.n_blocks < 2) return 0;   // one full chunk per image: the 8 x 12 board
+    if (hook == 1 || a.g.N != (unsigned)(vg::kValuLanesPerImage * vg::kPersCorners) || a.g.n_blocks < 2) return 0;   // three corners per lane: the 8 x 12 board
     if (hook == 2) return vg::kPersThreadsLong;
     if (hook == 3) return vg::kPersThreadsShort;
     if (a.g.n_blocks >= 16384u) return vg::kPersThreadsLong;
@@ -129,7 +128,7 @@ int launch_gram_valu_pers(hipStream_t stream, const vg::GramValuArgs &a, unsigne
     const unsigned int n_pairs = (a.g.n_blocks + 1) / 2, n_wg = n_pairs < resident ? n_pairs : resident;
     vg::GramValuArgs ap = a;
     ap.n_wg = n_wg;
-    constexpr size_t lds = vg::gram_valu_pers_lds_bytes<W, CH, THREADS>();
+    constexpr size_t lds = vg::gram_valu_pers_lds_bytes<W, THREADS>();
     hipLaunchKernelGGL((vg::vg_gram_valu_pers_kernel<MODEL, CH, THREADS>), dim3(n_wg), dim3(THREADS), lds, stream, ap, n_pairs);
     VG_HIP(hipGetLastError());
     *n_wg_out = n_wg;
@@ -240,11 +239,14 @@ int vgi::gram_fused_at(vg_problem *p, int dataset_id, const double *d_params, do
             if (!d.d_wg_partials) VG_HIP(hipMalloc(&d.d_wg_partials, sizeof(double) * (size_t)E * n_part));
             a.partials = d.d_wg_partials;
         }
-        const int pers = (inl && d.L == 1 && cam.model != VG_MODEL_MEI) ? gram_pers_shape<3>(a, sum != nullptr) : 0;   // Mei's 17-wide block: five entries per lane, no packed output table
+        const int pers = (inl && d.L == 1) ? gram_pers_shape(a, sum != nullptr) : 0;
         if (pers) {
             unsigned int n_wg = 0;
-            rc = cam.model == VG_MODEL_EUCM ? launch_gram_valu_pers_shape<vg::kEUCM, 3>(p->stream, a, pers, &n_wg)
-                                            : launch_gram_valu_pers_shape<vg::kUCM, 3>(p->stream, a, pers, &n_wg);
+            switch (cam.model) {
+            case VG_MODEL_EUCM: rc = launch_gram_valu_pers_shape<vg::kEUCM, 3>(p->stream, a, pers, &n_wg); break;
+            case VG_MODEL_UCM: rc = launch_gram_valu_pers_shape<vg::kUCM, 3>(p->stream, a, pers, &n_wg); break;
+            default: rc = launch_gram_valu_pers_shape<vg::kMEI, 2>(p->stream, a, pers, &n_wg); break;   // 17-wide rows: two corners, then the third
+            }
             a.n_wg = n_wg;
         } else {
             switch (cam.model) {

@@ -506,8 +506,8 @@ __global__ __launch_bounds__(kValuThreads, (valu_min_waves<MODEL, L, CH>())) voi
 }
 
 // ------------------------------------------------------------------------------------------
-// PERSISTENT form of the direct kernel for a single DIRECT member walked in the kernel and a board of exactly 32 CH points
-// (one full chunk per image: the 8 x 12 board of every BASELINE configuration): as many workgroups as are resident, each
+// PERSISTENT form of the direct kernel for a single DIRECT member walked in the kernel and a board of exactly 96 points
+// (three corners per lane: the 8 x 12 board of every BASELINE configuration): as many workgroups as are resident, each
 // owning a contiguous range of image PAIRS.  What it changes against one workgroup per octet:
 //   * the chain walk -- ~250 instructions that two lanes of every wave execute in the one-shot kernel, a sixth of the wave --
 //     runs ONCE per workgroup and chunk for up to 64 images, one image per lane of one wave, into LDS;
@@ -518,8 +518,10 @@ __global__ __launch_bounds__(kValuThreads, (valu_min_waves<MODEL, L, CH>())) voi
 //   * the per-pair totals go to LDS BY PAIR INDEX and are added in pair order after the chunk, so the workgroup's partial does
 //     not depend on which wave took which pair (the order of every sum stays fixed).
 // ------------------------------------------------------------------------------------------
-constexpr int kPersChunkPairs = 32;   // pairs per chunk: 64 frames + 32 pair totals in LDS
-constexpr int kPersMaxCH = 3;
+// pairs per chunk (their frames and pair totals live in LDS): 32 for blocks up to 13 wide, 24 for Mei's 17-wide block (153 entries
+// per total: two four-wave workgroups must still fit a CU's 160 KB)
+__host__ __device__ constexpr int pers_chunk_pairs(int W) { return W <= 13 ? 32 : 24; }
+constexpr int kPersCorners = 3;   // corners per lane: the board has exactly 32 x 3 points; rows of CH of them at a time in registers
 // Two shapes of the same kernel (THREADS):
 //   256  two workgroups of four waves per CU, ONE pair counter per workgroup -- fewer waves at a chunk's barrier: the better
 //        shape for long ranges (from 16 384 images on: 20 k images 34.0 -> 32.9 us, 100 k 155 -> 149.5 us);
@@ -530,12 +532,12 @@ constexpr int kPersMaxCH = 3;
 //        instead of 1 250 (10 k images: kernel 19.0 / 19.1 us, with the sum 22.6 -> 21.6 us; 5 k: 12.4 -> 12.25).
 constexpr int kPersThreadsLong = 256, kPersThreadsShort = 512;
 
-// LDS: frames [64][FS] | pair totals [32][E] | board [32 CH][3] | staging [waves][2][CH][64 lanes] x 16 bytes | 4 counters
-template <int W, int CH, int THREADS>
+// LDS: frames [2 P][FS] | pair totals [P][E] | board [96][3] | staging [waves][2][3][64 lanes] x 16 bytes | 4 counters   (P = pairs per chunk)
+template <int W, int THREADS>
 __host__ __device__ constexpr size_t gram_valu_pers_lds_bytes()
 {
-    return sizeof(double) * (size_t)(2 * kPersChunkPairs * frame_stride(1) + kPersChunkPairs * (W * (W + 1) / 2) + 3 * 32 * CH +
-                                     (THREADS / kWave) * 2 * CH * kWave * 2) + 32;
+    return sizeof(double) * (size_t)(2 * pers_chunk_pairs(W) * frame_stride(1) + pers_chunk_pairs(W) * (W * (W + 1) / 2) + 3 * 32 * kPersCorners +
+                                     (THREADS / kWave) * 2 * kPersCorners * kWave * 2) + 32;
 }
 
 // 16 bytes per lane from HBM into LDS at lds_addr + 16 * lane, without a register in between.  The compiler does not know this
@@ -571,13 +573,14 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
     using Rows = ValuRows<MODEL, 1, CH>;
     using d2 = HIP_vector_type<double, 2>;
     constexpr int K = Rows::K, W = Rows::W, E = Rows::E, FS = frame_stride(1);
-    constexpr int kOut = halved(E, 5);
-    static_assert(kOut <= 3 && W * W < 512, "packed output table");
+    constexpr int kOut = halved(E, 5), kPersChunkPairs = pers_chunk_pairs(W), CB = kPersCorners - CH;   // CB: corners of the second row chunk
+    constexpr bool kPackedOut = kOut <= 3 && W * W < 512;
     static_assert(E <= kPersThreads, "one entry of the partial per thread");
-    static_assert(CH <= kPersMaxCH, "staging block");
+    static_assert(CH >= 1 && CH <= kPersCorners, "rows of CH corners, then of the other 3 - CH");
+    static_assert(gram_valu_pers_lds_bytes<W, THREADS>() * (THREADS == kPersThreadsShort ? 1 : 2) <= 160 * 1024, "two waves per SIMD must fit the CU's LDS");
     double *fr_lds = valu_lds, *tot_lds = fr_lds + 2 * kPersChunkPairs * FS, *board_lds = tot_lds + kPersChunkPairs * E;
-    double *stage_lds = board_lds + 3 * 32 * CH;
-    int *counter = reinterpret_cast<int *>(stage_lds + kPersWaves * 2 * CH * kWave * 2);   // [4]: next pair of each SIMD's range
+    double *stage_lds = board_lds + 3 * 32 * kPersCorners;
+    int *counter = reinterpret_cast<int *>(stage_lds + kPersWaves * 2 * kPersCorners * kWave * 2);   // [4]: next pair of each SIMD's range
     if (gate_closed(a.g.gate, a.g.gate_expect)) return;
 #ifdef VG_GRAM_STAMPS   // measurement build (tools/exp/gram_pers_stamps_probe.py): 16 wall-clock stamps (100 MHz) per wave -- 0 entry,
                         // 1 walk + barrier done, 2 first pair's observations in LDS, 3..9 end of every pair (its stores issued); inside a
@@ -606,7 +609,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
         const double v = a.g.intr[i];
         intr_r[i] = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
     }
-    for (int i = threadIdx.x; i < 3 * 32 * CH; i += kPersThreads) board_lds[i] = a.g.board[i];   // visible behind the first barrier
+    for (int i = threadIdx.x; i < 3 * 32 * kPersCorners; i += kPersThreads) board_lds[i] = a.g.board[i];   // visible behind the first barrier
 
     double wg_sum = 0.;   // thread e < E: entry e of the workgroup's partial, chunks added in order
     // chunks of about equal size, a multiple of the waves that share them (every chunk ends at a barrier)
@@ -630,7 +633,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
             asm volatile("" : "+v"(tid));   // nothing derived from the thread index is kept across the walk
             const int lane = tid & (kWave - 1), wave = __builtin_amdgcn_readfirstlane(tid >> 6);
             const int sl = lane & (kValuLanesPerImage - 1), h = lane >> 5;
-            double *stage = stage_lds + (size_t)wave * (2 * CH * kWave * 2);
+            double *stage = stage_lds + (size_t)wave * (2 * kPersCorners * kWave * 2);
             const unsigned int stage_addr = (unsigned int)(size_t)(__attribute__((address_space(3))) void *)stage;
             const d2 *obs = reinterpret_cast<const d2 *>(a.g.obs);
             // pairs [range_first(s), range_first(s + 1)) of the chunk belong to SIMD s (one range = the whole chunk: kRanges == 1)
@@ -652,13 +655,13 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 }
                 return u;
             };
-            auto request = [&](int u, int parity) {   // the CH observations of this lane's corners of pair u -> stage[parity]
+            auto request = [&](int u, int parity) {   // the observations of this lane's three corners of pair u -> stage[parity]
                 const unsigned int li = 2u * (unsigned)u + (unsigned)h;
                 const unsigned int bb = li < chunk_images ? img0 + li : img0;
 #pragma unroll
-                for (int j = 0; j < CH; j++)
+                for (int j = 0; j < kPersCorners; j++)
                     pers_load_to_lds(obs + ((size_t)bb * a.g.N + (unsigned)(sl + kValuLanesPerImage * j)),
-                                     (unsigned int)__builtin_amdgcn_readfirstlane((int)(stage_addr + (unsigned)((parity * CH + j) * kWave * 16))));
+                                     (unsigned int)__builtin_amdgcn_readfirstlane((int)(stage_addr + (unsigned)((parity * kPersCorners + j) * kWave * 16))));
             };
             int u = claim(), parity = 0;
             if ((unsigned)u < chunk_pairs) {
@@ -670,16 +673,28 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 const unsigned int li = 2u * (unsigned)u + (unsigned)h;
                 const unsigned int b = img0 + li;
                 const bool bvalid = li < chunk_images;
-                const unsigned long long lane_out = kLaneOutTable<W>.v[sl];
+                unsigned long long lane_out = 0ull;
+                if constexpr (kPackedOut) lane_out = kLaneOutTable<W>.v[sl];
+                auto corner_in = [&](int j, double (&gb)[3], d2 &ob) {   // corner sl + 32 j of the lane's image: board point from LDS, observation from the staged block
+                    ob = reinterpret_cast<const d2 *>(stage)[(parity * kPersCorners + j) * kWave + lane];
+                    const int c = sl + kValuLanesPerImage * j;
+                    gb[0] = board_lds[3 * c];
+                    gb[1] = board_lds[3 * c + 1];
+                    gb[2] = board_lds[3 * c + 2];
+                };
                 ValuChunkIn<CH> in;
 #pragma unroll
                 for (int j = 0; j < CH; j++) {
-                    in.ob[j] = reinterpret_cast<const d2 *>(stage)[(parity * CH + j) * kWave + lane];
-                    const int c = sl + kValuLanesPerImage * j;
-                    in.gb[j][0] = board_lds[3 * c];
-                    in.gb[j][1] = board_lds[3 * c + 1];
-                    in.gb[j][2] = board_lds[3 * c + 2];
+                    corner_in(j, in.gb[j], in.ob[j]);
                     in.ragged[j] = !bvalid;
+                }
+                ValuChunkIn<(CB > 0 ? CB : 1)> in_b;   // Mei: the rows of two corners, then of the third (the one-shot kernel's chunks of 64 + 32)
+                if constexpr (CB > 0) {
+#pragma unroll
+                    for (int j = 0; j < CB; j++) {
+                        corner_in(CH + j, in_b.gb[j], in_b.ob[j]);
+                        in_b.ragged[j] = !bvalid;
+                    }
                 }
                 const int u_next = claim();
                 if ((unsigned)u_next < chunk_pairs) request(u_next, parity ^ 1);
@@ -696,6 +711,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 }
 #endif
                 valu_chunk<MODEL, 1, CH, kOut>(intr_r, fr, in, sl, out);
+                if constexpr (CB > 0) valu_chunk<MODEL, 1, CB, kOut>(intr_r, fr, in_b, sl, out);
 #ifdef VG_GRAM_STAMPS
                 if (pstamp_unit <= 4) {
                     asm volatile("" : "+v"(out[0]));
@@ -706,18 +722,44 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #endif
                 // the next pair's observations have had the whole pair to arrive: waiting HERE, in front of this pair's
                 // stores, is free -- at the head of the next pair the same wait would also wait for those stores
-                if constexpr (kOut == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(out[0]), "+v"(out[1]), "+v"(out[2])::"memory");
+                static_assert(kOut >= 1 && kOut <= 5, "the wait is tied to every entry the stores need");
+                if constexpr (kOut == 5) asm volatile("s_waitcnt vmcnt(0)" : "+v"(out[0]), "+v"(out[1]), "+v"(out[2]), "+v"(out[3]), "+v"(out[4])::"memory");
+                else if constexpr (kOut == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(out[0]), "+v"(out[1]), "+v"(out[2]), "+v"(out[3])::"memory");
+                else if constexpr (kOut == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(out[0]), "+v"(out[1]), "+v"(out[2])::"memory");
                 else if constexpr (kOut == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(out[0]), "+v"(out[1])::"memory");
                 else asm volatile("s_waitcnt vmcnt(0)" : "+v"(out[0])::"memory");
 #ifdef VG_GRAM_STAMPS
                 if (pstamp_unit == 3) VG_PSTAMP(12);
 #endif
-                const int base = (int)((lane_out >> 54) & 0xff), real = (int)(lane_out >> 62);
+                int base = 0, real = E;
+                if constexpr (kPackedOut) {
+                    base = (int)((lane_out >> 54) & 0xff);
+                    real = (int)(lane_out >> 62);
+                } else {
+                    int n = E;
+#pragma unroll
+                    for (int q = 0; q < 5; q++) {
+                        const int H = (n + 1) / 2;
+                        const bool bit = (sl >> (4 - q)) & 1;
+                        base += bit ? H : 0;
+                        real = bit ? (real - H > 0 ? real - H : 0) : (real < H ? real : H);
+                        n = H;
+                    }
+                }
                 double *G = a.g.gram + (size_t)(bvalid ? b : 0) * (W * W);
 #pragma unroll
                 for (int k = 0; k < kOut; k++) {
                     const bool have = k < real;
-                    const unsigned int o_rc = (unsigned)(lane_out >> (18 * k)) & 0x1ff, o_cr = (unsigned)(lane_out >> (18 * k + 9)) & 0x1ff;
+                    unsigned int o_rc, o_cr;
+                    if constexpr (kPackedOut) {
+                        o_rc = (unsigned)(lane_out >> (18 * k)) & 0x1ff;
+                        o_cr = (unsigned)(lane_out >> (18 * k + 9)) & 0x1ff;
+                    } else {
+                        const int e = have ? base + k : 0;
+                        const int r = kTriTable<W>.r[e], cc = kTriTable<W>.c[e];
+                        o_rc = r * W + cc;
+                        o_cr = cc * W + r;
+                    }
                     if (have && bvalid) {
                         G[o_rc] = out[k];
                         G[o_cr] = out[k];
