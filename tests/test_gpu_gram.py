@@ -252,3 +252,37 @@ def test_persistent_direct_kernel_equals_the_one_shot_kernel(vg, model, n_images
         pv = p.get_parameters()
         Gref = oracle_grams(model, status, board, corners, pv, 0, bases, strides, np.arange(n_images))
         assert_gram_parity(g1.reshape(n_images, W, W), Gref, "persistent")
+
+
+def test_persistent_kernel_with_an_image_to_sequence_map(vg):
+    """A dataset whose images are a shuffled subset of the pose sequence (image_index): the walker wave of the persistent kernel
+    follows the map as the one-shot kernel's walkers do -- same blocks bit for bit in both shapes, and equal to the oracle."""
+    from visgeom_amd import capi
+    from visgeom_amd import synthetic as S
+
+    n_seq, n_img = 90, 61
+    d = S.make_mono("eucm", n_seq, 3)
+    pick = RNG.permutation(n_seq)[:n_img]
+    p = vg.CalibrationProblem(0)
+    cam = p.add_camera("eucm", d["init_intrinsics"])
+    seq = p.add_transform(False, d["init_poses"])
+    ds = p.add_dataset(cam, [(seq, 0)], d["board"], d["corners"][pick], image_index=pick)
+    p.finalize()
+    W = len(d["init_intrinsics"]) + 7
+    out = {}
+    try:
+        for name, hook in (("one-shot", 1), ("four waves", 2), ("eight waves", 3)):
+            capi.debug_set("gram_persistent", hook)
+            gram, gsum = p.alloc_gram(ds)
+            gram.fill_(float("nan"))
+            p.prepare()
+            p.gram_fused_sum(ds, gram, gsum)
+            p.synchronize()
+            out[name] = (gram.cpu().numpy().copy(), gsum.cpu().numpy().copy())
+    finally:
+        capi.debug_set("gram_persistent", 0)
+    assert np.array_equal(out["one-shot"][0], out["four waves"][0]) and np.array_equal(out["one-shot"][0], out["eight waves"][0])
+    for name in ("four waves", "eight waves"):
+        assert np.allclose(out[name][1], out["one-shot"][1], rtol=1e-12, atol=0.)
+    Gref = oracle_grams("eucm", [0], d["board"], d["corners"][pick], p.get_parameters(), 0, [p.transform_offset(seq, 0)], [6], pick)
+    assert_gram_parity(out["eight waves"][0].reshape(n_img, W, W), Gref, "persistent, mapped images")
