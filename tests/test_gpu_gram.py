@@ -286,3 +286,43 @@ def test_persistent_kernel_with_an_image_to_sequence_map(vg):
         assert np.allclose(out[name][1], out["one-shot"][1], rtol=1e-12, atol=0.)
     Gref = oracle_grams("eucm", [0], d["board"], d["corners"][pick], p.get_parameters(), 0, [p.transform_offset(seq, 0)], [6], pick)
     assert_gram_parity(out["eight waves"][0].reshape(n_img, W, W), Gref, "persistent, mapped images")
+
+
+def test_persistent_kernel_on_failed_projections_and_missing_corners(vg):
+    """Boards behind the camera (the in-band 1e15 of calib_cost_functions.cpp:66-70) and NaN observations go through the persistent
+    kernel exactly as through the one-shot kernel: every block bit for bit, NaNs in the same places."""
+    from visgeom_amd import capi
+    from visgeom_amd import synthetic as S
+
+    n = 70
+    d = S.make_mono("eucm", n, 5)
+    poses = d["init_poses"].copy()
+    poses[[3, 40], 2] = -np.abs(poses[[3, 40], 2]) - 3.      # behind the camera ...
+    intr = d["init_intrinsics"].copy()
+    intr[0] = 0.3                                             # ... of a model (alpha < 1/2) that cannot see there: every projection of these images fails
+    corners = d["corners"].copy()
+    corners[5, 10, 0] = np.nan
+    corners[17, 95, :] = np.nan
+    p = vg.CalibrationProblem(0)
+    cam = p.add_camera("eucm", intr)
+    seq = p.add_transform(False, poses)
+    ds = p.add_dataset(cam, [(seq, 0)], d["board"], corners)
+    p.finalize()
+    out = {}
+    try:
+        for name, hook in (("one-shot", 1), ("four waves", 2), ("eight waves", 3)):
+            capi.debug_set("gram_persistent", hook)
+            gram, gsum = p.alloc_gram(ds)
+            gram.fill_(0.)
+            p.prepare()
+            p.gram_fused_sum(ds, gram, gsum)
+            p.synchronize()
+            out[name] = (gram.cpu().numpy().copy(), gsum.cpu().numpy().copy())
+    finally:
+        capi.debug_set("gram_persistent", 0)
+    g0 = out["one-shot"][0].reshape(n, -1)
+    assert np.isnan(g0[5]).any() and np.isnan(g0[17]).any() and np.isfinite(g0[4]).all()
+    assert np.abs(g0[3]).max() > 1e29 and np.abs(g0[40]).max() > 1e29      # 96 x 2 residuals of 1e15, squared
+    for name in ("four waves", "eight waves"):
+        assert np.array_equal(out[name][0], out["one-shot"][0], equal_nan=True), name
+        assert np.array_equal(np.isnan(out[name][1]), np.isnan(out["one-shot"][1]))
