@@ -537,8 +537,10 @@ int vg_camera_jacobian_evaluate(int device, void *hip_stream, int model, const d
 /* ---- measurement / test hooks.  The library reads no environment variable to change what it computes or how; the A/B
  * switches used by tests/ and tools/ are set here (process-wide, not thread safe): "inline_chain_max_bytes", "gram_force_mfma",
  * "gram_ch1", "gram_no_merge", "max_obs_per_launch", "solver_timing", "solver_host_loop", "solver_device_loop",
- * "solver_no_speculation", "emit_equal_tiles"; value 0 restores the default.  A production build (without VG_DEBUG_HOOKS) has none of them and
- * returns VG_ERR_STATE.  (VG_RCCL_LIBRARY, the path of the RCCL library to bind, is deployment configuration, not a hook.) */
+ * "solver_no_speculation", "emit_equal_tiles", ... (the list: enum DebugHook, visgeom_amd/csrc/vg_internal.hpp); value 0 restores
+ * the default.  The PRODUCTION library (python -m visgeom_amd._build --production, built without VG_DEBUG_HOOKS) has none of them:
+ * every switch is its default at compile time and this entry is not exported.  (VG_RCCL_LIBRARY, the path of the RCCL library to
+ * bind, is deployment configuration, not a hook.) */
 int vg_debug_set(const char *name, long long value);
 
 /* ---- measurement helpers (bench / profiling only): a pure streaming write / copy with the same

@@ -41,6 +41,22 @@ def test_header_symbols_are_exported_and_bound(lib):
     assert not extra, "bound but not declared: %s" % extra
 
 
+def test_production_library_exports_the_header_minus_the_hook_entry():
+    """the library that ships (built without VG_DEBUG_HOOKS): exactly the header's symbols except vg_debug_set, from the same
+    translation units, and no trace of the hook table"""
+    from visgeom_amd import _build
+
+    prod = _build.build_production()
+    out = subprocess.check_output(["nm", "-D", "--defined-only", prod], text=True)
+    exported = set(re.findall(r" T (vg_[a-z0-9_]+)", out))
+    assert exported == set(declared_symbols()) - {"vg_debug_set"}, sorted(exported ^ (set(declared_symbols()) - {"vg_debug_set"}))
+    blob = open(prod, "rb").read()
+    assert b"gfx950" in blob and b"vg_emit_kernel" in blob
+    assert b"inline_chain_max_bytes" not in blob and b"emit_map_window" not in blob   # the hook names are compiled out
+    L = ctypes.CDLL(prod)
+    assert L.vg_abi_version() == 1 and not hasattr(L, "vg_debug_set")
+
+
 def test_library_is_hip_code_for_gfx950():
     from visgeom_amd import _build
 

@@ -16,9 +16,12 @@ LIB = os.path.join(LIB_DIR, "libvisgeom_amd.so")
 # kernel is HBM bound, the extra VALU instructions are not on the critical path.
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
                "-fno-fast-math", "-Wall", "-Wno-unused-function"]
-# the A/B and test switches behind vg_debug_set(); VG_PRODUCTION=1 builds the library without them
-if not os.environ.get("VG_PRODUCTION"):
-    HIPCC_FLAGS.append("-DVG_DEBUG_HOOKS")
+# the A/B and test switches behind vg_debug_set(): the library tests/ and bench.py drive.  build_production() makes the
+# library that ships -- same sources without this switch (no hook table, every switch its default at compile time,
+# vg_debug_set not exported) -> lib/production/libvisgeom_amd.so
+HOOKS_FLAG = "-DVG_DEBUG_HOOKS"
+HIPCC_FLAGS.append(HOOKS_FLAG)
+PRODUCTION_LIB = os.path.join(LIB_DIR, "production", "libvisgeom_amd.so")
 
 
 def sources():
@@ -141,7 +144,13 @@ def build(force=False, verbose=False):
     return LIB
 
 
-def build_variant(name, extra_flags, verbose=False):
+def build_production(verbose=False):
+    """The library that ships: the same translation units without VG_DEBUG_HOOKS.  Objects are cached by content like the
+    default build's (lib/obj_production/), so an unchanged tree costs nothing."""
+    return build_variant("production", [], verbose=verbose, out=PRODUCTION_LIB, drop_flags=[HOOKS_FLAG])
+
+
+def build_variant(name, extra_flags, verbose=False, out=None, drop_flags=()):
     """An A/B library for tools/exp probes: the same sources with additional -D switches -> lib/variants/libvisgeom_amd_<name>.so
     (objects under lib/obj_<name>/; git-ignored like the product library, and like it carried to the GPU box by gpurun)."""
     global _EXTRA_FLAGS
@@ -149,10 +158,13 @@ def build_variant(name, extra_flags, verbose=False):
 
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     obj_dir = os.path.join(LIB_DIR, "obj_" + name)
-    out = os.path.join(LIB_DIR, "variants", "libvisgeom_amd_%s.so" % name)
+    out = out or os.path.join(LIB_DIR, "variants", "libvisgeom_amd_%s.so" % name)
     os.makedirs(obj_dir, exist_ok=True)
     os.makedirs(os.path.dirname(out), exist_ok=True)
     _EXTRA_FLAGS = list(extra_flags)
+    dropped = [f for f in drop_flags if f in HIPCC_FLAGS]
+    for f in dropped:
+        HIPCC_FLAGS.remove(f)
     try:
         srcs = sources()
         with ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 1)) as ex:
@@ -160,6 +172,7 @@ def build_variant(name, extra_flags, verbose=False):
         subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + [o for o, _ in done])
     finally:
         _EXTRA_FLAGS = []
+        HIPCC_FLAGS.extend(dropped)
     return out
 
 
@@ -179,7 +192,9 @@ def build_cli(verbose=False):
 
 
 if __name__ == "__main__":
-    if "--variant" in sys.argv:   # python -m visgeom_amd._build --variant NAME -DFLAG [-DFLAG ...]
+    if "--production" in sys.argv:
+        print(build_production(verbose=True))
+    elif "--variant" in sys.argv:   # python -m visgeom_amd._build --variant NAME -DFLAG [-DFLAG ...]
         i = sys.argv.index("--variant")
         print(build_variant(sys.argv[i + 1], sys.argv[i + 2:], verbose=True))
     else:

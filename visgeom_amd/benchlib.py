@@ -40,21 +40,27 @@ def timed(fn, reps):
 
 
 def emit_sweep(d, model, sizes, device=0, reps=60):
-    """The emit step over the first n images of one generated set, n in `sizes` (where the 256 MiB Infinity
-    Cache stops holding the output -- 10 k images write 215 MB, 15 k 322 MB): per size the route (one launch with the chain walked
-    in the emit kernel, or chain prep + emit on prepared frames), kernel microseconds (back-to-back launches, HIP events) and the
-    fraction of the 8 TB/s HBM peak at the algorithmic byte count."""
+    """The emit step over n images, n in `sizes`: the first n of one generated set, the set repeated where n exceeds it (the
+    kernel's work does not depend on the values).  Per size: the route (one launch with the chain walked in the emit kernel, or
+    chain prep + emit on prepared frames), kernel microseconds (back-to-back launches, HIP events, after a warm-up of at least
+    30 launches) and the fraction of the 8 TB/s HBM peak at the algorithmic byte count.  What the curve shows is explained in
+    profiles/r06_emit_drop.md: up to ~230 MB the output stays in the 256 MiB Infinity Cache; around 1 GB a quarter of every
+    launch still lands in the cache and is overwritten there by the next launch (a hump above the DRAM write rate); from
+    ~2 GB on the figure is the part's streaming-write rate."""
     from . import CalibrationProblem, capi
 
     rows = []
     K = KOF[model]
+    have = d["corners"].shape[0]
     for n in sizes:
-        if n > d["corners"].shape[0]:
-            continue
+        rep = (n + have - 1) // have
+        poses = d["init_poses"] if rep == 1 else np.tile(d["init_poses"], (rep, 1))
+        corners = d["corners"] if rep == 1 else np.tile(d["corners"], (rep, 1, 1))
         p = CalibrationProblem(device)
         cam = p.add_camera(model, d["init_intrinsics"])
-        seq = p.add_transform(False, d["init_poses"][:n])
-        ds = p.add_dataset(cam, [(seq, 0)], d["board"], d["corners"][:n])
+        seq = p.add_transform(False, poses[:n])
+        ds = p.add_dataset(cam, [(seq, 0)], d["board"], corners[:n])
+        del poses, corners
         p.finalize()
         res, ji, jm = p.alloc_outputs(ds)
 
@@ -65,14 +71,23 @@ def emit_sweep(d, model, sizes, device=0, reps=60):
         def emit():
             p.evaluate_dataset(ds, res, ji, jm)
 
-        t_step, t_emit = timed(step, reps), timed(emit, reps)
         nbytes = n * N_CORNERS * emit_bytes_per_obs(model, 1)
+        r = max(12, min(reps, int(60e9 / nbytes)))
+        for _ in range(30):
+            emit()
+        t_step, t_emit = timed(step, r), timed(emit, r)
         one = capi.load().vg_dataset_single_launch(p._h, ds) == 1
-        rows.append({"images": n, "output_MB": n * N_CORNERS * 16 * (K + 7) / 1e6, "route": "inline-chain" if one else "prep + emit",
+        out_mb = n * N_CORNERS * 16 * (K + 7) / 1e6
+        rows.append({"images": n, "output_MB": out_mb, "route": "inline-chain" if one else "prep + emit",
                      "kernel_us": t_emit * 1e6, "step_us": t_step * 1e6, "frac": nbytes / t_emit / HBM_PEAK,
-                     "frac_whole_step": nbytes / t_step / HBM_PEAK})
+                     "frac_whole_step": nbytes / t_step / HBM_PEAK,
+                     "regime": "inside the 256 MiB Infinity Cache" if out_mb * 1e6 < 256 * 2 ** 20 else
+                               "cache-assisted (part of every launch is overwritten in the Infinity Cache by the next)" if out_mb < 1700 else "DRAM streaming"})
         p.close()
         del res, ji, jm
+        import torch
+
+        torch.cuda.empty_cache()
     return rows
 
 

@@ -190,19 +190,42 @@ class VisgeomError(RuntimeError):
 
 
 _lib = None
+_has_hooks = False
 
 
 def lib_path():
-    return _build.LIB
+    """the library file this process loads: the default (hooks) build, or -- for the TEST HARNESS only, the library itself
+    reads no environment variable -- the file VISGEOM_AMD_LIBRARY names ("production" = lib/production/libvisgeom_amd.so)"""
+    sel = os.environ.get("VISGEOM_AMD_LIBRARY")
+    if not sel:
+        return _build.LIB
+    return _build.PRODUCTION_LIB if sel == "production" else sel
+
+
+class NoDebugHooks(VisgeomError):
+    """vg_debug_set on a production library (built without VG_DEBUG_HOOKS: the entry is not exported)"""
+
+    def __init__(self):
+        VisgeomError.__init__(self, ERR_STATE, "this library has no debug hooks (production build)")
+
+
+def has_debug_hooks():
+    load()
+    return _has_hooks
 
 
 def load():
     """Load libvisgeom_amd.so.  Raises if it is missing -- build it with
     `python -c "import __graft_entry__ as g; g.build()"`; there is no CPU fallback."""
     global _lib
+    global _has_hooks
     if _lib is not None:
         return _lib
-    if not os.path.exists(_build.LIB):
+    path = lib_path()
+    if path != _build.LIB:
+        if not os.path.exists(path):
+            raise ImportError("VISGEOM_AMD_LIBRARY: %s does not exist (python -m visgeom_amd._build --production)" % path)
+    elif not os.path.exists(_build.LIB):
         try:  # build the HIP library in-tree (hipcc cross-compiles); never substitute anything for it
             _build.build()
         except Exception as e:
@@ -212,8 +235,11 @@ def load():
         import torch  # noqa: F401
     except Exception:  # the library also works stand-alone against /opt/rocm
         pass
-    L = ctypes.CDLL(_build.LIB)
+    L = ctypes.CDLL(path)
+    _has_hooks = hasattr(L, "vg_debug_set")
     for name, (res, args) in SIGNATURES.items():
+        if name == "vg_debug_set" and not _has_hooks:   # the production library: the one entry it does not export
+            continue
         f = getattr(L, name)  # AttributeError here = header / library mismatch
         f.restype = res
         f.argtypes = args
@@ -228,7 +254,10 @@ def check(code):
 
 def debug_set(name, value):
     """measurement / test hook of the library (vg_debug_set): value 0 restores the default"""
-    check(load().vg_debug_set(name.encode(), int(value)))
+    L = load()
+    if not _has_hooks:
+        raise NoDebugHooks()
+    check(L.vg_debug_set(name.encode(), int(value)))
 
 
 def hooks_from_env():

@@ -179,6 +179,8 @@ void fill_emit_args_at(const vg_problem *p, const Dataset &d, vg::EmitArgs &a, i
     a.seq_index = d.seq_identity ? nullptr : d.d_seq + b0;
     a.first_block = b0;
     a.nt_stores = emit_output_bytes(a, cam.K) >= emit_nt_min_bytes() ? 1 : 0;  // a merged launch decides for all its datasets together
+    const long long mw = vgi::debug_hook(vgi::kHookEmitMapWindow);   // hook: W > 0 that window, -1 contiguous eighths, 0 the default
+    a.map_window = mw > 0 ? (unsigned int)mw : mw < 0 ? 0u : vg::kEmitMapWindow;
 }
 
 // the same with whole-dataset arrays: block b0's rows lie b0 blocks into each of them
@@ -199,28 +201,25 @@ void fill_emit_args(const vg_problem *p, const Dataset &d, vg::EmitArgs &a, int6
 namespace {
 long long g_debug_hooks[vgi::kHookCount] = {0};
 const char *const kDebugHookNames[vgi::kHookCount] = {"inline_chain_max_bytes", "gram_force_mfma", "gram_ch1", "gram_no_merge", "max_obs_per_launch",
-                                                      "solver_timing", "solver_host_loop", "solver_device_loop", "solver_no_speculation", "emit_equal_tiles", "schur_private_gather", "solver_event_wait", "solver_no_fold_frames", "solver_one_wave_fold", "solver_fold_max_groups", "emit_nt_min_bytes", "host_chunk_bytes", "gram_stamps", "gram_persistent"};
+                                                      "solver_timing", "solver_host_loop", "solver_device_loop", "solver_no_speculation", "emit_equal_tiles", "schur_private_gather", "solver_event_wait", "solver_no_fold_frames", "solver_one_wave_fold", "solver_fold_max_groups", "emit_nt_min_bytes", "host_chunk_bytes", "gram_stamps", "gram_persistent", "emit_map_window"};
 }  // namespace
 long long vgi::debug_hook(vgi::DebugHook h) { return g_debug_hooks[h]; }
 #endif
 
 extern "C" {
 
+#ifdef VG_DEBUG_HOOKS   // the production library does not export the entry at all (tests/test_capi_cpu.py)
 int vg_debug_set(const char *name, long long value)
 {
     if (!name) return fail(VG_ERR_INVALID_ARGUMENT, "name is NULL");
-#ifdef VG_DEBUG_HOOKS
     for (int k = 0; k < vgi::kHookCount; k++)
         if (std::strcmp(name, kDebugHookNames[k]) == 0) {
             g_debug_hooks[k] = value;
             return VG_OK;
         }
     return fail(VG_ERR_INVALID_ARGUMENT, std::string("unknown debug hook: ") + name);
-#else
-    (void)value;
-    return fail(VG_ERR_STATE, "this build has no debug hooks (built without VG_DEBUG_HOOKS)");
-#endif
 }
+#endif
 
 int vg_abi_version(void) { return VG_ABI_VERSION; }
 

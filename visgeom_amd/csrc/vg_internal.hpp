@@ -40,6 +40,7 @@ enum DebugHook {
     kHookHostChunkBytes,           // chunk size of vg_dataset_evaluate_to_host in bytes (0 = the default, 32 MiB): tests force many small chunks
     kHookGramStamps,               // measurement build (-DVG_GRAM_STAMPS) only: device address of the per-wave clock stamps of the Gram kernel
     kHookGramPersistent,           // persistent form of the direct Gram kernel (vg_gram_valu_pers_kernel): 1 = never, 2 / 3 = its four- / eight-wave shape whenever it applies, 0 = by size
+    kHookEmitMapWindow,            // tile map of the emit launches: W > 0 = windows of 8 W tiles, XCD x the x-th run of W tiles in each (1 = linear map); -1 = one contiguous eighth per XCD (the map before round 6); 0 = the default (kEmitMapWindow)
     kHookCount
 };
 #ifdef VG_DEBUG_HOOKS

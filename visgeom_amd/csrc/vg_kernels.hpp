@@ -125,6 +125,8 @@ struct EmitArgs {
     int L;
     int frame_stride_d;
     int nt_stores;         // 1: the launch's output streams past the Infinity Cache -> non-temporal stores (stream_store16)
+    unsigned int map_window;  // tile map of the launch: 0 = every XCD one contiguous eighth of the tiles; W > 0 = windows of 8 W tiles,
+                              // XCD x the x-th run of W tiles in each window (W = 1: the linear map); xcd_window_block, kEmitMapWindow
 };
 
 // Each lane holds the 2S doubles of its observation's two rows; the wave's 64 observations are one
@@ -235,6 +237,23 @@ __device__ __forceinline__ unsigned int xcd_contiguous_block(unsigned int b, uns
     constexpr unsigned int kXcds = 8;
     const unsigned int x = b % kXcds, j = b / kXcds, q = n / kXcds, r = n % kXcds;
     return x * q + (x < r ? x : r) + j;  // bijective on [0, n): XCD x owns q (+1 for x < r) consecutive tiles
+}
+
+// The same with the dies advancing TOGETHER through the output: the tiles are cut into windows of 8 W tiles and XCD x owns the
+// x-th run of W consecutive tiles of every window; the last, partial window is split into contiguous eighths like the whole
+// range above.  W >= n / 8 is xcd_contiguous_block, W = 1 the linear map.  Bijective on [0, n).
+// Why (profiles/r06_emit_drop.md): with one contiguous eighth per die a 2 GB evaluation keeps 8 x 3 write cursors >= 110 MB
+// apart, and on most boxes / placements that costs a tenth of the rate (EUCM 100 k images 395 us against 362 us with W = 16
+// on the same box and arrays; where the eighths run at full rate, 341 us, the windows give 344 us); inside the Infinity Cache
+// the maps do not differ.  The counters say it is the DRAM side: no address-translation misses (TCP_UTCL1_TRANSLATION_MISS
+// 1e3 of 4e7 requests), FEWER L2 -> fabric credit stalls and fewer writes in flight than at 1 GB, i.e. requests retire slower.
+constexpr unsigned int kEmitMapWindow = 16;   // runs of 16 tiles: 384 KiB of a 6-column Jacobian array per die and window
+__device__ __forceinline__ unsigned int xcd_window_block(unsigned int b, unsigned int n, unsigned int W)
+{
+    const unsigned int x = b & 7u, j = b >> 3, w = j / W, i = j - w * W, base = w * 8u * W, rem = n - base;
+    if (rem >= 8u * W) return base + x * W + i;
+    const unsigned int q = rem >> 3, r = rem & 7u;
+    return base + x * q + (x < r ? x : r) + i;
 }
 
 // dynamic LDS: 4 wave tiles, then (FRAMES_LDS) the frames of the images this workgroup touches
@@ -356,13 +375,15 @@ template <int MODEL, bool WANT_JAC, bool FRAMES_LDS, bool INLINE_CHAIN = false>
 #endif
 __global__ __launch_bounds__(kEmitThreads) __attribute__((amdgpu_waves_per_eu(VG_EMIT_WAVES, 8))) void vg_emit_kernel(EmitArgs a)
 {
-    emit_tile<MODEL, WANT_JAC, FRAMES_LDS, INLINE_CHAIN>(a, xcd_contiguous_block(blockIdx.x, gridDim.x) * (unsigned)kEmitThreads);
+    const unsigned int t = a.map_window ? xcd_window_block(blockIdx.x, gridDim.x, a.map_window) : xcd_contiguous_block(blockIdx.x, gridDim.x);
+    emit_tile<MODEL, WANT_JAC, FRAMES_LDS, INLINE_CHAIN>(a, t * (unsigned)kEmitThreads);
 }
 
 // ------------------------------------------------------------------------------------------
 // kernel 2, several datasets in ONE launch (stereo pair, camera rig): a problem's datasets are small launches each
 // (2 000 stereo pairs: 42 + 62 MB) whose ramp-up, drain and inter-kernel gap cost a quarter of the pass.  The tiles of
-// all datasets form one range; XCD x streams the x-th contiguous eighth of EVERY dataset, dataset after dataset, so a die
+// all datasets form one range; XCD x streams its share of EVERY dataset (the x-th eighth of its tiles, cut into runs of
+// kEmitMapWindow tiles: xcd_window_block), dataset after dataset, so a die
 // works inside one dataset's output arrays at a time and every die gets the same bytes and the same arithmetic whatever the
 // mix of models (a rig's Mei tile writes 1.85 x the bytes of its UCM tile: with one contiguous piece of equal tile count
 // per die, the dies holding the wide datasets finished last -- rig, 591 MB: 116 us against 109 us; profiles/NOTES.md "Merged
@@ -400,7 +421,8 @@ __global__ __launch_bounds__(kEmitThreads) __attribute__((amdgpu_waves_per_eu(VG
             if (d == m.n) return;
             const unsigned int nt = m.first_tile[d + 1] - m.first_tile[d], q = nt >> 3, r = nt & 7u, cnt = q + (x < r ? 1u : 0u);
             if (j < cnt) {
-                t = m.first_tile[d] + x * q + (x < r ? x : r) + j;
+                const unsigned int W = m.ds[d].map_window;   // XCD x's j-th tile of this dataset
+                t = m.first_tile[d] + (W ? xcd_window_block(j * 8u + x, nt, W) : x * q + (x < r ? x : r) + j);
                 break;
             }
             j -= cnt;
