@@ -619,13 +619,15 @@ int vgi::prepare_at(vg_problem *p, const double *d_params)
         vg::PrepMultiArgs m;
         m.n = (int)(p->prep.size() - g0 < (size_t)vg::kPrepMax ? p->prep.size() - g0 : (size_t)vg::kPrepMax);
         unsigned int waves = 0;
+        int widest = 0;
         for (int k = 0; k < m.n; k++) {
             m.ds[k] = p->prep[g0 + (size_t)k];
             m.first_wave[k] = waves;
             waves += (unsigned int)((m.ds[k].count + 63) / 64);
+            widest = m.ds[k].frame_stride_d > widest ? m.ds[k].frame_stride_d : widest;
         }
         for (int k = m.n; k <= vg::kPrepMax; k++) m.first_wave[k] = waves;
-        hipLaunchKernelGGL(vg::vg_chain_prep_multi_kernel, dim3(waves), dim3(64), 0, p->stream, d_params, m);
+        hipLaunchKernelGGL(vg::vg_chain_prep_multi_kernel, dim3(waves), dim3(64), (size_t)64 * widest * sizeof(double), p->stream, d_params, m);
         VG_HIP(hipGetLastError());
     }
     return VG_OK;
