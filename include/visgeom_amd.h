@@ -150,8 +150,7 @@ int vg_problem_add_transform(vg_problem *p, int is_global, int constant, int cou
  *   board: 3*n_points host doubles (initGrid :279-309 / initGridIR :234-250);
  *   image_index[n_images]: index into the sequence transform(s) for each block; images whose
  *     corner list was empty are simply not listed (:520);
- *   corners: [n_images][2*n_points] host doubles, [u0,v0,u1,v1,...] per image; NULL = all zeros (nothing is uploaded): the
- *     residuals of such a dataset are the projections themselves, which is how writeImageResidual (:1186-1292) projects. */
+ *   corners: [n_images][2*n_points] host doubles, [u0,v0,u1,v1,...] per image (NULL with n_images > 0 is an error). */
 int vg_problem_add_dataset(vg_problem *p, int camera_id, int chain_len, const int *transform_ids,
                            const int *status, int n_points, const double *board, int64_t n_images,
                            const int32_t *image_index, const double *corners, int *dataset_id);
@@ -408,6 +407,14 @@ int vg_refine_poses_timed(int device, void *hip_stream, int model, const double 
                           int64_t n_images, const double *corners, double *poses, const vg_solve_options *options,
                           int32_t *iterations, double *final_cost, int32_t *termination, double *kernel_seconds);
 
+/* The same refinement for a dataset that is RESIDENT in a finalized problem (reference flow: estimateInitialGrid
+ * unified_calibration.cpp:1137-1155 refines the poses that addGridResidualBlocks :514-630 then hands to the global problem over
+ * the same corners): the dataset's observations and board and the camera's CURRENT intrinsics are read where they lie in HBM;
+ * only poses [n_blocks][6] (host, in: start, out: result -- camera-frame board poses, independent of the dataset's chain) and
+ * the optional per-image outputs cross the bus, in one copy each way.  kernel_seconds (may be NULL): the launch alone. */
+int vg_dataset_refine_poses(vg_problem *p, int dataset_id, double *poses, const vg_solve_options *options, int32_t *iterations,
+                            double *final_cost, int32_t *termination, double *kernel_seconds);
+
 /* Host-only helper of the solver, exported so the host logic can be tested without a GPU:
  * solves the symmetric positive definite n x n system A x = b (row-major A, untouched) by Cholesky.
  * Returns VG_ERR_NUMERIC when A is not positive definite. */
@@ -449,7 +456,7 @@ typedef struct vg_calibration_timings {
     double read_files_s;        /* reading the JSON files into memory */
     double parse_json_s;        /* JSON text -> values (calibration file, corner / wheel files) */
     double geometric_init_s;    /* 4-corner pose construction (:1066-1135) + getInitTransform (:311-348), host */
-    double refine_total_s;      /* vg_refine_poses calls as seen by the host: staging, H2D, kernel, D2H */
+    double refine_total_s;      /* the per-image refinements as seen by the host: poses up, kernel, results back (corners: corner_upload_s) */
     double refine_kernel_s;     /* ... the vg_pose_lm_kernel launches alone (HIP events) */
     double global_init_s;       /* initGlobalTransform refinements (:358-429): a batched solve per global transform */
     double assemble_s;          /* compute(): problem assembly, uploads, vg_problem_finalize */
@@ -462,6 +469,9 @@ typedef struct vg_calibration_timings {
     int64_t refine_max_iterations; /* the slowest image's iteration count */
     int64_t json_bytes;         /* bytes of JSON text parsed */
     int64_t residual_lines;     /* lines written by write_residuals */
+    double corner_upload_s;     /* gathering the detected corners into pinned staging and their upload into HBM (once per dataset) */
+    int64_t corner_uploads;     /* corner blocks uploaded: one per dataset when every consumer shares it */
+    int64_t corner_upload_bytes;
 } vg_calibration_timings;
 int vg_calibration_get_timings(const vg_calibration *c, vg_calibration_timings *out);
 /* Host-only pieces of the pose initialisation, exported so that they can be checked block by block without a GPU (the

@@ -442,6 +442,9 @@ def test_front_end_phase_clock_and_stereo_file_with_a_global_transform_from_the_
               "readback_s", "residual_eval_s", "residual_format_s"):
         assert t[k] > 0, k
     assert t["refine_kernel_s"] < t["refine_total_s"]
+    # the corners cross the bus once per dataset: camera 1's block is shared by its per-image refinement and the global problem,
+    # camera 2's by the initGlobalTransform sub-problem and the global problem; one more block for the single image that seeds xiCam12
+    assert t["corner_uploads"] == 3 and t["corner_upload_bytes"] == (2 * 60 + 1) * 96 * 16 and t["corner_upload_s"] > 0
     assert t["refine_images"] == 60 + 1 and t["refine_iterations"] >= t["refine_images"] and t["refine_max_iterations"] >= 2
     assert t["residual_lines"] == 2 * 60 * 96 and t["json_bytes"] > 2 * 60 * 96 * 20
     assert rel(c.intrinsics("camera1"), st["gt_intrinsics1"]) < 1e-6 and rel(c.intrinsics("camera2"), st["gt_intrinsics2"]) < 1e-6

@@ -80,3 +80,64 @@ def test_options_and_ragged_sizes():
     for b in range(5):
         ref = scipy_pose("ucm", d["gt_intrinsics"], d["board"][idx], d["corners"][b, idx], start[b])
         assert np.max(np.abs(pN[b] - ref.x)) < 1e-6 and abs(costN[b] - ref.cost) <= 1e-6 * ref.cost
+
+
+@pytest.mark.parametrize("model", ["eucm", "mei"])
+def test_resident_route_gives_the_same_bits_as_the_host_pointer_route(model):
+    """vg_dataset_refine_poses (the dataset's corners, board and the camera's current intrinsics read in HBM) against
+    vg_refine_poses (everything uploaded per call): same kernel, same inputs -> same poses, counts, costs, bit for bit; repeated
+    calls (the library's cached scratch) and a second problem of another size in between do not change them."""
+    from visgeom_amd import CalibrationProblem, synthetic as S
+    from visgeom_amd.calibration import refine_poses
+
+    n = 203   # not a multiple of the 8 images per workgroup
+    d = S.make_mono(model, n, 5)
+    intr = d["gt_intrinsics"] * (1 - 5e-4)
+    start = d["gt_poses"] + np.random.default_rng(11).uniform(-0.02, 0.02, (n, 6))
+    ref = refine_poses(model, intr, d["board"], d["corners"], start)
+    p = CalibrationProblem(0)
+    cam = p.add_camera(model, intr)
+    # the dataset's own chain is irrelevant to the refinement (camera-frame poses): a two-member chain here
+    g = p.add_transform(True, np.array([0.1, 0, 0, 0, 0.01, 0]))
+    seq = p.add_transform(False, start)
+    ds = p.add_dataset(cam, [(g, 1), (seq, 0)], d["board"], d["corners"])
+    p.finalize()
+    for rep in range(3):
+        ks = []
+        got = p.refine_poses(ds, start, kernel_seconds=ks)
+        assert ks[0] > 0
+        for a, b in zip(got, ref):
+            assert a.tobytes() == b.tobytes()
+        if rep == 0:   # another call of another size through the same cached scratch
+            small = refine_poses(model, intr, d["board"], d["corners"][:5], start[:5])
+            assert small[0].tobytes() == ref[0][:5].tobytes()
+    # the intrinsics are the problem's CURRENT ones
+    x = p.get_parameters()
+    x[p.camera_offset(cam):p.camera_offset(cam) + intr.size] = d["gt_intrinsics"]
+    p.set_parameters(x)
+    got2 = p.refine_poses(ds, start)
+    ref2 = refine_poses(model, d["gt_intrinsics"], d["board"], d["corners"], start)
+    assert got2[0].tobytes() == ref2[0].tobytes() and got2[0].tobytes() != ref[0].tobytes()
+    p.close()
+
+
+def test_public_add_dataset_rejects_missing_corners():
+    """corners == NULL with images is an error on the public entry (the zero-observation projection dataset of
+    writeImageResidual is an internal entry)"""
+    import ctypes
+
+    from visgeom_amd import capi, synthetic as S
+
+    L = capi.load()
+    d = S.make_mono("eucm", 3, 1)
+    h = ctypes.c_void_p()
+    capi.check(L.vg_problem_create(ctypes.byref(h), 0, None))
+    cam, seq = ctypes.c_int(-1), ctypes.c_int(-1)
+    dp = ctypes.POINTER(ctypes.c_double)
+    capi.check(L.vg_problem_add_camera(h, 0, d["init_intrinsics"].ctypes.data_as(dp), 0, ctypes.byref(cam)))
+    capi.check(L.vg_problem_add_transform(h, 0, 0, 3, np.ascontiguousarray(d["init_poses"]).ctypes.data_as(dp), ctypes.byref(seq)))
+    tids, st = (ctypes.c_int * 1)(seq.value), (ctypes.c_int * 1)(0)
+    board = np.ascontiguousarray(d["board"])
+    rc = L.vg_problem_add_dataset(h, cam.value, 1, tids, st, board.shape[0], board.ctypes.data_as(dp), 3, None, None, None)
+    assert rc == capi.ERR_INVALID_ARGUMENT and b"corners" in L.vg_last_error()
+    L.vg_problem_destroy(h)

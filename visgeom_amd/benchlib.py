@@ -243,10 +243,10 @@ def section(cfg, reps=200, device=0, images=None, solve_runs=2, comm=None, allre
 # The product entry point end to end: `calib a.json` (test/calibration/generic_calibration.cpp:32-44 -> addResiduals ->
 # compute, unified_calibration.cpp:350-356,39-89) on a generated calibration file, phase by phase.
 
-CALIB_PHASES = ("read_files_s", "parse_json_s", "geometric_init_s", "refine_total_s", "global_init_s", "assemble_s", "solve_s",
+CALIB_PHASES = ("read_files_s", "parse_json_s", "geometric_init_s", "corner_upload_s", "refine_total_s", "global_init_s", "assemble_s", "solve_s",
                 "readback_s", "residual_eval_s", "residual_format_s")
 # phases whose time is GPU work (kernels + the copies they need); the rest is host work
-CALIB_GPU_PHASES = ("refine_total_s", "global_init_s", "solve_s", "residual_eval_s")
+CALIB_GPU_PHASES = ("corner_upload_s", "refine_total_s", "global_init_s", "solve_s", "residual_eval_s")
 
 
 def write_calib_workload(directory, workload, images):
@@ -305,6 +305,7 @@ def calib_e2e(workload="mono_eucm", images=10000, directory=None, runs=2, cli=Tr
             row = {"total_s": total, "phases": {k: tm[k] for k in CALIB_PHASES}, "refine_kernel_s": tm["refine_kernel_s"],
                    "refine_images": tm["refine_images"], "refine_iterations_mean": tm["refine_iterations"] / max(tm["refine_images"], 1),
                    "refine_iterations_max": tm["refine_max_iterations"], "residual_lines": tm["residual_lines"],
+                   "corner_uploads": tm["corner_uploads"], "corner_upload_megabytes": tm["corner_upload_bytes"] / 1e6,
                    "solve": {k: c.summary[k] for k in ("num_iterations", "termination", "final_cost", "total_seconds")},
                    "max_rel_intrinsics_error_vs_generating": max(
                        float(np.max(np.abs(c.intrinsics(name) - g) / np.maximum(np.abs(g), 1.0))) for name, g in info["gt"].items())}
@@ -362,14 +363,32 @@ def pose_init(model="eucm", images=10000, reps=5, device=0, keep_inputs=False):
         capi.check(L.vg_initial_grid_pose(capi.MODELS[model], intr.ctypes.data_as(dp), b4.ctypes.data_as(dp), c4.ctypes.data_as(dp),
                                           start[i].ctypes.data_as(dp)))
     t_geo_py = time.perf_counter() - t0   # through ctypes, one call per image: an upper bound of the host loop in the library
+    # the product route (the calibration front end, a host that owns a vg_problem): the corners are resident in the problem the
+    # poses are for -- vg_dataset_refine_poses moves only the 6-vectors and the per-image results
+    from . import CalibrationProblem
+
+    pr = CalibrationProblem(device)
+    cam = pr.add_camera(model, intr)
+    seq = pr.add_transform(False, start)
+    dsr = pr.add_dataset(cam, [(seq, 0)], board, corners)
+    pr.finalize()
     best, it, kernel_s = None, None, None
     for _ in range(max(1, reps)):
         ks = []
         t0 = time.perf_counter()
-        poses, it, cost, term = refine_poses(model, intr, board, corners, start, device=device, kernel_seconds=ks)
+        poses, it, cost, term = pr.refine_poses(dsr, start, kernel_seconds=ks)
         dt = time.perf_counter() - t0
         best = dt if best is None or dt < best else best
         kernel_s = ks[0] if kernel_s is None or ks[0] < kernel_s else kernel_s
+    pr.close()
+    # the stand-alone entry with everything in host memory (vg_refine_poses): the same launch behind an upload of the corners
+    best_host = None
+    for _ in range(max(1, reps)):
+        t0 = time.perf_counter()
+        poses_h, it_h, _, _ = refine_poses(model, intr, board, corners, start, device=device)
+        dt = time.perf_counter() - t0
+        best_host = dt if best_host is None or dt < best_host else best_host
+    assert np.array_equal(poses_h, poses) and np.array_equal(it_h, it)   # the same kernel on the same inputs
     flops = float(np.sum((it.astype(np.float64) + 1) * N * (EVAL_FLOPS[model] + 2 * 7 * 8)))
     out = {"workload": "%s, %d images x %d corners, start = 4-corner pose at the initial intrinsics" % (model, images, N),
            "kernel": "vg_pose_lm_kernel<%s>" % model, "kernel_ms": kernel_s * 1e3,
@@ -377,7 +396,10 @@ def pose_init(model="eucm", images=10000, reps=5, device=0, keep_inputs=False):
                         "frac": flops / kernel_s / FP64_PEAK,
                         "note": "latency bound: every half-wave runs its image's whole LM (a dependent evaluate -> 32-lane sum -> 6 x 6 "
                                 "Cholesky chain per iteration), a wave lives as long as its slower image"},
-           "refine_call_ms": best * 1e3, "iterations_mean": float(it.mean()), "iterations_p99": float(np.percentile(it, 99)),
+           "refine_call_ms": best * 1e3, "refine_call_route": "vg_dataset_refine_poses: corners resident in the problem; poses up, results back",
+           "refine_call_over_kernel": best / kernel_s,
+           "host_pointer_call_ms": best_host * 1e3, "host_pointer_route": "vg_refine_poses: %.1f MB of corners uploaded from pageable host memory per call" % (corners.nbytes / 1e6),
+           "iterations_mean": float(it.mean()), "iterations_p99": float(np.percentile(it, 99)),
            "iterations_max": int(it.max()), "converged": int(np.sum(term <= 2)), "algorithmic_flops": flops,
            "max_pose_error_vs_generating": float(np.max(np.abs(poses - d["gt_poses"]))),
            "geometric_init_through_ctypes_ms": t_geo_py * 1e3}

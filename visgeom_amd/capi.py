@@ -59,7 +59,8 @@ class CalibrationTimings(ctypes.Structure):
     _fields_ = [(n, ctypes.c_double) for n in ("read_files_s", "parse_json_s", "geometric_init_s", "refine_total_s", "refine_kernel_s",
                                                "global_init_s", "assemble_s", "solve_s", "readback_s", "residual_eval_s",
                                                "residual_format_s")] + \
-               [(n, ctypes.c_int64) for n in ("refine_images", "refine_iterations", "refine_max_iterations", "json_bytes", "residual_lines")]
+               [(n, ctypes.c_int64) for n in ("refine_images", "refine_iterations", "refine_max_iterations", "json_bytes", "residual_lines")] + \
+               [("corner_upload_s", ctypes.c_double), ("corner_uploads", ctypes.c_int64), ("corner_upload_bytes", ctypes.c_int64)]
 
 
 TERMINATION = {0: "CONVERGENCE_FUNCTION", 1: "CONVERGENCE_GRADIENT", 2: "CONVERGENCE_PARAMETER", 3: "NO_CONVERGENCE",
@@ -144,6 +145,7 @@ SIGNATURES = {
                                        ctypes.POINTER(SolveOptions), _i32p, _dp, _i32p]),
     "vg_refine_poses_timed": (ctypes.c_int, [ctypes.c_int, _vp, ctypes.c_int, _dp, ctypes.c_int, _dp, ctypes.c_int64, _dp, _dp,
                                              ctypes.POINTER(SolveOptions), _i32p, _dp, _i32p, _dp]),
+    "vg_dataset_refine_poses": (ctypes.c_int, [_vp, ctypes.c_int, _dp, ctypes.POINTER(SolveOptions), _i32p, _dp, _i32p, _dp]),
     "vg_host_cholesky_solve": (ctypes.c_int, [ctypes.c_int, _dp, _dp, _dp]),
     "vg_calibration_create": (ctypes.c_int, [_vpp, ctypes.c_int]),
     "vg_calibration_destroy": (None, [_vp]),

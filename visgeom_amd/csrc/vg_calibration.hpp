@@ -111,6 +111,9 @@ struct ImageData {  // unified_calibration.h:46-87 (the fields the grid residual
     double sqSize = -1;
     int imageWidth = 0, imageHeight = 0;
     std::vector<std::vector<double>> detectedCornersVec;  // per image: 2N doubles or empty
+    // the corners of every non-empty image, in image order, in HBM: uploaded by the first consumer (the per-image refinement of
+    // estimateInitialGrid, the initGlobalTransform sub-problem or the global problem), shared by all of them (resident_corners)
+    mutable std::shared_ptr<vgi::CornerBlock> resident;
     int getFirstExtractedIdx() const
     {
         size_t i = 0;
@@ -118,19 +121,6 @@ struct ImageData {  // unified_calibration.h:46-87 (the fields the grid residual
         return (int)i;
     }
 };
-
-// the corners of `images` (indices into detectedCornersVec, every one non-empty with 2 N doubles) as one block [image][N][2], copied
-// by the host's threads into memory nobody cleared first (10 000 images: 15 MB; growing a vector by insert() cost 4 ms per use)
-inline std::unique_ptr<double[]> gather_corners(const ImageData &data, const std::vector<int> &images, int N)
-{
-    std::unique_ptr<double[]> out(new double[images.size() * 2 * (size_t)N + 1]);
-    double *dst = out.get();
-    vgpar::parallel_ranges(images.size(), 256, [&](size_t b, size_t e, int) {
-        for (size_t k = b; k < e; k++)
-            std::memcpy(dst + k * 2 * (size_t)N, data.detectedCornersVec[(size_t)images[k]].data(), sizeof(double) * 2 * (size_t)N);
-    });
-    return out;
-}
 
 // Eigen's default stream format of a row vector: the stream's default notation with 6 significant digits (what printf's
 // "%g" prints: vgtext::fmt_g6, vg_text_format.hpp), coefficients right-aligned to the widest one, separated by one space
@@ -208,6 +198,34 @@ struct PhaseClock {
     ~PhaseClock() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
 };
 
+// The dataset's corners in HBM.  `images` = every non-empty image in order (what all three consumers ask for once a sequence
+// is initialised through its first dataset): ONE upload per calibration run, kept with the dataset.  Any other image list (the
+// single image that initialises a global transform; the not-yet-initialised rest of a shared sequence) gets a block of its own.
+inline std::shared_ptr<vgi::CornerBlock> resident_corners(vg_calibration *c, const ImageData &data, const std::vector<int> &images)
+{
+    const int N = (int)data.board.size();
+    bool all = true;
+    size_t k = 0;
+    for (size_t i = 0; i < data.detectedCornersVec.size() && all; i++)
+        if (!data.detectedCornersVec[i].empty()) all = k < images.size() && images[k++] == (int)i;
+    all = all && k == images.size();
+    if (all && data.resident && data.resident->n_images == (int64_t)images.size() && data.resident->N == N && data.resident->device == c->device)
+        return data.resident;
+    PhaseClock clk(c->timings.corner_upload_s);
+    std::shared_ptr<vgi::CornerBlock> blk;
+    const int rc = vgi::upload_corners(c->device, nullptr, (int64_t)images.size(), N, [&](int64_t first, int64_t count, double *dst) {
+        vgpar::parallel_ranges((size_t)count, 256, [&](size_t b, size_t e, int) {
+            for (size_t i = b; i < e; i++)
+                std::memcpy(dst + i * 2 * (size_t)N, data.detectedCornersVec[(size_t)images[(size_t)first + i]].data(), sizeof(double) * 2 * (size_t)N);
+        });
+    }, &blk);
+    if (rc != VG_OK) throw Error{rc, vg_last_error()};
+    c->timings.corner_uploads += 1;
+    c->timings.corner_upload_bytes += (int64_t)(sizeof(double) * 2 * (size_t)N * images.size());
+    if (all) data.resident = blk;
+    return blk;
+}
+
 // One sub-problem on the GPU through the public C ABI: the dataset's chain with a chosen set of constant blocks.
 // Used for the two initial refinements (estimateInitialGrid :1137-1155 and initGlobalTransform :358-429).
 inline void refine_on_gpu(vg_calibration *c, const ImageData &data, const std::vector<int> &images,
@@ -240,12 +258,11 @@ inline void refine_on_gpu(vg_calibration *c, const ImageData &data, const std::v
             chk(vg_problem_add_transform(p, 1, chain_const[l], 1, vals.data(), &tids[l]));
         }
     }
-    std::vector<double> board, corners;
+    std::vector<double> board;
     for (auto &pt : data.board) board.insert(board.end(), pt.begin(), pt.end());
-    for (int img : images) corners.insert(corners.end(), data.detectedCornersVec[(size_t)img].begin(), data.detectedCornersVec[(size_t)img].end());
     int ds = -1;
-    chk(vg_problem_add_dataset(p, cam, (int)chain_names.size(), tids.data(), chain_status.data(), N, board.data(),
-                               (int64_t)images.size(), nullptr, corners.data(), &ds));
+    chk(vgi::problem_add_dataset_resident(p, cam, (int)chain_names.size(), tids.data(), chain_status.data(), N, board.data(),
+                                          (int64_t)images.size(), nullptr, resident_corners(c, data, images), &ds));
     chk(vg_problem_finalize(p));
     vg_solve_options o;
     vg_solve_options_init(&o);
@@ -392,12 +409,17 @@ inline std::vector<Array6d> estimate_initial_grids(vg_calibration *c, const Imag
         for (auto &pt : data.board) board.insert(board.end(), pt.begin(), pt.end());
         poses.reserve(6 * images.size());
         for (int img : images) poses.insert(poses.end(), cam_pose[(size_t)img].begin(), cam_pose[(size_t)img].end());
-        const std::unique_ptr<double[]> corners = gather_corners(data, images, N);   // (a non-empty list has 2 N entries: read_corners)
+        // (a non-empty corner list has 2 N entries: read_corners).  The corners cross the bus here for the first and last time:
+        // the global problem reads the same block (compute()).  Its upload has its own clock (corner_upload_s), taken out of this one.
+        const double up0 = c->timings.corner_upload_s;
+        const std::shared_ptr<vgi::CornerBlock> corners = resident_corners(c, data, images);
+        const double up = c->timings.corner_upload_s - up0;
         std::vector<int32_t> iters(images.size(), 0);
         double kernel_s = 0.;
-        const int rc = vgi::refine_poses(c->device, nullptr, c->cameraModelMap[data.cameraName], c->intrinsicMap[data.cameraName].data(), N,
-                                         board.data(), (int64_t)images.size(), corners.get(), poses.data(), nullptr, iters.data(), nullptr,
-                                         nullptr, &kernel_s);
+        const int rc = vgi::refine_poses_resident(c->device, nullptr, c->cameraModelMap[data.cameraName], nullptr, c->intrinsicMap[data.cameraName].data(), N,
+                                                  nullptr, board.data(), (int64_t)images.size(), corners->d_obs, poses.data(), nullptr, iters.data(), nullptr,
+                                                  nullptr, &kernel_s);
+        c->timings.refine_total_s -= up;
         if (rc != VG_OK) throw Error{rc, vg_last_error()};
         c->timings.refine_kernel_s += kernel_s;
         c->timings.refine_images += (int64_t)images.size();
@@ -943,10 +965,15 @@ int vg_calibration_compute(vg_calibration *c, const vg_solve_options *options, v
         // without images so that dataset ids keep matching dataVec (its residual file is still written afterwards)
         for (size_t i = 0; i < data.detectedCornersVec.size() && !data.doNotSolveGlobal; i++)
             if (!data.detectedCornersVec[i].empty()) idx.push_back((int32_t)i);  // :520
-        const std::unique_ptr<double[]> corners = vgcal::gather_corners(data, std::vector<int>(idx.begin(), idx.end()), (int)data.board.size());
-        if ((rc = vg_problem_add_dataset(p, camId[data.cameraName], (int)tids.size(), tids.data(), data.transStatusVec.data(),
-                                         (int)data.board.size(), board.data(), (int64_t)idx.size(), idx.data(),
-                                         corners.get(), nullptr)) != VG_OK)
+        std::shared_ptr<vgi::CornerBlock> corners;
+        try {   // the block the initialisation uploaded, when there was one; uploaded now otherwise
+            corners = vgcal::resident_corners(c, data, std::vector<int>(idx.begin(), idx.end()));
+        } catch (const vgcal::Error &e) {
+            return bail(e.code);
+        }
+        if ((rc = vgi::problem_add_dataset_resident(p, camId[data.cameraName], (int)tids.size(), tids.data(), data.transStatusVec.data(),
+                                                    (int)data.board.size(), board.data(), (int64_t)idx.size(), idx.data(),
+                                                    corners, nullptr)) != VG_OK)
             return bail(rc);
     }
     for (auto &od : c->odometry) {  // one OdometryPrior per consecutive pair (:790-801), optional anchor (:803-806)
@@ -1133,7 +1160,7 @@ int vg_calibration_write_residuals(vg_calibration *c, int dataset, const char *p
         const int st[1] = {VG_TRANSFORM_DIRECT};
         if ((rc = vg_problem_add_camera(p, c->cameraModelMap[data.cameraName], c->intrinsicMap[data.cameraName].data(), 1, &cam)) == VG_OK &&
             (rc = vg_problem_add_transform(p, 0, 1, (int64_t)n, xi.data(), &seq)) == VG_OK &&
-            (rc = vg_problem_add_dataset(p, cam, 1, &seq, st, N, board.data(), (int64_t)n, nullptr, nullptr, &ds)) == VG_OK &&   // no corners: zero observations
+            (rc = vgi::problem_add_projection_dataset(p, cam, 1, &seq, st, N, board.data(), (int64_t)n, nullptr, &ds)) == VG_OK &&   // zero observations
             (rc = vg_problem_finalize(p)) == VG_OK) {
             // projecting = the residual against zero observations.  One launch into a device block of this call, one copy back
             // (vg_dataset_evaluate_to_host would set up its pinned staging for a problem that lives for one evaluation)

@@ -49,7 +49,8 @@ int check_device(int device)
 void free_dataset(Dataset &d)
 {
     if (d.d_board) (void)hipFree(d.d_board);
-    if (d.d_obs) (void)hipFree(d.d_obs);
+    if (d.d_obs && !d.resident) (void)hipFree(d.d_obs);   // a resident block is freed by its last owner
+    d.resident.reset();
     if (d.d_frames) (void)hipFree(d.d_frames);
     if (d.d_seq) (void)hipFree(d.d_seq);
     if (d.d_failed) (void)hipFree(d.d_failed);
@@ -314,9 +315,12 @@ int vg_problem_add_transform(vg_problem *p, int is_global, int constant, int cou
     return VG_OK;
 }
 
-int vg_problem_add_dataset(vg_problem *p, int camera_id, int chain_len, const int *transform_ids, const int *status,
-                           int n_points, const double *board, int64_t n_images, const int32_t *image_index,
-                           const double *corners, int *dataset_id)
+}  // extern "C"
+
+namespace {
+int add_dataset_common(vg_problem *p, int camera_id, int chain_len, const int *transform_ids, const int *status,
+                       int n_points, const double *board, int64_t n_images, const int32_t *image_index,
+                       const double *corners, const std::shared_ptr<vgi::CornerBlock> &resident, int *dataset_id)
 {
     if (!p) return fail(VG_ERR_INVALID_ARGUMENT, "problem is NULL");
     if (p->finalized) return fail(VG_ERR_STATE, "problem already finalized");
@@ -349,11 +353,44 @@ int vg_problem_add_dataset(vg_problem *p, int camera_id, int chain_len, const in
         d.h_seq[(size_t)i] = (int32_t)idx;
     }
     d.h_board.assign(board, board + 3 * (size_t)n_points);
-    d.zero_obs = corners == nullptr;
-    if (corners) d.h_obs.assign(corners, corners + (size_t)n_images * 2 * n_points);
+    if (resident) {
+        if (resident->device != p->device || resident->N != n_points || resident->n_images < n_images)
+            return fail(VG_ERR_INVALID_ARGUMENT, "the resident corner block does not fit the dataset (device, board size or image count)");
+        d.resident = resident;
+    } else {
+        d.zero_obs = corners == nullptr;
+        if (corners) d.h_obs.assign(corners, corners + (size_t)n_images * 2 * n_points);
+    }
     p->dss.push_back(std::move(d));
     if (dataset_id) *dataset_id = (int)p->dss.size() - 1;
     return VG_OK;
+}
+}  // namespace
+
+// a dataset whose observations are zeros (cleared on the device, nothing uploaded): its residuals are the projections
+// themselves, which is how writeImageResidual (unified_calibration.cpp:1186-1292) projects the board
+int vgi::problem_add_projection_dataset(vg_problem *p, int camera_id, int chain_len, const int *transform_ids, const int *status, int n_points,
+                                        const double *board, int64_t n_images, const int32_t *image_index, int *dataset_id)
+{
+    return add_dataset_common(p, camera_id, chain_len, transform_ids, status, n_points, board, n_images, image_index, nullptr, nullptr, dataset_id);
+}
+
+int vgi::problem_add_dataset_resident(vg_problem *p, int camera_id, int chain_len, const int *transform_ids, const int *status, int n_points,
+                                      const double *board, int64_t n_images, const int32_t *image_index,
+                                      const std::shared_ptr<CornerBlock> &corners, int *dataset_id)
+{
+    if (!corners) return fail(VG_ERR_INVALID_ARGUMENT, "corner block is NULL");
+    return add_dataset_common(p, camera_id, chain_len, transform_ids, status, n_points, board, n_images, image_index, nullptr, corners, dataset_id);
+}
+
+extern "C" {
+
+int vg_problem_add_dataset(vg_problem *p, int camera_id, int chain_len, const int *transform_ids, const int *status,
+                           int n_points, const double *board, int64_t n_images, const int32_t *image_index,
+                           const double *corners, int *dataset_id)
+{
+    if (n_images > 0 && !corners) return fail(VG_ERR_INVALID_ARGUMENT, "corners is NULL");
+    return add_dataset_common(p, camera_id, chain_len, transform_ids, status, n_points, board, n_images, image_index, corners, nullptr, dataset_id);
 }
 
 int vg_problem_add_transformation_prior(vg_problem *p, int transform_id, const double *stiffness)
@@ -499,13 +536,15 @@ int vg_problem_finalize(vg_problem *p)
         const size_t nb = (size_t)d.n_blocks;
         VG_HIP(hipMalloc(&d.d_board, sizeof(double) * 3 * (size_t)d.N));
         VG_HIP(hipMemcpy(d.d_board, d.h_board.data(), sizeof(double) * 3 * (size_t)d.N, hipMemcpyHostToDevice));
-        VG_HIP(hipMalloc(&d.d_obs, sizeof(double) * (nb ? nb : 1) * 2 * d.N));
+        if (d.resident) d.d_obs = d.resident->d_obs;
+        else VG_HIP(hipMalloc(&d.d_obs, sizeof(double) * (nb ? nb : 1) * 2 * d.N));
         VG_HIP(hipMalloc(&d.d_seq, sizeof(int32_t) * (nb ? nb : 1)));
         VG_HIP(hipMalloc(&d.d_frames, sizeof(double) * (nb ? nb : 1) * d.frame_stride));
         VG_HIP(hipMalloc(&d.d_failed, sizeof(unsigned long long)));
         VG_HIP(hipMemset(d.d_failed, 0, sizeof(unsigned long long)));
         if (nb) {
-            if (d.zero_obs) VG_HIP(hipMemset(d.d_obs, 0, sizeof(double) * nb * 2 * d.N));   // a projection dataset: r = proj - 0
+            if (d.resident) {}   // already in HBM (vgi::upload_corners)
+            else if (d.zero_obs) VG_HIP(hipMemset(d.d_obs, 0, sizeof(double) * nb * 2 * d.N));   // a projection dataset: r = proj - 0
             else VG_HIP(hipMemcpy(d.d_obs, d.h_obs.data(), sizeof(double) * nb * 2 * d.N, hipMemcpyHostToDevice));
             VG_HIP(hipMemcpy(d.d_seq, d.h_seq.data(), sizeof(int32_t) * nb, hipMemcpyHostToDevice));
         }

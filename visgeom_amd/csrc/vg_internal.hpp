@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <functional>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -81,6 +83,20 @@ struct ParamBlock {
     std::vector<double> init;
 };
 
+// The corners of one dataset in HBM, uploaded ONCE and shared by everything that reads them: the per-image refinement of
+// estimateInitialGrid, the initGlobalTransform sub-problem and the global problem (vg_calibration.hpp; reference flow
+// unified_calibration.cpp:1137-1155 then :514-630).  Freed with the last owner.
+struct CornerBlock {
+    int device = 0;
+    double *d_obs = nullptr;   // [n_images][N][2]
+    int64_t n_images = 0;
+    int N = 0;
+    CornerBlock() = default;
+    CornerBlock(const CornerBlock &) = delete;
+    CornerBlock &operator=(const CornerBlock &) = delete;
+    ~CornerBlock();
+};
+
 struct Dataset {
     int camera = -1, L = 0, N = 0;
     int tids[vg::kMaxChain] = {0};
@@ -90,6 +106,7 @@ struct Dataset {
     std::vector<int32_t> h_seq;
     bool seq_identity = true;  // image b uses element b of its sequence: no index array needed on the device
     bool zero_obs = false;     // added without corners: the observations are zeros (cleared on the device, nothing uploaded)
+    std::shared_ptr<CornerBlock> resident;   // the observations live in a shared block (d_obs points into it, not owned)
     double *d_board = nullptr, *d_obs = nullptr, *d_frames = nullptr;
     int32_t *d_seq = nullptr;
     unsigned long long *d_failed = nullptr;
@@ -195,4 +212,18 @@ int gram_sum_into(vg_problem *p, int dataset_id, const double *gram, double *sum
 int refine_poses(int device, void *hip_stream, int model, const double *intrinsics, int n_points, const double *board, int64_t n_images,
                  const double *corners, double *poses, const vg_solve_options *options, int32_t *iterations, double *final_cost,
                  int32_t *termination, double *kernel_seconds);
+// the same on observations that already live in HBM (d_obs [n_images][N][2]); intrinsics / board from device pointers or, when
+// those are NULL, from the host arrays (uploaded with the poses in one copy).  locked: the caller holds the scratch mutex.
+int refine_poses_resident(int device, void *hip_stream, int model, const double *d_intr, const double *h_intr, int n_points, const double *d_board,
+                          const double *h_board, int64_t n_images, const double *d_obs, double *poses, const vg_solve_options *options,
+                          int32_t *iterations, double *final_cost, int32_t *termination, double *kernel_seconds, bool locked = false);
+void refine_release_cached();   // the refinement's cached device / pinned blocks (vg_release_cached_memory)
+using GatherFn = std::function<void(int64_t first, int64_t count, double *dst)>;
+int upload_corners(int device, void *hip_stream, int64_t n_images, int n_points, const GatherFn &gather, std::shared_ptr<CornerBlock> *out);
+int problem_add_projection_dataset(vg_problem *p, int camera_id, int chain_len, const int *transform_ids, const int *status, int n_points,
+                                   const double *board, int64_t n_images, const int32_t *image_index, int *dataset_id);
+// vg_problem_add_dataset with the observations taken from a resident block (rows [0, n_images) of it) instead of a host array
+int problem_add_dataset_resident(vg_problem *p, int camera_id, int chain_len, const int *transform_ids, const int *status, int n_points,
+                                 const double *board, int64_t n_images, const int32_t *image_index, const std::shared_ptr<CornerBlock> &corners,
+                                 int *dataset_id);
 }  // namespace vgi

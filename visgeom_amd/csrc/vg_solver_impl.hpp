@@ -99,8 +99,11 @@ extern "C" {
 
 void vg_release_cached_memory(void)
 {
-    std::lock_guard<std::mutex> lk(g_arena_cache.m);
-    g_arena_cache.drop();
+    {
+        std::lock_guard<std::mutex> lk(g_arena_cache.m);
+        g_arena_cache.drop();
+    }
+    vgi::refine_release_cached();
 }
 
 void vg_solve_options_init(vg_solve_options *o)

@@ -347,6 +347,31 @@ class CalibrationProblem:
         capi.check(self._lib.vg_dataset_gram_sum(self._h, d, ctypes.c_void_p(gram.data_ptr()),
                                                  ctypes.c_void_p(out.data_ptr())))
 
+    def refine_poses(self, d, poses, kernel_seconds=None, **options):
+        """estimateInitialGrid's per-image refinement (unified_calibration.cpp:1137-1155) on the dataset's resident corners
+        (vg_dataset_refine_poses): n independent 6-DOF problems in one launch at the camera's current intrinsics.  poses [n, 6]:
+        camera-frame board poses to start from.  Returns (poses, iterations, final_cost, termination)."""
+        n = self.datasets[d]["n_blocks"]
+        out = np.array(poses, dtype=np.float64, order="C").reshape(n, 6)   # one copy: the call works in place
+        it, cost, term = np.empty(n, dtype=np.int32), np.empty(n), np.empty(n, dtype=np.int32)
+        opt = None
+        if options:
+            opt = capi.SolveOptions()
+            self._lib.vg_solve_options_init(ctypes.byref(opt))
+            opt.max_num_iterations, opt.function_tolerance, opt.gradient_tolerance, opt.parameter_tolerance = 500, 1e-6, 1e-10, 1e-8
+            opt.soft_l1_scale = 25.0
+            for k, v in options.items():
+                if not hasattr(opt, k):
+                    raise TypeError("unknown solver option %r" % k)
+                setattr(opt, k, v)
+        ip = ctypes.POINTER(ctypes.c_int32)
+        ks = ctypes.c_double(0.0)
+        capi.check(self._lib.vg_dataset_refine_poses(self._h, d, _ptr(out), ctypes.byref(opt) if opt is not None else None,
+                                                     it.ctypes.data_as(ip), _ptr(cost), term.ctypes.data_as(ip), ctypes.byref(ks)))
+        if kernel_seconds is not None:
+            kernel_seconds[:] = [ks.value]
+        return out, it, cost, term
+
     # -- solve ------------------------------------------------------------------------------
     def solve(self, allreduce=None, comm=None, **options):
         """Levenberg-Marquardt with per-pose Schur elimination; replaces ceres::Solve at
