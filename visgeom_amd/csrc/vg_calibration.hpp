@@ -606,9 +606,31 @@ inline void read_frame_corners(vgjson::Cursor &cur, const std::string &cameraID,
             cur.skip();
             continue;
         }
-        // one {camera, points} entry; keys in any order, the first occurrence of a key counts (as a lookup by name does)
-        bool has_camera = false, has_points = false, is_mine = false;
+        // one {camera, points} entry; keys in any order, the first occurrence of a key counts (as a lookup by name does).  Only the
+        // points of the wanted camera are converted (the reference's readCorners touches no other entry's points): behind a
+        // foreign `camera` they are skipped, in front of the `camera` key their span is kept and read once the entry is ours.
+        bool has_camera = false, has_points = false, is_mine = false, deferred = false;
+        size_t span_b = 0, span_e = 0;
         std::vector<double> pts;
+        auto read_points = [&](vgjson::Cursor &pc) {
+            pts.reserve(2 * n_board);
+            if (pc.peek() != '[') {
+                pc.skip();
+            } else if (pc.open('[', ']')) {
+                do {  // one [u, v, ...] point: the first two values count
+                    int k = 0;
+                    if (pc.peek() != '[') pc.skip();
+                    else if (pc.open('[', ']')) {
+                        do {
+                            if (k < 2) pts.push_back(pc.number());
+                            else (void)pc.number();
+                            k++;
+                        } while (pc.next(']'));
+                    }
+                    if (k < 2) throw std::runtime_error("a corner needs two coordinates");
+                } while (pc.next(']'));
+            }
+        };
         if (cur.open('{', '}')) {
             do {
                 const std::string key = cur.string();
@@ -619,27 +641,21 @@ inline void read_frame_corners(vgjson::Cursor &cur, const std::string &cameraID,
                     is_mine = cur.string() == cameraID;
                 } else if (key == "points" && !has_points) {
                     has_points = true;
-                    pts.reserve(2 * n_board);
-                    if (cur.peek() != '[') {
+                    if (has_camera && is_mine) read_points(cur);
+                    else {
+                        span_b = cur.pos();
                         cur.skip();
-                    } else if (cur.open('[', ']')) {
-                        do {  // one [u, v, ...] point: the first two values count
-                            int k = 0;
-                            if (cur.peek() != '[') cur.skip();
-                            else if (cur.open('[', ']')) {
-                                do {
-                                    if (k < 2) pts.push_back(cur.number());
-                                    else (void)cur.number();
-                                    k++;
-                                } while (cur.next(']'));
-                            }
-                            if (k < 2) throw std::runtime_error("a corner needs two coordinates");
-                        } while (cur.next(']'));
+                        span_e = cur.pos();
+                        deferred = !has_camera;
                     }
                 } else {
                     cur.skip();
                 }
             } while (cur.next('}'));
+        }
+        if (is_mine && deferred) {
+            vgjson::Cursor pc(cur.text(), span_b, span_e);
+            read_points(pc);
         }
         if (!has_camera) throw std::runtime_error("No such node (camera)");
         if (is_mine) {

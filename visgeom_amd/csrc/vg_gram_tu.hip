@@ -107,6 +107,18 @@ unsigned int gram_pers_resident()
 // which shape, by size: none below 4 096 images (less than a round of the one-shot kernel's octets), the eight-wave shape up to
 // 16 384, the four-wave shape beyond (profiles/r05z_gram_pers_probe5.txt; NOTES).  hook gram_persistent: 1 = never,
 // 2 = the four-wave shape whenever it applies, 3 = the eight-wave shape whenever it applies
+// the persistent kernel leaves one partial sum per workgroup: its grid never exceeds this, and the partial buffer is sized from the
+// same constant (the occupancy query is at most ~608 on this part, but nothing tied the two together)
+constexpr unsigned int kPersMaxWorkgroups = 1024;
+
+// doubles of a dataset's per-workgroup partial sums, whichever Gram kernel writes them: one per octet of images (one-shot kernel)
+// or one per workgroup of the persistent grid (at most one per image pair, never more than kPersMaxWorkgroups)
+inline size_t gram_partial_count(int64_t n_blocks)
+{
+    const size_t octets = (size_t)((n_blocks + vg::kValuImagesPerBlock - 1) / vg::kValuImagesPerBlock), n_pairs = ((size_t)n_blocks + 1) / 2;
+    return std::max<size_t>(octets, std::min<size_t>(n_pairs, kPersMaxWorkgroups));
+}
+
 inline int gram_pers_shape(const vg::GramValuArgs &a, bool with_sum)
 {
     const long long hook = vgi::debug_hook(vgi::kHookGramPersistent);
@@ -125,7 +137,7 @@ int launch_gram_valu_pers(hipStream_t stream, const vg::GramValuArgs &a, unsigne
     constexpr int W = vg::CameraTraits<MODEL>::K + 7;
     const unsigned int resident = gram_pers_resident<MODEL, CH, THREADS>();
     if (!resident) return fail(VG_ERR_HIP, "occupancy query of the persistent Gram kernel failed");
-    const unsigned int n_pairs = (a.g.n_blocks + 1) / 2, n_wg = n_pairs < resident ? n_pairs : resident;
+    const unsigned int n_pairs = (a.g.n_blocks + 1) / 2, n_wg = std::min(std::min(n_pairs, resident), kPersMaxWorkgroups);
     vg::GramValuArgs ap = a;
     ap.n_wg = n_wg;
     constexpr size_t lds = vg::gram_valu_pers_lds_bytes<W, THREADS>();
@@ -235,7 +247,7 @@ int vgi::gram_fused_at(vg_problem *p, int dataset_id, const double *d_params, do
         if (sum) {
             // room for either kernel's partials: one per octet (one-shot), one per resident workgroup (persistent: at most one per
             // image pair and never more than 1 024)
-            const size_t n_pairs = ((size_t)d.n_blocks + 1) / 2, n_part = std::max<size_t>(a.n_wg, std::min<size_t>(n_pairs, 1024));
+            const size_t n_part = gram_partial_count(d.n_blocks);
             if (!d.d_wg_partials) VG_HIP(hipMalloc(&d.d_wg_partials, sizeof(double) * (size_t)E * n_part));
             a.partials = d.d_wg_partials;
         }
@@ -382,8 +394,7 @@ int vg_problem_gram_fused_sum(vg_problem *p, double *const *grams, double *const
         Dataset &d = p->dss[i];
         if (!d.n_blocks || d.n_blocks > 0x7fffffff) continue;
         const int W = p->cams[d.camera].K + 6 * d.L + 1, E = W * (W + 1) / 2;
-        const size_t n_wg = (size_t)((d.n_blocks + vg::kValuImagesPerBlock - 1) / vg::kValuImagesPerBlock);
-        const size_t n_pairs = ((size_t)d.n_blocks + 1) / 2, n_part = std::max<size_t>(n_wg, std::min<size_t>(n_pairs, 1024));   // as in gram_fused_at: the buffer is shared
+        const size_t n_part = gram_partial_count(d.n_blocks);   // as in gram_fused_at: the buffer is shared
         if (!d.d_wg_partials) VG_HIP(hipMalloc(&d.d_wg_partials, sizeof(double) * (size_t)E * n_part));
         parts[(size_t)i] = d.d_wg_partials;
     }

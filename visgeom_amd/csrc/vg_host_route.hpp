@@ -107,6 +107,18 @@ extern "C" int vg_dataset_evaluate_to_host(vg_problem *p, int dataset_id, double
     const bool inline_chain = single_launch_dataset(p, d);
     if (!inline_chain && (rc = vgi::ensure_frames(p)) != VG_OK) return rc;
     hipStream_t cs = d.host_copy_stream;
+    // From the first launch on, a failure must not return while copies into the caller's arrays (or the staging the next call
+    // reuses) are still queued: whichever way the function is left, both streams are drained first.
+    struct Drain {
+        hipStream_t a, b;
+        bool armed;
+        ~Drain()
+        {
+            if (!armed) return;
+            (void)hipStreamSynchronize(a);
+            (void)hipStreamSynchronize(b);
+        }
+    } drain{p->stream, cs, true};
     // queue everything: evaluate chunk k, mark it, copy it behind the mark
     size_t off = 0;  // doubles into the staging blocks
     for (int k = 0; k < n_chunks; k++) {
@@ -151,6 +163,7 @@ extern "C" int vg_dataset_evaluate_to_host(vg_problem *p, int dataset_id, double
     }
     if (direct) {
         VG_HIP(hipStreamSynchronize(cs));
+        drain.armed = false;   // the copy stream waited for every launch: nothing is in flight
         return VG_OK;
     }
     // the host's threads move chunk k into the caller's arrays while chunk k + 1 is on the bus
@@ -189,5 +202,6 @@ extern "C" int vg_dataset_evaluate_to_host(vg_problem *p, int dataset_id, double
         });
         off += chunk_doubles;
     }
+    drain.armed = false;   // every chunk's copy event has been waited for
     return VG_OK;
 }

@@ -214,6 +214,7 @@ class Cursor {
 public:
     Cursor(const char *text, size_t begin, size_t end) : s(text), i(begin), n(end) {}
     size_t pos() const { return i; }
+    const char *text() const { return s; }   // with pos(): a span to come back to (Cursor(text(), begin, end))
     bool at_end()
     {
         ws();
