@@ -316,7 +316,10 @@ def test_corner_file_is_read_exactly_and_frames_keep_their_order(tmp_path, n_fra
     skip = {3, 17, n_frames - 1}
     frames = []
     for i in range(n_frames):
-        fr = [{"camera": "other", "points": [[1.0, 2.0]], "extra": {"a": [1, {"b": "]"}], "s": 'x"y\\'}}]
+        # entries of other cameras: their points are never converted (readCorners only touches the matching entry), whether the
+        # `points` key stands behind or in front of `camera` -- a one-coordinate corner / a non-number there is not an error
+        fr = [{"camera": "other", "points": [[1.0, 2.0], [3.0]], "extra": {"a": [1, {"b": "]"}], "s": 'x"y\\'}},
+              {"points": [["u", None]], "camera": "another"}]
         if i not in skip:
             fr.append({"points": d["corners"][i].tolist(), "note": "first", "camera": "cam"})   # keys in another order
             fr.append({"camera": "cam", "points": (d["corners"][i] + 1).tolist()})                # a second match is ignored

@@ -221,7 +221,11 @@ __global__ __launch_bounds__(kSchurThreads * kSchurMaxBatches) void vg_schur_row
                                                                             int shared_gather)
 {
     extern __shared__ __attribute__((aligned(16))) double sm_rows[];  // [batches * poses_per_wg * 6][C + 1] (odd-ish stride)
+#ifdef VG_SCHUR_EVEN_STRIDE   // A/B library: the stride before round 6
     const int C = a.G + 1, CS = C + 1, tid = threadIdx.x % kSchurThreads;
+#else
+    const int C = a.G + 1, CS = C | 1, tid = threadIdx.x % kSchurThreads;   // odd row stride (the LDS is sized for C + 1): with C = 7 a stride of 8 doubles put every fourth row on the same banks
+#endif
     const int pl = tid / C, gcol = tid - pl * C;        // pose of the batch, column
     const bool lane_on = pl < poses_per_wg;
     // every batch has its own 256 lanes (blockDim.x = kSchurThreads * batches): the chains pose -> reference list -> Gram
