@@ -139,7 +139,35 @@ def cpu_baseline(d, model, budget_s):
         affinity = len(os.sched_getaffinity(0))
     except (AttributeError, OSError):
         affinity = None
+    # physical cores of the host (sockets x cores per socket from /proc/cpuinfo): what "all host cores" would be without the
+    # container's CPU quota.  The extrapolation is LINEAR in the measured single-thread rate -- an upper bound for this port (no
+    # memory-bandwidth or turbo derating), stated so that the quota-bound ratio is never quoted alone.
+    phys = None
+    try:
+        ids = set()
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                pid = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                cid = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if pid is not None and cid is not None:
+                    ids.add((pid, cid))
+                pid = cid = None
+        phys = len(ids) or None
+    except OSError:
+        phys = None
+    quota = None
+    try:
+        q, per = (_cgroup_cpu_max() or "").split()[:2]
+        quota = None if q == "max" else float(q) / float(per)
+    except (ValueError, AttributeError):
+        quota = None
     return {"value": vc, "unit": "evals/s", "cores": cores, "kind": "port",
+            "cgroup_cpu_quota_cpus": quota, "physical_cores": phys,
+            "extrapolated_all_physical_cores": {"value": v1 * phys, "unit": "evals/s", "cores": phys,
+                                                "how": "single_thread_value x physical cores, linear (an upper bound: no memory-bandwidth or clock derating)"} if phys else None,
             # the count actually used next to what the box offers -- logical CPUs (hardware_concurrency), the CPUs
             # this process may run on, OpenMP's own maximum; `cores` = the threads of the leg reported as `value`
             "hardware_concurrency": os.cpu_count(), "cpus_allowed": affinity, "omp_max_threads": omp_max,
@@ -910,7 +938,10 @@ def main():
            [k for k in ("config3_stereo", "config5_rig", "eucm_100k", "emit_sweep", "calib_e2e", "pose_init") if k in out]}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(d, a.model, a.cpu_seconds)
-        out["gpu_over_cpu_allcores"] = value / out["cpu_baseline"]["value"]
+        out["gpu_over_cpu_allcores"] = value / out["cpu_baseline"]["value"]   # against the threads the box's quota grants (cpu_baseline.cores)
+        ex = out["cpu_baseline"].get("extrapolated_all_physical_cores")
+        if ex:   # the same ratio against every physical core of the host, by linear extrapolation of the measured per-thread rate
+            out["gpu_over_cpu_extrapolated_all_physical_cores"] = value / ex["value"]
     p.close()
     if comm is not None:
         comm.close()
