@@ -10,14 +10,15 @@ namespace {
 
 // ---- memory of the refinement calls, kept by the library between calls (vg_release_cached_memory) -----------------------------
 // Round 5's wrapper paid eight hipMalloc + eight hipFree, five pageable uploads and four read-backs around a 0.25 ms kernel
-// (call 1.0 ms).  Now: ONE device block and ONE pinned block, grow-only, laid out [next | intr | board | poses | cost | it | term]
-// so that the inputs are ONE upload of the front and the results ONE read-back of the tail (the poses sit where the two overlap),
-// two events made once, and -- for callers whose corners already live in HBM (a vg_problem's dataset, the calibration front
-// end's CornerBlock) -- no observation traffic at all.
+// (call 1.0 ms).  Now: ONE device block [next | intr | board] and ONE pinned block [next | intr | board | poses | cost | it | term],
+// grow-only, two events made once.  The small front is ONE upload; the per-image data -- a 6-vector read once at the start of an
+// image's solve, 6 + 3 values written once at its end -- is read and written by the kernel IN the pinned block (mapped host
+// memory): no copy in either direction, the results are there when the stream is idle.  For callers whose corners already live in
+// HBM (a vg_problem's dataset, the calibration front end's CornerBlock) there is no observation traffic at all.
 struct RefineScratch {
     int device = -1;
-    char *dev = nullptr, *pin = nullptr;
-    size_t cap = 0;
+    char *dev = nullptr, *pin = nullptr, *pin_dev = nullptr;   // pin_dev: the pinned block as the device addresses it
+    size_t cap = 0, dev_cap = 0;
     double *d_obs = nullptr;   // the host-pointer entry's observations (grow-only)
     size_t obs_cap = 0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -39,19 +40,26 @@ struct RefineScratch {
 std::mutex g_refine_m;
 RefineScratch g_refine;
 
-int refine_scratch_for(int device, size_t bytes, size_t obs_bytes)
+int refine_scratch_for(int device, size_t bytes, size_t obs_bytes, size_t front_bytes = 0)
 {
     RefineScratch &r = g_refine;
     if (r.device != device) r.drop();
     r.device = device;
-    if (bytes > r.cap) {
+    if (front_bytes > r.dev_cap) {   // the device block holds the front only: counter, intrinsics, board
         if (r.dev) (void)hipFree(r.dev);
+        r.dev = nullptr;
+        r.dev_cap = 0;
+        const size_t want = front_bytes < 64 * 1024 ? (size_t)64 * 1024 : front_bytes * 2;
+        VG_HIP(hipMalloc(&r.dev, want));
+        r.dev_cap = want;
+    }
+    if (bytes > r.cap) {
         if (r.pin) (void)hipHostFree(r.pin);
-        r.dev = r.pin = nullptr;
+        r.pin = r.pin_dev = nullptr;
         r.cap = 0;
         const size_t want = bytes + bytes / 4 + 4096;
-        VG_HIP(hipMalloc(&r.dev, want));
-        VG_HIP(hipHostMalloc(&r.pin, want, hipHostMallocDefault));
+        VG_HIP(hipHostMalloc(&r.pin, want, hipHostMallocMapped));
+        VG_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&r.pin_dev), r.pin, 0));
         r.cap = want;
     }
     if (obs_bytes > r.obs_cap) {
@@ -170,22 +178,22 @@ int vgi::refine_poses_resident(int device, void *hip_stream, int model, const do
     const size_t o_next = 0, o_intr = 256, o_board = o_intr + up256(sizeof(double) * K), o_poses = o_board + up256(sizeof(double) * 3 * N),
                  o_cost = o_poses + up256(sizeof(double) * 6 * n), o_it = o_cost + up256(sizeof(double) * n), o_term = o_it + up256(sizeof(int) * n),
                  total = o_term + up256(sizeof(int) * n);
-    const int rcs = refine_scratch_for(device, total, 0);
+    const int rcs = refine_scratch_for(device, total, 0, o_poses);
     if (rcs != VG_OK) return rcs;
     RefineScratch &r = g_refine;
     *reinterpret_cast<unsigned int *>(r.pin + o_next) = 0u;
     if (!d_intr) std::memcpy(r.pin + o_intr, h_intr, sizeof(double) * K);
     if (!d_board) std::memcpy(r.pin + o_board, h_board, sizeof(double) * 3 * N);
     std::memcpy(r.pin + o_poses, poses, sizeof(double) * 6 * n);
-    VG_HIP(hipMemcpyAsync(r.dev, r.pin, o_cost, hipMemcpyHostToDevice, st));   // everything in front of the results: ONE copy
+    VG_HIP(hipMemcpyAsync(r.dev, r.pin, o_poses, hipMemcpyHostToDevice, st));   // counter, intrinsics, board: ONE small copy
     vg::PoseLmArgs a;
     a.board = d_board ? d_board : reinterpret_cast<const double *>(r.dev + o_board);
     a.obs = d_obs;
     a.intr = d_intr ? d_intr : reinterpret_cast<const double *>(r.dev + o_intr);
-    a.poses = reinterpret_cast<double *>(r.dev + o_poses);
-    a.iterations = reinterpret_cast<int *>(r.dev + o_it);
-    a.final_cost = reinterpret_cast<double *>(r.dev + o_cost);
-    a.termination = reinterpret_cast<int *>(r.dev + o_term);
+    a.poses = reinterpret_cast<double *>(r.pin_dev + o_poses);   // mapped host memory: read once, written once per image
+    a.iterations = iterations ? reinterpret_cast<int *>(r.pin_dev + o_it) : nullptr;
+    a.final_cost = final_cost ? reinterpret_cast<double *>(r.pin_dev + o_cost) : nullptr;
+    a.termination = termination ? reinterpret_cast<int *>(r.pin_dev + o_term) : nullptr;
     a.next = reinterpret_cast<unsigned int *>(r.dev + o_next);
     a.n_images = (unsigned int)n_images;
     a.N = (unsigned int)n_points;
@@ -233,10 +241,7 @@ int vgi::refine_poses_resident(int device, void *hip_stream, int model, const do
     }
     VG_HIP(hipGetLastError());
     if (kernel_seconds) VG_HIP(hipEventRecord(r.e1, st));
-    // poses, and whatever else the caller asked for, in ONE read-back (the segments are consecutive)
-    const size_t back_end = termination ? total : iterations ? o_term : final_cost ? o_it : o_cost;
-    VG_HIP(hipMemcpyAsync(r.pin + o_poses, r.dev + o_poses, back_end - o_poses, hipMemcpyDeviceToHost, st));
-    VG_HIP(hipStreamSynchronize(st));
+    VG_HIP(hipStreamSynchronize(st));   // the kernel's stores to the mapped block are visible once the stream is idle
     std::memcpy(poses, r.pin + o_poses, sizeof(double) * 6 * n);
     if (iterations) std::memcpy(iterations, r.pin + o_it, sizeof(int) * n);
     if (final_cost) std::memcpy(final_cost, r.pin + o_cost, sizeof(double) * n);
