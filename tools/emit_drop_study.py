@@ -401,3 +401,26 @@ if "multi" in sections:
         p.close()
         del f
         torch.cuda.empty_cache()
+
+if "headline" in sections:
+    print("== headline: 10 k images (inside the Infinity Cache), contiguous eighths (hook -1) against windows W = 16 / 4 / 64, 400 launches each, alternating")
+    for model in ("eucm", "mei"):
+        dm = synthetic.make_mono(model, 10000, 1)
+        p = CalibrationProblem(0)
+        cam = p.add_camera(model, dm["init_intrinsics"])
+        seq = p.add_transform(False, dm["init_poses"])
+        ds = p.add_dataset(cam, [(seq, 0)], dm["board"], dm["corners"])
+        p.finalize()
+        p.prepare()
+        res, ji, jm = p.alloc_outputs(ds)
+        nb = 10000 * N_CORNERS * emit_bytes_per_obs(model, 1)
+        for rep in range(5):
+            cells = []
+            for W in (-1, 16, 4, 64):
+                capi.debug_set("emit_map_window", W)
+                series(lambda: p.evaluate_dataset(ds, res, ji, jm), 50)
+                t = timed(lambda: p.evaluate_dataset(ds, res, ji, jm), 400)
+                cells.append("%s %.2f us (%.3f)" % ("eighths" if W < 0 else "W=%d" % W, t * 1e6, nb / t / HBM_PEAK))
+            print("  %s: %s" % (model, "  ".join(cells)), flush=True)
+        capi.debug_set("emit_map_window", 0)
+        p.close()

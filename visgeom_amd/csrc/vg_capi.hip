@@ -102,6 +102,17 @@ int64_t emit_nt_min_bytes()
     return h ? (int64_t)h : (int64_t)230000000;
 }
 
+// Tile map of an emit launch by its output: one contiguous eighth per XCD while the launch stays inside or near the Infinity Cache
+// (<= 1.2 GB: same box, alternating, the eighths are level with the windows for EUCM and 2 % ahead for Mei at 10 k images,
+// profiles/r06l_headline_map_ab.txt), windows of 8 x kEmitMapWindow tiles beyond, where the eighths fall into their slow mode on
+// most boxes (from ~1.6 GB; profiles/r06_emit_drop.md).  hook emit_map_window: W > 0 that window, -1 the eighths, whatever the size.
+unsigned int emit_map_window(int64_t launch_output_bytes)
+{
+    const long long mw = vgi::debug_hook(vgi::kHookEmitMapWindow);
+    if (mw) return mw > 0 ? (unsigned int)mw : 0u;
+    return launch_output_bytes >= (int64_t)1200000000 ? vg::kEmitMapWindow : 0u;
+}
+
 int64_t emit_output_bytes(const vg::EmitArgs &a, int K)
 {
     int64_t per_obs = 16;
@@ -180,8 +191,7 @@ void fill_emit_args_at(const vg_problem *p, const Dataset &d, vg::EmitArgs &a, i
     a.seq_index = d.seq_identity ? nullptr : d.d_seq + b0;
     a.first_block = b0;
     a.nt_stores = emit_output_bytes(a, cam.K) >= emit_nt_min_bytes() ? 1 : 0;  // a merged launch decides for all its datasets together
-    const long long mw = vgi::debug_hook(vgi::kHookEmitMapWindow);   // hook: W > 0 that window, -1 contiguous eighths, 0 the default
-    a.map_window = mw > 0 ? (unsigned int)mw : mw < 0 ? 0u : vg::kEmitMapWindow;
+    a.map_window = emit_map_window(emit_output_bytes(a, cam.K));   // likewise
 }
 
 // the same with whole-dataset arrays: block b0's rows lie b0 blocks into each of them
@@ -795,7 +805,10 @@ int vg_problem_evaluate(vg_problem *p, const vg_dataset_outputs *outs)
         {   // one store policy for the whole launch: its datasets share the Infinity Cache
             int64_t launch_bytes = 0;
             for (int k = 0; k < m.n; k++) launch_bytes += emit_output_bytes(m.ds[k], p->cams[p->dss[shared[g0 + k]].camera].K);
-            for (int k = 0; k < m.n; k++) m.ds[k].nt_stores = launch_bytes >= emit_nt_min_bytes() ? 1 : 0;
+            for (int k = 0; k < m.n; k++) {
+                m.ds[k].nt_stores = launch_bytes >= emit_nt_min_bytes() ? 1 : 0;
+                m.ds[k].map_window = emit_map_window(launch_bytes);
+            }
         }
         // pieces of equal bytes per XCD: a tile of dataset k weighs its bytes per observation -- once the pass is large
         // enough to be bound by the write stream (past the 256 MiB Infinity Cache); a small pass (a stereo pair: 104 MB in

@@ -284,7 +284,7 @@ __device__ __forceinline__ unsigned int xcd_contiguous_block(unsigned int b, uns
 // on the same box and arrays; where the eighths run at full rate, 341 us, the windows give 344 us); inside the Infinity Cache
 // the maps do not differ.  The counters say it is the DRAM side: no address-translation misses (TCP_UTCL1_TRANSLATION_MISS
 // 1e3 of 4e7 requests), FEWER L2 -> fabric credit stalls and fewer writes in flight than at 1 GB, i.e. requests retire slower.
-constexpr unsigned int kEmitMapWindow = 16;   // runs of 16 tiles: 384 KiB of a 6-column Jacobian array per die and window
+constexpr unsigned int kEmitMapWindow = 16;   // runs of 16 tiles: 384 KiB of a 6-column Jacobian array per die and window (launches >= 1.2 GB: emit_map_window, vg_capi.hip)
 __device__ __forceinline__ unsigned int xcd_window_block(unsigned int b, unsigned int n, unsigned int W)
 {
     const unsigned int x = b & 7u, j = b >> 3, w = j / W, i = j - w * W, base = w * 8u * W, rem = n - base;
