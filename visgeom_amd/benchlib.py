@@ -73,9 +73,19 @@ def emit_sweep(d, model, sizes, device=0, reps=60):
 
         nbytes = n * N_CORNERS * emit_bytes_per_obs(model, 1)
         r = max(12, min(reps, int(60e9 / nbytes)))
-        for _ in range(30):
-            emit()
-        t_step, t_emit = timed(step, r), timed(emit, r)
+        # warm-up by TIME: the first ~10 ms of launches after the host-side set-up run up to 10 % slower (clock ramp: launches 8-16
+        # of a 100 k-image series, profiles/r06b_emit_ramp.txt) -- with 30 launches only, the first of the two measurements of a
+        # mid-size point (20 k - 25 k images) fell into it
+        import time as _time
+
+        import torch
+
+        t0 = _time.perf_counter()
+        while _time.perf_counter() - t0 < 0.025:
+            for _ in range(10):
+                emit()
+            torch.cuda.synchronize()
+        t_emit, t_step = timed(emit, r), timed(step, r)
         one = capi.load().vg_dataset_single_launch(p._h, ds) == 1
         out_mb = n * N_CORNERS * 16 * (K + 7) / 1e6
         rows.append({"images": n, "output_MB": out_mb, "route": "inline-chain" if one else "prep + emit",
@@ -85,8 +95,6 @@ def emit_sweep(d, model, sizes, device=0, reps=60):
                                "cache-assisted (part of every launch is overwritten in the Infinity Cache by the next)" if out_mb < 1700 else "DRAM streaming"})
         p.close()
         del res, ji, jm
-        import torch
-
         torch.cuda.empty_cache()
     return rows
 
