@@ -676,7 +676,8 @@ int vgi::prepare_at(vg_problem *p, const double *d_params)
             widest = m.ds[k].frame_stride_d > widest ? m.ds[k].frame_stride_d : widest;
         }
         for (int k = m.n; k <= vg::kPrepMax; k++) m.first_wave[k] = waves;
-        hipLaunchKernelGGL(vg::vg_chain_prep_multi_kernel, dim3(waves), dim3(64), (size_t)64 * widest * sizeof(double), p->stream, d_params, m);
+        m.staged = waves >= vg::kPrepStagedMinWaves ? 1 : 0;
+        hipLaunchKernelGGL(vg::vg_chain_prep_multi_kernel, dim3(waves), dim3(64), m.staged ? (size_t)64 * widest * sizeof(double) : (size_t)0, p->stream, d_params, m);
         VG_HIP(hipGetLastError());
     }
     return VG_OK;

@@ -66,7 +66,9 @@ struct PrepMultiArgs {
     PrepDataset ds[kPrepMax];
     unsigned int first_wave[kPrepMax + 1];  // first wave (= 64-thread workgroup) of each dataset in this launch
     int n;
+    int staged;   // 1: the frames leave through LDS as linear 16-byte stores (launches of >= kPrepStagedMinWaves waves: bandwidth matters)
 };
+constexpr unsigned int kPrepStagedMinWaves = 512;   // 32 768 images
 
 #ifdef VG_TU_CORE  // this kernel is launched by one translation unit only; the others see the header without it
 // problems of more than kPrepMax datasets: the descriptors in a table in global memory, one lane per block across all datasets
@@ -87,9 +89,10 @@ __global__ __launch_bounds__(64) void vg_chain_prep_table_kernel(const double *_
                 D->frames + b * D->frame_stride_d);
 }
 
-// The wave's 64 frames are staged in LDS (dynamic: 64 x the launch's widest frame) and leave as one linear run of 16-byte
-// stores: written by the lanes themselves -- every lane its own 264-byte frame -- the kernel ran at 1.3 TB/s and cost 20 us per
-// 100 k images, 214 us at 1 M (gpurun_out/r06g).  All members' parameters are requested in one round in front of the walk.
+// All members' parameters are requested in one round in front of the walk.  Large launches (m.staged): the wave's 64 frames are
+// staged in LDS (dynamic: 64 x the launch's widest frame) and leave as one linear run of 16-byte stores -- written by the lanes
+// themselves, every lane its own 264-byte frame, the kernel ran at 1.3 TB/s and cost 20 us per 100 k images, 214 us at 1 M
+// (now 13 / 67 us; profiles/r06_emit_drop.md).
 __global__ __launch_bounds__(64) void vg_chain_prep_multi_kernel(const double *__restrict__ params, PrepMultiArgs m)
 {
     using d2 = HIP_vector_type<double, 2>;
@@ -111,17 +114,26 @@ __global__ __launch_bounds__(64) void vg_chain_prep_multi_kernel(const double *_
 #pragma unroll
                 for (int k = 0; k < 6; k++) xi[l][k] = src[k];
             }
-        double *frame = prep_tile + threadIdx.x * stride;
-        ChainState s;   // build_frame(), its member loop unrolled over the preloaded members
-        chain_state_init(s);
+        auto walk = [&](double *frame) {   // build_frame(), its member loop unrolled over the preloaded members
+            ChainState s;
+            chain_state_init(s);
 #pragma unroll
-        for (int l = 0; l < kMaxChain; l++)
-            if (l < L) {
-                const Quat q1 = chain_acc_quat(s);
-                chain_walk_member(s, q1, xi[l], D.chain.status[l] != 0, frame + 12 + 21 * l);
-            }
-        chain_finish(s, frame);
+            for (int l = 0; l < kMaxChain; l++)
+                if (l < L) {
+                    const Quat q1 = chain_acc_quat(s);
+                    chain_walk_member(s, q1, xi[l], D.chain.status[l] != 0, frame + 12 + 21 * l);
+                }
+            chain_finish(s, frame);
+        };
+        // small launches (a stereo pair's 64 waves, a rig's 316) are pure latency: their lanes store their frames themselves, as
+        // before round 6 -- the LDS round trip would only add to the dependent chain (7.0 -> 7.6 us for the stereo pair)
+        if (!m.staged) {
+            walk(D.frames + b * stride);
+            return;
+        }
+        walk(prep_tile + threadIdx.x * stride);
     }
+    if (!m.staged) return;
     // one wave per workgroup: LDS executes its DS operations in order, only the compiler needs the fence
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
