@@ -141,3 +141,21 @@ def test_public_add_dataset_rejects_missing_corners():
     rc = L.vg_problem_add_dataset(h, cam.value, 1, tids, st, board.shape[0], board.ctypes.data_as(dp), 3, None, None, None)
     assert rc == capi.ERR_INVALID_ARGUMENT and b"corners" in L.vg_last_error()
     L.vg_problem_destroy(h)
+
+
+def test_cached_scratch_survives_release_and_growth():
+    """the refinement's device / pinned blocks are kept between calls and handed back by vg_release_cached_memory: a call after the
+    release, a larger call (the blocks grow) and a smaller one again give the bits of the first call"""
+    import visgeom_amd
+    from visgeom_amd import synthetic as S
+    from visgeom_amd.calibration import refine_poses
+
+    d = S.make_mono("ucm", 300, 4)
+    start = d["gt_poses"] + 0.01
+    a = refine_poses("ucm", d["gt_intrinsics"], d["board"], d["corners"][:40], start[:40])
+    visgeom_amd.release_cached_memory()
+    b = refine_poses("ucm", d["gt_intrinsics"], d["board"], d["corners"][:40], start[:40])
+    big = refine_poses("ucm", d["gt_intrinsics"], d["board"], d["corners"], start)
+    c = refine_poses("ucm", d["gt_intrinsics"], d["board"], d["corners"][:40], start[:40])
+    for x, y, z, w in zip(a, b, c, big):
+        assert x.tobytes() == y.tobytes() == z.tobytes() == w[:40].tobytes()
