@@ -823,7 +823,7 @@ def main():
             traffic_b = None
         return {"workload": "%s mono, %d images x %d corners on this GPU: %.2f GB of output per step (beyond the 256 MiB Infinity Cache)" % (model_b.upper(), n_b, N, nb / 1e9),
                 "step_ms": t_step * 1e3, "evals_per_s": n_b * N / t_step,
-                "launches": "one launch" if one else "vg_chain_prep_kernel + vg_emit_kernel on prepared frames",
+                "launches": "one launch" if one else "vg_chain_prep_multi_kernel + vg_emit_kernel on prepared frames",
                 "roofline": {"bound": "hbm", "kernel": "vg_emit_kernel<%s,jac,frames-in-LDS%s>" % (model_b, ",inline-chain" if one else ""),
                              "achieved": nb / t_emit / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nb / t_emit / 1e9 / HBM_PEAK_GBS,
                              "frac_whole_step": nb / t_step / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": nb,

@@ -63,7 +63,7 @@ def test_library_is_hip_code_for_gfx950():
     _build.build()
     blob = open(_build.LIB, "rb").read()
     assert b"gfx950" in blob, "no gfx950 code object inside the shared library"
-    assert b"vg_emit_kernel" in blob and b"vg_chain_prep_kernel" in blob
+    assert b"vg_emit_kernel" in blob and b"vg_chain_prep_multi_kernel" in blob
 
 
 def test_static_facts(lib):

@@ -1,6 +1,6 @@
 // vg_kernels.hpp -- HIP kernels of the residual / Jacobian hot path (gfx950, wave64).
 //
-//   kernel 1  vg_chain_prep_kernel   one lane per residual block (image): transform chain -> frame
+//   kernel 1  vg_chain_prep_multi_kernel   one lane per residual block (image) of every dataset: transform chain -> frame
 //   kernel 2  vg_emit_kernel         one lane per (image, corner) observation: residual pair +
 //                                    the 2 x (K + 6L) Jacobian rows, written in the Ceres block layout
 //
@@ -27,24 +27,10 @@ struct ChainDesc {
 };
 
 // ------------------------------------------------------------------------------------------
-// kernel 1: chain prep.  64-thread workgroups so that 10 k images spread over ~157 CUs with one
-// wave each: the kernel is latency bound (a dependent chain of sqrt / sincos / atan2 / divisions),
-// not throughput bound.
+// kernel 1: chain prep (vg_chain_prep_multi_kernel below; a table variant for problems of more than kPrepMax datasets).  64-thread
+// workgroups so that 10 k images spread over ~157 CUs with one wave each: the small launches are latency bound (a dependent
+// chain of sqrt / sincos / divisions), the large ones (>= 512 waves) bandwidth bound on their frame stores.
 // ------------------------------------------------------------------------------------------
-#ifdef VG_TU_CORE  // this kernel is launched by one translation unit only; the others see the header without it
-__global__ __launch_bounds__(64) void vg_chain_prep_kernel(const double *__restrict__ params, ChainDesc cd,
-                                                            const int *__restrict__ seq_index, long long n_blocks,
-                                                            double *__restrict__ frames, int frame_stride_d)
-{
-    const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= n_blocks) return;
-    const long long si = seq_index ? (long long)seq_index[b] : b;
-    // the frame is written straight to global memory (fire-and-forget stores, no scratch array)
-    build_frame(cd.L, cd.status, [&](int l) { return params + cd.base[l] + cd.stride[l] * si; },
-                frames + b * frame_stride_d);
-}
-#endif
-
 // all datasets of a problem in ONE launch: the kernel is latency bound, so four datasets cost the same ~7 us as one
 struct PrepDataset {
     ChainDesc chain;
