@@ -45,7 +45,7 @@ def make_problem(d, n, first=0):
     seq = p.add_transform(False, d["init_poses"][first:first + n])
     ds = p.add_dataset(cam, [(seq, 0)], d["board"], d["corners"][first:first + n])
     p.finalize()
-    p.force_prepared_frames(True)   # prep + emit at every size (the route of >= 600 MB launches)
+    p.force_prepared_frames(True)   # prep + emit at every size (the route of the DRAM-streaming launches)
     p.prepare()
     return p, ds
 

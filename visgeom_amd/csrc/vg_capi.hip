@@ -84,14 +84,16 @@ size_t emit_lds_bytes(bool want_jac, bool frames_lds, int N, int frame_stride)
 }
 
 // Largest evaluation (bytes of residuals + Jacobian rows + observations per launch) for which the emit kernel walks a
-// single-member chain itself.  The in-kernel walk saves the ~6.5 us chain-prep launch and costs the store stream a little per
-// workgroup; with the non-temporal output stores of round 5 the walk wins up to ~30 k EUCM images (step, same box,
-// profiles/r05c_emit_sweep_ab.txt: 20 k images 68.0 vs 75.5 us, 25 k 90.8 vs 92.7, 35 k 128.0 vs 127.0, 50 k 176.8 vs 172.7).
-// (Rounds 3-4, plain stores: the crossover sat at the 256 MiB Infinity Cache, 288 MB.)  tools/exp/emit_sweep_probe.py
+// single-member chain itself.  The in-kernel walk saves the chain-prep launch (~7 us + its boundary) and the frames' round trip
+// through memory; it costs every workgroup ~2 us in front of its first store.  While the launch is absorbed by the Infinity Cache
+// that is hidden -- whole step, same box, alternating (profiles/r06n_inline_vs_prep.txt, in-kernel walk / prep + emit): EUCM
+// 35 k images 110 / 121 us, 50 k 156 / 167, 75 k (1.6 GB) 231 / 241; Mei 40 k 151 / 159, 60 k 248 / 257 -- but once the launch streams
+// to DRAM the stores are latency bound and a workgroup that waits two microseconds before storing is bytes missing in flight:
+// 85 k images (1.8 GB) 301 / 279 us, 100 k 430 / 360.  Rounds 3-5 (before non-temporal stores, then before this A/B): 288 MB, 600 MB.
 int64_t inline_chain_max_bytes()
 {
     const long long h = vgi::debug_hook(vgi::kHookInlineChainMaxBytes);
-    return h ? (int64_t)h : (int64_t)600000000;
+    return h ? (int64_t)h : (int64_t)1650000000;
 }
 
 // Smallest output of a launch (bytes of residuals + Jacobian rows) that is written with non-temporal stores: everything that
