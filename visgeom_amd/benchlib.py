@@ -23,13 +23,23 @@ def emit_bytes_per_obs(model, L):
     return 32 + 16 * (KOF[model] + 6 * L)
 
 
-def timed(fn, reps):
-    """seconds per call: HIP events on torch's current stream (the stream the problems launch on) around `reps` calls"""
+def timed(fn, reps, warm_s=0.02):
+    """seconds per call: HIP events on torch's current stream (the stream the problems launch on) around `reps` calls, behind a
+    warm-up of at least max(3, reps / 10) calls AND `warm_s` seconds of them: the first ~10 ms of launches after a host-side pause
+    run up to 10 % slower (clock ramp; profiles/r06b_emit_ramp.txt: launches 8-16 of a 100 k-image series)"""
+    import time
+
     import torch
 
-    for _ in range(max(3, reps // 10)):
-        fn()
-    torch.cuda.synchronize()
+    n_warm, batch, t0 = 0, 4, time.perf_counter()
+    while n_warm < max(3, reps // 10) or time.perf_counter() - t0 < warm_s:
+        tb = time.perf_counter()
+        for _ in range(batch):
+            fn()
+        n_warm += batch
+        torch.cuda.synchronize()
+        if time.perf_counter() - tb < 1e-3 and batch < 256:   # keep the device busy between the host's looks at the clock
+            batch *= 2
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
@@ -73,18 +83,9 @@ def emit_sweep(d, model, sizes, device=0, reps=60):
 
         nbytes = n * N_CORNERS * emit_bytes_per_obs(model, 1)
         r = max(12, min(reps, int(60e9 / nbytes)))
-        # warm-up by TIME: the first ~10 ms of launches after the host-side set-up run up to 10 % slower (clock ramp: launches 8-16
-        # of a 100 k-image series, profiles/r06b_emit_ramp.txt) -- with 30 launches only, the first of the two measurements of a
-        # mid-size point (20 k - 25 k images) fell into it
-        import time as _time
-
+        # (timed() warms up by time: with a few launches only, the first of the two measurements of a mid-size point fell into the clock ramp)
         import torch
 
-        t0 = _time.perf_counter()
-        while _time.perf_counter() - t0 < 0.025:
-            for _ in range(10):
-                emit()
-            torch.cuda.synchronize()
         t_emit, t_step = timed(emit, r), timed(step, r)
         one = capi.load().vg_dataset_single_launch(p._h, ds) == 1
         out_mb = n * N_CORNERS * 16 * (K + 7) / 1e6
