@@ -128,6 +128,11 @@ int vgi::upload_corners(int device, void *hip_stream, int64_t n_images, int n_po
     }
     const int64_t per_chunk = (int64_t)(r.stage_half / per_image);
     if (per_chunk < 1) return fail(VG_ERR_INVALID_ARGUMENT, "a single image's corners exceed the staging buffer");
+    // whichever way this is left, nothing of the library's staging may still be on the bus when the next caller fills it
+    struct Drain {
+        hipStream_t st;
+        ~Drain() { (void)hipStreamSynchronize(st); }
+    } drain{st};
     bool used[2] = {false, false};
     int k = 0;
     for (int64_t first = 0; first < n_images; first += per_chunk, k ^= 1) {
@@ -139,7 +144,7 @@ int vgi::upload_corners(int device, void *hip_stream, int64_t n_images, int n_po
         VG_HIP(hipEventRecord(r.stage_done[k], st));
         used[k] = true;
     }
-    VG_HIP(hipStreamSynchronize(st));   // the staging is the library's: nothing of it may be in flight when the next caller fills it
+    VG_HIP(hipStreamSynchronize(st));
     *out = blk;
     return VG_OK;
 }
@@ -185,6 +190,15 @@ int vgi::refine_poses_resident(int device, void *hip_stream, int model, const do
     if (!d_intr) std::memcpy(r.pin + o_intr, h_intr, sizeof(double) * K);
     if (!d_board) std::memcpy(r.pin + o_board, h_board, sizeof(double) * 3 * N);
     std::memcpy(r.pin + o_poses, poses, sizeof(double) * 6 * n);
+    // from here on work that reads and writes the library's own blocks is queued: no way out of this function without draining it
+    struct Drain {
+        hipStream_t st;
+        bool armed;
+        ~Drain()
+        {
+            if (armed) (void)hipStreamSynchronize(st);
+        }
+    } drain{st, true};
     VG_HIP(hipMemcpyAsync(r.dev, r.pin, o_poses, hipMemcpyHostToDevice, st));   // counter, intrinsics, board: ONE small copy
     vg::PoseLmArgs a;
     a.board = d_board ? d_board : reinterpret_cast<const double *>(r.dev + o_board);
@@ -242,6 +256,7 @@ int vgi::refine_poses_resident(int device, void *hip_stream, int model, const do
     VG_HIP(hipGetLastError());
     if (kernel_seconds) VG_HIP(hipEventRecord(r.e1, st));
     VG_HIP(hipStreamSynchronize(st));   // the kernel's stores to the mapped block are visible once the stream is idle
+    drain.armed = false;
     std::memcpy(poses, r.pin + o_poses, sizeof(double) * 6 * n);
     if (iterations) std::memcpy(iterations, r.pin + o_it, sizeof(int) * n);
     if (final_cost) std::memcpy(final_cost, r.pin + o_cost, sizeof(double) * n);
