@@ -289,8 +289,10 @@ int vgi::refine_poses(int device, void *hip_stream, int model, const double *int
     const int rcs = refine_scratch_for(device, 0, obs_bytes);
     if (rcs != VG_OK) return rcs;
     VG_HIP(hipMemcpyAsync(g_refine.d_obs, corners, obs_bytes, hipMemcpyHostToDevice, reinterpret_cast<hipStream_t>(hip_stream)));
-    return refine_poses_resident(device, hip_stream, model, nullptr, intrinsics, n_points, nullptr, board, n_images, g_refine.d_obs, poses, options,
-                                 iterations, final_cost, termination, kernel_seconds, /*locked=*/true);
+    const int rc = refine_poses_resident(device, hip_stream, model, nullptr, intrinsics, n_points, nullptr, board, n_images, g_refine.d_obs, poses,
+                                         options, iterations, final_cost, termination, kernel_seconds, /*locked=*/true);
+    if (rc != VG_OK) (void)hipStreamSynchronize(reinterpret_cast<hipStream_t>(hip_stream));   // the corner upload reads the caller's array
+    return rc;
 }
 
 // the poses of a dataset that is resident in a finalized problem: its observations, its board and the camera's CURRENT
