@@ -329,7 +329,20 @@ __device__ __forceinline__ void emit_tile(const EmitArgs &a, const unsigned int 
             if (const unsigned int f = tid; f < nf) {
                 const long long bi = (long long)b_first + f;
                 const long long si = a.seq_index ? (long long)a.seq_index[bi] : a.first_block + bi;
+#ifdef VG_EMIT_REFERENCE_WALK   // A/B library: the reference-order walk of rounds 1-5 (~300 dependent instructions)
                 build_frame_single_direct(a.chain_params + a.chain_stride * si, fr_lds + f * a.frame_stride_d);
+#else
+                {   // The short walk of the Gram kernels (one sincos at the half angle, R12 = I, M12 from uhat^2 = u u^T - I: the
+                    // reference's frame to 1e-16; inside and just above its first-order branches it IS the reference-order
+                    // routine).  While <= 4 lanes walk, the tile's other 252 wait at the barrier below with no store in
+                    // flight: a third of the chain gone is 36.3 -> 34.1 us at 10 k images, 22.0 -> 19.8 at 5 k, 161 -> 152 at 50 k
+                    // (same box, alternating; profiles/r06q_emit_fastwalk_ab.txt).  The corner arithmetic stays in reference order.
+                    double xi_r[6];
+#pragma unroll
+                    for (int k = 0; k < 6; k++) xi_r[k] = (a.chain_params + a.chain_stride * si)[k];
+                    build_frame_single_direct_fast(xi_r, fr_lds + f * a.frame_stride_d);
+                }
+#endif
             }
         } else {
             const int n16 = (int)(nf * (unsigned)a.frame_stride_d) >> 1;
