@@ -54,7 +54,11 @@ __device__ __forceinline__ void pose_gram(const PoseLmArgs &a, unsigned int b, i
 {
     constexpr int K = CameraTraits<MODEL>::K;
     using d2 = HIP_vector_type<double, 2>;
+#ifdef VG_POSE_REFERENCE_WALK   // A/B library: the reference-order walk
     if (sl == 0) build_frame_single_direct(x, fr);
+#else
+    if (sl == 0) build_frame_single_direct_fast(x, fr);   // 31 lanes wait for this one: the short walk (vg_geometry.hpp), the frame to 1e-16
+#endif
     wave_lds_fence();
     double acc[kPoseE];
 #pragma unroll
