@@ -2,7 +2,7 @@
 tile is a launch-time choice of the host by output size (contiguous eighths per XCD up to 1.2 GB, windows of 8 x 16 tiles beyond):
 any map must be a bijection of the tiles, i.e. give the same rows bit for bit.  Here: (1) every window width through the hook on
 ragged tile counts -- whole windows, a partial last window, fewer tiles than one window, a tile count that is not a multiple of 8 --
-for the single-dataset and the merged launch; (2) a launch that is large enough (80 k images, 1.72 GB) to take the windowed map and
+for the single-dataset and the merged launch; (2) a launch that is large enough (100 k images, 2.15 GB) to take the windowed map and
 non-temporal stores BY ITSELF -- the route of the 100 k ... 1 M image rows of bench.py's emit_sweep -- held to the oracle on a strided
 subset of its blocks and, on all of them, to the rows the same images give in small launches (this one also runs on the production
 library, which has no hook)."""
@@ -82,7 +82,7 @@ def test_a_launch_beyond_1p2_GB_takes_the_windowed_map_and_still_equals_the_orac
 
     from visgeom_amd import CalibrationProblem, synthetic as S
 
-    n = 80000   # 80 000 x 96 x 224 B = 1.72 GB: windows (>= 1.2 GB) + non-temporal stores + chain prep (> 1.65 GB), chosen by the library
+    n = 100000   # 100 000 x 96 x 224 B = 2.15 GB: windows (>= 1.2 GB) + non-temporal stores + chain prep (> 2.0 GB), chosen by the library
     d = S.make_mono("eucm", n, 9)
     p = CalibrationProblem(0)
     cam = p.add_camera("eucm", d["init_intrinsics"])
@@ -104,7 +104,7 @@ def test_a_launch_beyond_1p2_GB_takes_the_windowed_map_and_still_equals_the_orac
                                              0, [6], [6], np.arange(pick.size), threads=4)
     R, JI, JM = res[pick].cpu().numpy(), ji[pick].cpu().numpy(), jm[0][pick].cpu().numpy()
     for k, b in enumerate(pick):
-        assert_block_parity(R[k], [JI[k], JM[k]], r_ref[k], [ji_ref[k], jm_ref[0][k]], d["corners"][b], "block %d of the 1.7 GB launch" % b)
+        assert_block_parity(R[k], [JI[k], JM[k]], r_ref[k], [ji_ref[k], jm_ref[0][k]], d["corners"][b], "block %d of the 2.15 GB launch" % b)
     # the same images in a small launch (contiguous eighths, plain stores, prepared frames forced): same bits
     lo, hi = 41000, 41900
     q = CalibrationProblem(0)

@@ -89,11 +89,13 @@ size_t emit_lds_bytes(bool want_jac, bool frames_lds, int N, int frame_stride)
 // that is hidden -- whole step, same box, alternating (profiles/r06n_inline_vs_prep.txt, in-kernel walk / prep + emit): EUCM
 // 35 k images 110 / 121 us, 50 k 156 / 167, 75 k (1.6 GB) 231 / 241; Mei 40 k 151 / 159, 60 k 248 / 257 -- but once the launch streams
 // to DRAM the stores are latency bound and a workgroup that waits two microseconds before storing is bytes missing in flight:
-// 85 k images (1.8 GB) 301 / 279 us, 100 k 430 / 360.  Rounds 3-5 (before non-temporal stores, then before this A/B): 288 MB, 600 MB.
+// 85 k images (1.8 GB) 301 / 279 us, 100 k 430 / 360.  With the short walk in the tile (profiles/r06s_inline_vs_prep_fastwalk.txt, another
+// box): 75 k 212 / 258, 85 k 239 / 304, 100 k 372 / 368, 150 k 556 / 549; Mei 70 k (1.9 GB) 306 / 315, 80 k 350 / 384 -- where the cache-assisted
+// range ends depends on the box; 2.0 GB sits between the two.  Rounds 3-5 (before non-temporal stores, then before these A/Bs): 288 MB, 600 MB.
 int64_t inline_chain_max_bytes()
 {
     const long long h = vgi::debug_hook(vgi::kHookInlineChainMaxBytes);
-    return h ? (int64_t)h : (int64_t)1650000000;
+    return h ? (int64_t)h : (int64_t)2000000000;
 }
 
 // Smallest output of a launch (bytes of residuals + Jacobian rows) that is written with non-temporal stores: everything that
